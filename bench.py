@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CSR SpMV (f64) at 10M x 10M / 140M nnz, 1/2/4/8 GPUs.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over the whole matrix with every input
+already resident in HBM: each rank runs the HIP kernel on its row range, then
+(N > 1) the y slices are all-gathered over RCCL so that every rank holds the
+complete y.  x is broadcast ONCE from rank 0 before the timed region (its time
+is reported as x_bcast_ms).  The matrix is fixed as N grows ("scaling":
+"strong").  value = 2*nnz / time per step, whole job.
+
+Rank 0 prints ONE JSON line.  `roofline` is computed from the ALGORITHMIC
+bytes of the rank-local launch (SURVEY.md section 8d:
+nnz*(8+4) + 4*(rows+1) + 8*ncols + 8*rows) and the launch's average duration
+measured with HIP events on the launch stream; `cpu_baseline` times the CPU
+oracle (single thread, like the reference) on the same matrix, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3],
+                    help="BASELINE config: 3 = 10Mx10M/140M nnz (headline), 2 = 1Mx1M/14M nnz")
+    ap.add_argument("--dist", default="banded", choices=["banded", "uniform"],
+                    help="column distribution: banded W=4096 (headline) or uniform (stress row)")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (tuning)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
+                     "(one process per GPU); see the module docstring")
+        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    import torch
+    import torch.distributed as dist
+    import spalinalg_amd as sp
+    from spalinalg_amd.dist import RowPartitionedSpmv, even_rows
+
+    if not torch.cuda.is_available() or sp.device_count() < 1:
+        sys.exit("bench.py needs a GPU: libspal_hip has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    cfg = sp.synth.CONFIGS[args.config]
+    nrows, ncols, per_row = cfg["nrows"], cfg["ncols"], cfg["per_row"]
+    window = cfg["window"] if args.dist == "banded" else ncols
+    np_dt = np.float64 if args.dtype == "f64" else np.float32
+    t_dt = torch.float64 if args.dtype == "f64" else torch.float32
+    esz = 8 if args.dtype == "f64" else 4
+    nnz = nrows * per_row
+
+    # ---- the rank's shard: rows [r0, r1), generated on the host, uploaded through the C ABI
+    bounds = even_rows(nrows, world)  # same entries in every row: even rows == even entries
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    t0 = time.time()
+    rp, ci, va = sp.synth.banded_csr(nrows, ncols, per_row, window, sp.synth.matrix_seed(args.config),
+                                     dtype=np_dt, rows=(r0, r1))
+    t_gen = time.time() - t0
+    t0 = time.time()
+    shard = sp.CsrMatrix._trusted(r1 - r0, ncols, rp, ci, va)   # generator output is valid by construction;
+    dev = shard.device(local_rank)                               # create() re-validates it anyway
+    t_upload = time.time() - t0
+    for kv in args.opt:
+        k, v = kv.split("=")
+        dev.set_option(k, int(v))
+    plan = dev.describe()
+
+    op = RowPartitionedSpmv.from_shard(dev, bounds, rank, world, device)
+
+    # ---- x: generated on rank 0, broadcast once over RCCL
+    if rank == 0:
+        x = torch.from_numpy(sp.synth.vector(ncols, dtype=np_dt)).to(device)
+    else:
+        x = torch.zeros(ncols, dtype=t_dt, device=device)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    tb = time.perf_counter()
+    op.broadcast_x(x)
+    torch.cuda.synchronize()
+    x_bcast_ms = (time.perf_counter() - tb) * 1e3 if world > 1 else 0.0
+    y = torch.empty(nrows, dtype=t_dt, device=device)
+
+    def step():
+        if world == 1:
+            dev.spmv_torch(x, out=y)       # y is the rank's (= the whole) slice
+        else:
+            op.spmv(x, y)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t_wall0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t_wall0) * 1e3
+    ev_ms = e0.elapsed_time(e1)
+    elapsed = torch.tensor([wall_ms if world > 1 else ev_ms], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    total_ms = float(elapsed.item())
+    ms_per_step = total_ms / args.steps
+
+    # ---- the dominant kernel alone (HIP events on the launch stream = torch's current stream)
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    y_loc = op.y_local[: r1 - r0]
+    for _ in range(3):
+        dev.spmv_torch(x, out=y_loc)
+    torch.cuda.synchronize()
+    k0.record()
+    for _ in range(args.steps):
+        dev.spmv_torch(x, out=y_loc)
+    k1.record()
+    torch.cuda.synchronize()
+    kern_ms = k0.elapsed_time(k1) / args.steps
+    kmax = torch.tensor([kern_ms], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+    kern_ms_max = float(kmax.item())
+
+    local_nnz = (r1 - r0) * per_row
+    local_bytes = sp.synth.spmv_bytes(local_nnz, r1 - r0, r1 - r0, ncols, esz)
+    whole_bytes = sp.synth.spmv_bytes(nnz, nrows, nrows, ncols, esz)
+    achieved = local_bytes / (kern_ms * 1e-3) / 1e9          # GB/s, this rank's launch
+    peak = sp.synth.HBM_PEAK_BYTES_PER_S / 1e9
+    gflops = sp.synth.spmv_flops(nnz) / (ms_per_step * 1e-3) / 1e9
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- a spot check so a wrong kernel cannot post a number (rows evaluated directly in numpy)
+    ycpu = y[r0:r0 + 4].cpu().numpy() if world == 1 else y[:4].cpu().numpy()
+    xh = sp.synth.vector(ncols, dtype=np_dt)
+    for r in range(4):
+        lo, hi = int(rp[r]), int(rp[r + 1])
+        ref = float(np.dot(va[lo:hi].astype(np.float64), xh[ci[lo:hi].astype(np.int64)].astype(np.float64)))
+        if abs(float(ycpu[r]) - ref) > (1e-10 if esz == 8 else 1e-4) * max(1.0, abs(ref)):
+            sys.exit(f"spot check failed at row {r}: {ycpu[r]} vs {ref}")
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            t = json.load(open(tpath))
+            key = f"config{args.config}_{args.dist}_{args.dtype}_n{world}"
+            traffic = t.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "CSR SpMV GFLOP/s (f64, 10Mx10M, 140M nnz)" if args.config == 3 and esz == 8
+                  else f"CSR SpMV GFLOP/s ({args.dtype}, config {args.config})",
+        "value": round(gflops, 3),
+        "unit": "GFLOP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 6),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": f"CsrMatrix {args.dtype} SpMV y=A*x, {nrows}x{ncols}, {per_row} nnz/row "
+                        f"({nnz} nnz), {args.dist} columns"
+                        + (f" W={window}" if args.dist == "banded" else "")
+                        + f" (BASELINE configs[{2 if args.config == 3 else 1}]), "
+                        + ("single GPU" if world == 1 else
+                           f"rows partitioned over {world} GPUs, x bcast once, y all-gather per step (RCCL)"),
+            "nrows": nrows, "ncols": ncols, "nnz": nnz, "index_bits": 32,
+            "partition": "none" if world == 1 else f"rows/{world}",
+            "plan": plan,
+        },
+        "achieved_hbm_pct": round(100.0 * whole_bytes / (ms_per_step * 1e-3) / (world * sp.synth.HBM_PEAK_BYTES_PER_S), 2),
+        "algorithmic_bytes_per_step": whole_bytes,
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 2),
+            "peak": peak,
+            "unit": "GB/s",
+            "frac": round(achieved / peak, 4),
+            "traffic": traffic,
+            "kernel": "csr_spmv_vector",
+            "kernel_ms": round(kern_ms, 6),
+            "kernel_ms_max_over_ranks": round(kern_ms_max, 6),
+            "algorithmic_bytes_per_launch": local_bytes,
+        },
+        "compute_only": {
+            "ms_per_step": round(kern_ms_max, 6),
+            "value": round(sp.synth.spmv_flops(nnz) / (kern_ms_max * 1e-3) / 1e9, 3),
+            "unit": "GFLOP/s",
+        },
+        "x_bcast_ms": round(x_bcast_ms, 4),
+        "setup_s": {"generate": round(t_gen, 2), "validate_narrow_upload_plan": round(t_upload, 2)},
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        import oracle  # CPU baseline leg only: the oracle is the thing timed here, never the product
+        rp32, ci32 = rp.astype(np.uint32), ci.astype(np.uint32)
+        yh = np.empty(nrows, dtype=np_dt)
+        oracle.csr_spmv_idx32(rp32, ci32, va, xh, yh)  # warm the pages
+        passes, t0 = 0, time.perf_counter()
+        while True:
+            oracle.csr_spmv_idx32(rp32, ci32, va, xh, yh)
+            passes += 1
+            el = time.perf_counter() - t0
+            if el >= args.cpu_seconds or passes >= 50:
+                break
+        out["cpu_baseline"] = {
+            "value": round(sp.synth.spmv_flops(nnz) * passes / el / 1e9, 4),
+            "unit": "GFLOP/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"{passes} full passes over the same {nrows}x{ncols} / {nnz}-nnz matrix in {el:.1f} s, "
+                      f"1 thread (the reference is single-threaded), 32-bit indices, gcc -O2 -ffp-contract=off; "
+                      f"host has {os.cpu_count()} logical cores",
+            "gpu_agrees_with_cpu": bool(np.allclose(y.cpu().numpy(), yh, rtol=1e-10 if esz == 8 else 1e-4,
+                                                    atol=1e-12 if esz == 8 else 1e-5)),
+        }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

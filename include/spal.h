@@ -1,0 +1,223 @@
+/*
+ * spal.h -- C ABI of libspal_hip.so: the MI355X (gfx950) SpMV / assembly path
+ * that sits underneath spalinalg's public CsrMatrix / CscMatrix / CooMatrix
+ * types (reference: lokyhark/spalinalg, paths below relative to its root).
+ *
+ * The reference has no FFI of its own; every entry point here
+ * names the reference interface it would be bound under.  The Rust-side
+ * binding a maintainer adds is shown in INTEGRATION.md and rust_shim/.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes only, no C++ types, no exceptions, no torch.
+ *  - `usize` of the reference == uint64_t here (x86-64 Linux).
+ *  - host arrays are BORROWED for the duration of the call; device copies are
+ *    owned by the opaque handle and released by *_destroy.
+ *  - every function returns a spal_status; on failure a thread-local message
+ *    is available from spal_last_error().  The reference's convention is to
+ *    panic on a contract violation (assert!, src/csr.rs:144-156); a binding
+ *    turns any non-zero status into panic!() to keep that behaviour.
+ *  - scalars: exactly the two `Scalar` impls, f32 and f64 (src/scalar.rs:56-57).
+ *  - there is NO CPU fallback: without a usable HIP device every compute
+ *    entry point fails with SPAL_ERR_NO_DEVICE / SPAL_ERR_HIP.
+ */
+#ifndef SPAL_H
+#define SPAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum spal_status {
+    SPAL_OK = 0,
+    SPAL_ERR_INVALID_ARGUMENT = 1, /* null pointer, x.len() != ncols (src/csr/ops/mul.rs:9) ... */
+    SPAL_ERR_INVARIANT = 2,        /* the reference constructor would panic (src/csr.rs:144-156) */
+    SPAL_ERR_HIP = 3,              /* a HIP runtime call failed */
+    SPAL_ERR_OUT_OF_MEMORY = 4,
+    SPAL_ERR_UNSUPPORTED = 5,      /* shape does not fit the device's 32-bit index format */
+    SPAL_ERR_NO_DEVICE = 6,
+    SPAL_ERR_INDEX_OUT_OF_BOUNDS = 7 /* COO entry outside the matrix (src/coo.rs:432-433) */
+} spal_status;
+
+/* Opaque device-resident matrices. */
+typedef struct spal_csr *spal_csr_t; /* mirrors CsrMatrix<T>, src/csr.rs:66-72 */
+typedef struct spal_csc *spal_csc_t; /* mirrors CscMatrix<T>, src/csc.rs:66-72 */
+typedef struct spal_coo *spal_coo_t; /* mirrors CooMatrix<T>, src/coo.rs:53-57 (SoA on device) */
+
+/* ---- library ---------------------------------------------------------- */
+const char *spal_last_error(void);   /* thread-local, never NULL */
+const char *spal_version(void);
+int spal_device_count(int *count);   /* 0 devices is SPAL_OK with *count = 0 */
+
+/* ---- host-side checks (no device needed) ------------------------------- */
+/* The assertions of CsrMatrix::new (src/csr.rs:144-156), in order.  On
+ * SPAL_ERR_INVARIANT *reason (may be NULL) receives the 1-based ordinal of
+ * the first assertion that fails:  1 nrows>0, 2 ncols>0, 3 rowptr.len()==
+ * nrows+1, 4 rowptr[0]==0, 5 colind.len()==rowptr[nrows], 6 values.len()==
+ * rowptr[nrows], 7 rowptr sorted, 8 colind in range, 9 colind strictly
+ * increasing inside each row. */
+int spal_csr_validate(uint64_t nrows, uint64_t ncols,
+                      const uint64_t *rowptr, uint64_t rowptr_len,
+                      const uint64_t *colind, uint64_t colind_len,
+                      uint64_t values_len, int *reason);
+/* CscMatrix::new (src/csc.rs:144-156): same ordinals with colptr / rowind. */
+int spal_csc_validate(uint64_t nrows, uint64_t ncols,
+                      const uint64_t *colptr, uint64_t colptr_len,
+                      const uint64_t *rowind, uint64_t rowind_len,
+                      uint64_t values_len, int *reason);
+/* Contiguous row ranges with balanced stored entries, for the row-partitioned
+ * multi-GPU product.  bounds has nparts+1 entries,
+ * bounds[0] = 0, bounds[nparts] = nrows, non-decreasing. */
+int spal_partition_rows(const uint64_t *rowptr, uint64_t nrows,
+                        uint32_t nparts, uint64_t *bounds);
+
+/* ---- CSR: y = A * x ------------------------------------------------------
+ * Replaces the reference's only route to A*x, `&a * &x_as_matrix`
+ * (`impl Mul for &CsrMatrix<T>`, src/csr/ops/mul.rs:5-59); bound as
+ * `impl Mul<&[T]> for &CsrMatrix<T>`.
+ * create: borrows rowptr()/colind()/values() (src/csr.rs:228-258), checks
+ * the constructor's invariants, narrows indices to 32 bits and uploads. */
+int spal_csr_create_f64(int device, uint64_t nrows, uint64_t ncols,
+                        const uint64_t *rowptr, uint64_t rowptr_len,
+                        const uint64_t *colind, uint64_t colind_len,
+                        const double *values, uint64_t values_len,
+                        spal_csr_t *out);
+int spal_csr_create_f32(int device, uint64_t nrows, uint64_t ncols,
+                        const uint64_t *rowptr, uint64_t rowptr_len,
+                        const uint64_t *colind, uint64_t colind_len,
+                        const float *values, uint64_t values_len,
+                        spal_csr_t *out);
+int spal_csr_destroy(spal_csr_t a);
+/* nrows()/ncols()/nnz() (src/csr.rs:200-222, :287-289); elem_size 4 or 8. */
+int spal_csr_shape(spal_csr_t a, uint64_t *nrows, uint64_t *ncols,
+                   uint64_t *nnz, int *elem_size);
+/* Host convenience: H2D x, kernel, D2H y.  x_len must equal ncols and y_len
+ * nrows (mirrors assert_eq! at src/csr/ops/mul.rs:9).  y is fully
+ * overwritten; rows without stored entries give 0.0. */
+int spal_csr_spmv_f64(spal_csr_t a, const double *x, uint64_t x_len,
+                      double *y, uint64_t y_len);
+int spal_csr_spmv_f32(spal_csr_t a, const float *x, uint64_t x_len,
+                      float *y, uint64_t y_len);
+/* Timed path: x (ncols) and y (nrows) are DEVICE pointers on the handle's
+ * device; the launch is enqueued on `stream` (a hipStream_t, NULL = the
+ * default stream) and not synchronised.  Safe to call concurrently on one
+ * handle (read-only). */
+int spal_csr_spmv_dev_f64(spal_csr_t a, const double *x_dev, double *y_dev,
+                          void *stream);
+int spal_csr_spmv_dev_f32(spal_csr_t a, const float *x_dev, float *y_dev,
+                          void *stream);
+/* Copies the device matrix back into caller arrays shaped like the
+ * reference's fields (rowptr nrows+1, colind nnz, values nnz). */
+int spal_csr_download_f64(spal_csr_t a, uint64_t *rowptr, uint64_t *colind,
+                          double *values);
+int spal_csr_download_f32(spal_csr_t a, uint64_t *rowptr, uint64_t *colind,
+                          float *values);
+/* Kernel plan knobs (tuning / tests).  Keys: "kernel" (0 = auto),
+ * "rows_per_block", "lanes_per_row", "lds_x" (-1 auto/0/1), "unroll", "threads".  Unknown key or
+ * a value the kernels are not instantiated for: SPAL_ERR_INVALID_ARGUMENT. */
+int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value);
+/* Writes a one-line JSON description of the active plan into buf. */
+int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len);
+
+/* ---- CSC: y = A * x (atomic scatter) --------------------------------------
+ * Replaces `&a * &x_as_matrix` for `impl Mul for &CscMatrix<T>`
+ * (src/csc/ops/mul.rs:5-60); bound as `impl Mul<&[T]> for &CscMatrix<T>`. */
+int spal_csc_create_f64(int device, uint64_t nrows, uint64_t ncols,
+                        const uint64_t *colptr, uint64_t colptr_len,
+                        const uint64_t *rowind, uint64_t rowind_len,
+                        const double *values, uint64_t values_len,
+                        spal_csc_t *out);
+int spal_csc_create_f32(int device, uint64_t nrows, uint64_t ncols,
+                        const uint64_t *colptr, uint64_t colptr_len,
+                        const uint64_t *rowind, uint64_t rowind_len,
+                        const float *values, uint64_t values_len,
+                        spal_csc_t *out);
+int spal_csc_destroy(spal_csc_t a);
+int spal_csc_shape(spal_csc_t a, uint64_t *nrows, uint64_t *ncols,
+                   uint64_t *nnz, int *elem_size);
+int spal_csc_spmv_f64(spal_csc_t a, const double *x, uint64_t x_len,
+                      double *y, uint64_t y_len);
+int spal_csc_spmv_f32(spal_csc_t a, const float *x, uint64_t x_len,
+                      float *y, uint64_t y_len);
+int spal_csc_spmv_dev_f64(spal_csc_t a, const double *x_dev, double *y_dev,
+                          void *stream);
+int spal_csc_spmv_dev_f32(spal_csc_t a, const float *x_dev, float *y_dev,
+                          void *stream);
+int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value);
+int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len);
+
+/* ---- COO -> CSR assembly on the device -------------------------------------
+ * Replaces `impl From<&CooMatrix<T>> for CsrMatrix<T>`
+ * (src/csr/conv/coo.rs:4-115): stable order by (row, col), duplicates summed
+ * left to right in insertion order, results equal to zero dropped.
+ * Triplets are passed as three arrays (Rust does not fix the layout of
+ * Vec<(usize, usize, T)>, so a binding unzips `coo.iter()`, src/coo.rs:491). */
+int spal_coo_upload_f64(int device, uint64_t nrows, uint64_t ncols, uint64_t len,
+                        const uint64_t *rows, const uint64_t *cols,
+                        const double *vals, spal_coo_t *out);
+int spal_coo_upload_f32(int device, uint64_t nrows, uint64_t ncols, uint64_t len,
+                        const uint64_t *rows, const uint64_t *cols,
+                        const float *vals, spal_coo_t *out);
+int spal_coo_destroy(spal_coo_t c);
+/* Device-resident assembly (the timed path): enqueues on `stream`, returns a
+ * new CSR handle.  Synchronises the stream once (the output size is data
+ * dependent). */
+int spal_coo_assemble_csr(spal_coo_t c, void *stream, spal_csr_t *out);
+/* One-call convenience: upload + assemble + free the COO copy. */
+int spal_coo_to_csr_f64(int device, uint64_t nrows, uint64_t ncols, uint64_t len,
+                        const uint64_t *rows, const uint64_t *cols,
+                        const double *vals, spal_csr_t *out);
+int spal_coo_to_csr_f32(int device, uint64_t nrows, uint64_t ncols, uint64_t len,
+                        const uint64_t *rows, const uint64_t *cols,
+                        const float *vals, spal_csr_t *out);
+
+/* ---- device memory helpers for callers without a HIP binding of their own
+ * (the Rust shim, ctypes tests, the C++ tools). ---------------------------- */
+int spal_dev_malloc(int device, size_t bytes, void **ptr);
+int spal_dev_free(int device, void *ptr);
+int spal_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes);
+int spal_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);
+int spal_device_synchronize(int device);
+
+/* ---- synthetic inputs of BASELINE.json's configs ---
+ * SplitMix64 based, bit-exact across implementations; host side, threaded.
+ * banded: every row has exactly `per_row` distinct sorted columns drawn from
+ * a window of `window` columns centred on the diagonal (window == ncols gives
+ * the uniform "stress" distribution); values in [-1, 1). */
+int spal_gen_banded_csr_f64(uint64_t nrows, uint64_t ncols, uint32_t per_row,
+                            uint64_t window, uint64_t seed, uint64_t *rowptr,
+                            uint64_t *colind, double *values);
+int spal_gen_banded_csr_f32(uint64_t nrows, uint64_t ncols, uint32_t per_row,
+                            uint64_t window, uint64_t seed, uint64_t *rowptr,
+                            uint64_t *colind, float *values);
+/* rows [row_begin, row_end) of the same matrix only (a rank's shard of the
+ * row-partitioned product); rowptr has row_end - row_begin + 1 entries and
+ * starts at 0. */
+int spal_gen_banded_csr_rows_f64(uint64_t nrows, uint64_t ncols, uint32_t per_row,
+                                 uint64_t window, uint64_t seed, uint64_t row_begin,
+                                 uint64_t row_end, uint64_t *rowptr,
+                                 uint64_t *colind, double *values);
+int spal_gen_banded_csr_rows_f32(uint64_t nrows, uint64_t ncols, uint32_t per_row,
+                                 uint64_t window, uint64_t seed, uint64_t row_begin,
+                                 uint64_t row_end, uint64_t *rowptr,
+                                 uint64_t *colind, float *values);
+/* sequential 2u-1 stream: x vectors */
+int spal_gen_vector_f64(uint64_t n, uint64_t seed, double *x);
+int spal_gen_vector_f32(uint64_t n, uint64_t seed, float *x);
+/* `len` uniform random triplets row=r()%nrows, col=r()%ncols, val=2u-1; then,
+ * deterministically, `dup_permille` per mille of the entries are overwritten
+ * by exact copies of an earlier entry's (row, col) and `cancel_permille` per
+ * mille by an earlier entry with the value negated. */
+int spal_gen_coo_f64(uint64_t nrows, uint64_t ncols, uint64_t len, uint64_t seed,
+                     uint32_t dup_permille, uint32_t cancel_permille,
+                     uint64_t *rows, uint64_t *cols, double *vals);
+int spal_gen_coo_f32(uint64_t nrows, uint64_t ncols, uint64_t len, uint64_t seed,
+                     uint32_t dup_permille, uint32_t cancel_permille,
+                     uint64_t *rows, uint64_t *cols, float *vals);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPAL_H */

@@ -1,0 +1,13 @@
+"""spalinalg_amd -- MI355X (gfx950) SpMV / assembly path for spalinalg.
+
+Host-side mirror of the reference's public types (`CsrMatrix`, `CscMatrix`,
+`CooMatrix`; reference src/lib.rs:16-19) over the C ABI of libspal_hip.so
+(include/spal.h).  The compute path is hand-written HIP only; there is no
+CPU fallback.
+"""
+from ._ffi import Panic, SpalError, device_count  # noqa: F401
+from .matrix import CooMatrix, CscMatrix, CsrMatrix, DeviceCsr, DeviceCsc  # noqa: F401
+from . import synth  # noqa: F401
+
+__all__ = ["CsrMatrix", "CscMatrix", "CooMatrix", "DeviceCsr", "DeviceCsc", "Panic",
+           "SpalError", "device_count", "synth"]

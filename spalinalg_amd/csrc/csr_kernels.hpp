@@ -1,0 +1,270 @@
+// csr_kernels.hpp -- gfx950 kernels for y = A*x with A in CSR (32-bit indices).
+//
+// Semantics follow the reference-derived contract (SURVEY.md section 8a-1,
+// reference src/csr/ops/mul.rs:25-45): y[i] = sum over the stored entries of
+// row i of values[p] * x[colind[p]]; rows without entries give 0.0.  The GPU
+// sums a row in a tree over L lanes (and may fuse mul+add), so results agree
+// with the sequential CPU order to rounding (<= 1e-10 relative, tested), not
+// bit for bit.
+//
+// The path is HBM-bandwidth bound (0.15 flop/byte): no MFMA.  What matters is
+//  - values / colind streamed once, coalesced, non-temporal;
+//  - the block's window of x staged in LDS so the gather never leaves the CU;
+//  - row blocks dealt to XCDs in contiguous runs so neighbouring windows share
+//    one L2;
+//  - enough independent loads in flight per wave (U row groups per iteration).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spal {
+
+constexpr int kWave = 64;
+
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the
+// blocks that share an XCD).  Map them so that each XCD owns one contiguous
+// run of row blocks: used for L2 locality only, never for correctness.
+__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t per_xcd) {
+    return (bid & 7u) * per_xcd + (bid >> 3);
+}
+
+template <typename T>
+__device__ __forceinline__ T load_stream(const T *p) {
+    return __builtin_nontemporal_load(p);
+}
+
+// Pins a loaded value so the compiler cannot sink its load into the (rarely
+// false) branch that consumes it; costs no instruction.
+__device__ __forceinline__ void keep_unconditional(double &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void keep_unconditional(float &v) { asm volatile("" : "+v"(v)); }
+
+// ---- reduction over the L lanes that share a row ----------------------------
+// DPP row shifts move data inside 16-lane rows without touching LDS; the two
+// steps that cross a 16-lane row (L = 32, 64) go through __shfl_down.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    int lo = (int)(uint32_t)u, hi = (int)(uint32_t)(u >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    int i = __builtin_bit_cast(int, v);
+    i = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(float, i);
+}
+// row_shl:n -- lane i receives lane i+n of its 16-lane row, 0.0 past the end
+constexpr int DPP_ROW_SHL(int n) { return 0x100 + n; }
+
+template <typename T, int L, bool USE_DPP>
+__device__ __forceinline__ T group_reduce(T v) {
+    if constexpr (USE_DPP) {
+        if constexpr (L >= 64) v += __shfl_down(v, 32, 64);
+        if constexpr (L >= 32) v += __shfl_down(v, 16, 32);
+        if constexpr (L >= 16) v += dpp_mov<DPP_ROW_SHL(8)>(v);
+        if constexpr (L >= 8) v += dpp_mov<DPP_ROW_SHL(4)>(v);
+        if constexpr (L >= 4) v += dpp_mov<DPP_ROW_SHL(2)>(v);
+        if constexpr (L >= 2) v += dpp_mov<DPP_ROW_SHL(1)>(v);
+    } else {
+#pragma unroll
+        for (int o = L / 2; o > 0; o >>= 1) v += __shfl_down(v, o, L);
+    }
+    return v;
+}
+
+// ---- per-block x window ------------------------------------------------------
+// desc[b] = {first column of the window, window length}; length 0 means the
+// window does not fit the LDS budget and the block gathers x from global.
+// All of a thread's loads are issued before the first LDS write so that the
+// staging costs one memory round trip, not one per 16 bytes.
+template <typename T, int BLOCK>
+__device__ __forceinline__ void stage_window(T *xw, const T *__restrict__ x, uint32_t cbase,
+                                             uint32_t wlen) {
+    constexpr uint32_t V = 16 / sizeof(T);  // elements per 16-byte load
+    const T *src = x + cbase;
+    if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+        using vec_t = __attribute__((ext_vector_type(4))) uint32_t;
+        const uint32_t nvec = wlen / V;
+        const vec_t *s4 = reinterpret_cast<const vec_t *>(src);
+        vec_t *d4 = reinterpret_cast<vec_t *>(xw);
+        constexpr uint32_t K = 4;
+        for (uint32_t i0 = threadIdx.x; i0 < nvec; i0 += K * BLOCK) {
+            vec_t t[K];
+#pragma unroll
+            for (uint32_t k = 0; k < K; ++k) {
+                const uint32_t i = i0 + k * BLOCK;
+                t[k] = s4[i < nvec ? i : i0];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < K; ++k) {
+                const uint32_t i = i0 + k * BLOCK;
+                if (i < nvec) d4[i] = t[k];
+            }
+        }
+        for (uint32_t i = nvec * V + threadIdx.x; i < wlen; i += BLOCK) xw[i] = src[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < wlen; i += BLOCK) xw[i] = src[i];
+    }
+}
+
+// ---- the "vector" kernel: L lanes per row ------------------------------------
+// One workgroup owns R consecutive rows.  Each wave walks its rows G = 64/L at
+// a time, U such groups ("a step" = G*U rows) per iteration.  Rows longer
+// than L loop.
+//
+// HBM latency under load is microseconds, so a wave must keep several KB of
+// loads in flight.  The row loop is software-pipelined by hand:
+//     step i+2: row pointers          (L2/L1 hits mostly)
+//     step i+1: colind + values       (the HBM stream)
+//     step i  : x gather from LDS, multiply, reduce, store
+// All loads are unconditional with clamped addresses (an idle lane re-reads a
+// neighbour's element: no extra traffic) so they issue back to back and the
+// compiler can wait with a counted vmcnt; idle lanes are masked by a select.
+template <int U>
+struct RowStep {
+    uint32_t p[U];  // this lane's first entry of its row
+    uint32_t e[U];  // one past the row's last entry (0: no row)
+};
+template <typename T, int U>
+struct EntryStep {
+    uint32_t c[U];
+    T v[U];
+};
+
+template <int L, int U>
+__device__ __forceinline__ RowStep<U> load_rows(const uint32_t *__restrict__ rowptr,
+                                                uint32_t base, uint32_t row1, uint32_t g,
+                                                uint32_t s) {
+    constexpr uint32_t G = kWave / L;
+    RowStep<U> o;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t r = base + u * G + g;
+        const uint32_t rc = min(r, row1 - 1);
+        const uint32_t a0 = rowptr[rc], a1 = rowptr[rc + 1];
+        o.p[u] = a0 + s;
+        o.e[u] = (r < row1) ? a1 : 0u;
+    }
+    return o;
+}
+
+template <typename T, int U>
+__device__ __forceinline__ EntryStep<T, U> load_entries(const uint32_t *__restrict__ colind,
+                                                        const T *__restrict__ vals,
+                                                        const RowStep<U> &rs, uint32_t last_nz) {
+    EntryStep<T, U> o;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t q = min(rs.p[u], last_nz);
+        o.c[u] = load_stream(colind + q);
+        o.v[u] = load_stream(vals + q);
+    }
+    return o;
+}
+
+template <typename T, int L, int U, bool INLDS, bool USE_DPP, int BLOCK>
+__device__ __forceinline__ void vector_rows(const uint32_t *__restrict__ rowptr,
+                                            const uint32_t *__restrict__ colind,
+                                            const T *__restrict__ vals, const T *__restrict__ x,
+                                            const T *xw, T *__restrict__ y, uint32_t row0,
+                                            uint32_t row1, uint32_t cbase, uint32_t last_nz) {
+    constexpr uint32_t G = kWave / L;
+    constexpr uint32_t NW = BLOCK / kWave;
+    constexpr uint32_t STRIDE = NW * G * U;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = threadIdx.x / kWave;
+    const uint32_t g = lane / L, s = lane % L;
+
+    uint32_t base = row0 + wave * (G * U);
+    if (base >= row1) return;  // wave-uniform
+    RowStep<U> rs = load_rows<L, U>(rowptr, base, row1, g, s);
+    EntryStep<T, U> es = load_entries<T, U>(colind, vals, rs, last_nz);
+    RowStep<U> rs_next = load_rows<L, U>(rowptr, base + STRIDE, row1, g, s);
+
+    for (;;) {
+        // step i+1: the stream; step i+2: its row pointers
+        EntryStep<T, U> es_next = load_entries<T, U>(colind, vals, rs_next, last_nz);
+        RowStep<U> rs_next2 = load_rows<L, U>(rowptr, base + 2 * STRIDE, row1, g, s);
+
+        // step i: all U gathers go out before the first product needs one
+        T acc[U], xv[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            live[u] = rs.p[u] < rs.e[u];
+            // an idle lane's clamped column may lie outside this block's window
+            const uint32_t cc = live[u] ? es.c[u] : cbase;
+            xv[u] = INLDS ? xw[cc - cbase] : x[cc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            keep_unconditional(xv[u]);
+            // select, not multiply by zero: an idle lane must not inject x's NaN/Inf
+            acc[u] = live[u] ? es.v[u] * xv[u] : T(0);
+        }
+        // rows with more than L entries
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            for (uint32_t q = rs.p[u] + L; q < rs.e[u]; q += L) {
+                const uint32_t cc = load_stream(colind + q);
+                const T vv = load_stream(vals + q);
+                const T xv = INLDS ? xw[cc - cbase] : x[cc];
+                acc[u] = __builtin_fma(vv, xv, acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = group_reduce<T, L, USE_DPP>(acc[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r = base + u * G + g;
+            if (s == 0 && r < row1) y[r] = acc[u];
+        }
+
+        base += STRIDE;
+        if (base >= row1) break;  // wave-uniform
+        rs = rs_next;
+        es = es_next;
+        rs_next = rs_next2;
+    }
+}
+
+template <typename T, int L, int U, bool LDSX, bool USE_DPP, int BLOCK>
+__global__ __launch_bounds__(BLOCK, 8) void csr_spmv_vector(
+    const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
+    const T *__restrict__ vals, const T *__restrict__ x, T *__restrict__ y,
+    const uint2 *__restrict__ desc, uint32_t nrows, uint32_t nnz, uint32_t R, uint32_t nblocks,
+    uint32_t per_xcd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
+    T *xw = reinterpret_cast<T *>(spal_smem);
+
+    const uint32_t b = xcd_contiguous_block(blockIdx.x, per_xcd);
+    if (b >= nblocks) return;
+    const uint32_t row0 = b * R;
+    const uint32_t row1 = min(row0 + R, nrows);
+    const uint32_t last_nz = nnz - 1;  // nnz >= 1 (the host never launches an empty matrix)
+
+    if constexpr (LDSX) {
+        const uint2 d = desc[b];  // block-uniform
+        if (d.y != 0) {
+            stage_window<T, BLOCK>(xw, x, d.x, d.y);
+            __syncthreads();
+            vector_rows<T, L, U, true, USE_DPP, BLOCK>(rowptr, colind, vals, x, xw, y, row0, row1,
+                                                       d.x, last_nz);
+            return;
+        }
+    }
+    vector_rows<T, L, U, false, USE_DPP, BLOCK>(rowptr, colind, vals, x, nullptr, y, row0, row1, 0u,
+                                                last_nz);
+}
+
+// y[i] = 0 for an all-empty matrix slice (nnz == 0): nothing to stream.
+template <typename T>
+__global__ void fill_zero(T *y, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = T(0);
+}
+
+}  // namespace spal

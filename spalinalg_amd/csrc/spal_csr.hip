@@ -1,0 +1,534 @@
+// spal_csr.hip -- CSR handle: create / plan / launch / download.
+// C ABI entry points documented in include/spal.h.
+#include "csr_kernels.hpp"
+#include "spal_internal.hpp"
+
+namespace spal {
+
+DeviceGuard::DeviceGuard(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        status = fail(SPAL_ERR_NO_DEVICE, "no HIP device available (%s)",
+                      e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return;
+    }
+    if (device < 0 || device >= count) {
+        status = fail(SPAL_ERR_INVALID_ARGUMENT, "device %d out of range (0..%d)", device, count - 1);
+        return;
+    }
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device) {
+        e = hipSetDevice(device);
+        if (e != hipSuccess) status = fail(SPAL_ERR_HIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    }
+}
+DeviceGuard::~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
+
+// ---- per-row-block column window ---------------------------------------------
+// Columns are strictly increasing inside a row (src/csr.rs:152-156), so a
+// row's first and last stored column bound it.  One workgroup per row block:
+// out[b] = {min first column, max last column + 1}, {0xffffffff, 0} if the
+// block stores nothing.
+__global__ __launch_bounds__(256) void csr_block_windows(
+    const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind, uint32_t nrows,
+    uint32_t R, uint2 *__restrict__ out) {
+    __shared__ uint32_t s_min, s_max;
+    if (threadIdx.x == 0) {
+        s_min = 0xffffffffu;
+        s_max = 0u;
+    }
+    __syncthreads();
+    const uint32_t row0 = blockIdx.x * R;
+    const uint32_t row1 = min(row0 + R, nrows);
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (uint32_t r = row0 + threadIdx.x; r < row1; r += 256) {
+        const uint32_t a0 = rowptr[r], a1 = rowptr[r + 1];
+        if (a0 < a1) {
+            lo = min(lo, colind[a0]);
+            hi = max(hi, colind[a1 - 1] + 1u);
+        }
+    }
+    atomicMin(&s_min, lo);
+    atomicMax(&s_max, hi);
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = make_uint2(s_min, s_max);
+}
+
+// ---- plan -------------------------------------------------------------------
+// LDS budget for the x window.  160 KiB per CU; 64 KiB per workgroup keeps two
+// 512-thread workgroups (16 waves) resident, smaller windows admit more.
+static constexpr uint32_t kLdsBudgetBytes = 64 * 1024;
+
+static int pick_lanes(double mean_row) {
+    int L = 2;
+    while (L < 64 && (double)L < mean_row) L <<= 1;
+    return L;
+}
+
+template <typename T, int L, int U, bool LDSX, int BLOCK>
+static hipError_t launch_vec(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    const CsrPlan &p = a->plan;
+    const uint32_t per_xcd = (p.nblocks + 7) / 8;
+    const size_t lds = LDSX ? (size_t)p.lds_entries * sizeof(T) : 0;
+    auto kern = csr_spmv_vector<T, L, U, LDSX, true, BLOCK>;
+    if (lds > 48 * 1024) {
+        // raise the dynamic-LDS cap once per kernel instance and device
+        static std::atomic<uint64_t> configured{0};
+        const uint64_t bit = 1ull << (a->device & 63);
+        if (!(configured.load(std::memory_order_relaxed) & bit)) {
+            hipError_t e = hipFuncSetAttribute((const void *)kern,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)kLdsBudgetBytes);
+            if (e != hipSuccess) return e;
+            configured.fetch_or(bit, std::memory_order_relaxed);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(BLOCK), lds, st, a->d_rowptr, a->d_colind,
+                       (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc, (uint32_t)a->nrows,
+                       (uint32_t)a->nnz, (uint32_t)p.rows_per_block, p.nblocks, per_xcd);
+    return hipGetLastError();
+}
+
+template <typename T, int L, int U, bool LDSX>
+static hipError_t launch_vec_block(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    return a->plan.threads == 1024 ? launch_vec<T, L, U, LDSX, 1024>(a, x, y, st)
+                                   : launch_vec<T, L, U, LDSX, 512>(a, x, y, st);
+}
+
+template <typename T, int L, int U>
+static hipError_t launch_vec_lds(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    return a->plan.lds_x ? launch_vec_block<T, L, U, true>(a, x, y, st)
+                         : launch_vec_block<T, L, U, false>(a, x, y, st);
+}
+
+template <typename T, int L>
+static hipError_t launch_vec_unroll(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    switch (a->plan.unroll) {
+        case 1: return launch_vec_lds<T, L, 1>(a, x, y, st);
+        case 2: return launch_vec_lds<T, L, 2>(a, x, y, st);
+        case 4: return launch_vec_lds<T, L, 4>(a, x, y, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <typename T>
+static hipError_t launch_vec_lanes(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    switch (a->plan.lanes_per_row) {
+        case 2: return launch_vec_unroll<T, 2>(a, x, y, st);
+        case 4: return launch_vec_unroll<T, 4>(a, x, y, st);
+        case 8: return launch_vec_unroll<T, 8>(a, x, y, st);
+        case 16: return launch_vec_unroll<T, 16>(a, x, y, st);
+        case 32: return launch_vec_unroll<T, 32>(a, x, y, st);
+        case 64: return launch_vec_unroll<T, 64>(a, x, y, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream) {
+    if (a->nnz == 0) {
+        const uint64_t n = a->nrows;
+        if (a->elem_size == 8)
+            hipLaunchKernelGGL(fill_zero<double>, dim3((n + 255) / 256), dim3(256), 0, stream,
+                               (double *)y_dev, n);
+        else
+            hipLaunchKernelGGL(fill_zero<float>, dim3((n + 255) / 256), dim3(256), 0, stream,
+                               (float *)y_dev, n);
+        SPAL_HIP_TRY(hipGetLastError());
+        return SPAL_OK;
+    }
+    hipError_t e = a->elem_size == 8 ? launch_vec_lanes<double>(a, x_dev, y_dev, stream)
+                                     : launch_vec_lanes<float>(a, x_dev, y_dev, stream);
+    if (e != hipSuccess)
+        return fail(SPAL_ERR_HIP, "csr spmv launch failed: %s", hipGetErrorString(e));
+    return SPAL_OK;
+}
+
+// Chooses lanes per row, rows per block and whether the x window goes through
+// LDS, then builds the per-block window table on the device.
+int csr_plan_build(spal_csr *a) {
+    CsrPlan &p = a->plan;
+    p.kernel = 1;
+    const double mean = a->nrows ? (double)a->nnz / (double)a->nrows : 0.0;
+    if (!p.user_lanes) p.lanes_per_row = pick_lanes(mean);
+    if (!p.user_unroll) p.unroll = 4;
+    if (!p.user_threads) p.threads = 1024;
+    if (a->d_desc) {
+        SPAL_HIP_TRY(hipFree(a->d_desc));
+        a->d_desc = nullptr;
+    }
+    if (a->nnz == 0) {
+        p.rows_per_block = 1024;
+        p.nblocks = (uint32_t)((a->nrows + 1023) / 1024);
+        p.lds_x = 0;
+        return SPAL_OK;
+    }
+    const uint32_t budget = kLdsBudgetBytes / (uint32_t)a->elem_size;  // elements
+    const uint32_t valign = 16u / (uint32_t)a->elem_size;
+    const uint32_t cand_all[] = {4096, 2048, 1024, 512};
+    std::vector<uint32_t> cands;
+    if (p.user_rows_per_block) cands.push_back((uint32_t)p.rows_per_block);
+    else cands.assign(cand_all, cand_all + 4);
+
+    std::vector<uint2> best_desc;
+    uint32_t best_R = 0, best_cap = 0;
+    double best_frac = -1.0;
+    const bool want_lds = p.user_lds ? p.lds_x != 0 : true;
+    for (uint32_t R : cands) {
+        const uint32_t nb = (uint32_t)((a->nrows + R - 1) / R);
+        uint2 *d_win = nullptr;
+        SPAL_HIP_TRY(hipMalloc(&d_win, (size_t)nb * sizeof(uint2)));
+        hipLaunchKernelGGL(csr_block_windows, dim3(nb), dim3(256), 0, a->stream, a->d_rowptr,
+                           a->d_colind, (uint32_t)a->nrows, R, d_win);
+        std::vector<uint2> win(nb);
+        hipError_t e = hipMemcpyAsync(win.data(), d_win, (size_t)nb * sizeof(uint2),
+                                      hipMemcpyDeviceToHost, a->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
+        (void)hipFree(d_win);
+        SPAL_HIP_TRY(e);
+        uint64_t fit_rows = 0;
+        uint32_t cap = 0;
+        for (uint32_t b = 0; b < nb; ++b) {
+            uint2 w = win[b];
+            if (w.y == 0) {  // block stores nothing: trivially fits with an empty window
+                win[b] = make_uint2(0, 0);
+                fit_rows += std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
+                continue;
+            }
+            const uint32_t cb = w.x & ~(valign - 1);
+            const uint32_t len = w.y - cb;
+            if (want_lds && len <= budget) {
+                win[b] = make_uint2(cb, len);
+                cap = std::max(cap, len);
+                fit_rows += std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
+            } else {
+                win[b] = make_uint2(0, 0);
+            }
+        }
+        const double frac = (double)fit_rows / (double)a->nrows;
+        // prefer the largest R whose blocks (nearly) all fit; otherwise the best coverage
+        const bool good = frac >= 0.9;
+        if (best_R == 0 || (good && best_frac < 0.9) || (!good && best_frac < 0.9 && frac > best_frac)) {
+            best_R = R; best_frac = frac; best_cap = cap; best_desc.swap(win);
+        }
+        if (good) break;
+    }
+    p.rows_per_block = (int)best_R;
+    p.nblocks = (uint32_t)((a->nrows + best_R - 1) / best_R);
+    p.lds_row_fraction = best_frac;
+    // LDS only pays when most rows can use it; otherwise run without the
+    // allocation so more workgroups fit per CU.
+    const bool use_lds = want_lds && best_cap > 0 && (p.user_lds || best_frac >= 0.5);
+    p.lds_x = use_lds ? 1 : 0;
+    p.lds_entries = use_lds ? ((best_cap + valign - 1) & ~(valign - 1)) : 0;
+    if (!use_lds)
+        for (auto &d : best_desc) d = make_uint2(0, 0);
+    SPAL_HIP_TRY(hipMalloc(&a->d_desc, (size_t)p.nblocks * sizeof(uint2)));
+    SPAL_HIP_TRY(hipMemcpy(a->d_desc, best_desc.data(), (size_t)p.nblocks * sizeof(uint2),
+                           hipMemcpyHostToDevice));
+    return SPAL_OK;
+}
+
+static void csr_free(spal_csr *a) {
+    if (!a) return;
+    (void)hipFree(a->d_rowptr);
+    (void)hipFree(a->d_colind);
+    (void)hipFree(a->d_values);
+    (void)hipFree(a->d_desc);
+    (void)hipFree(a->d_x);
+    (void)hipFree(a->d_y);
+    if (a->stream) (void)hipStreamDestroy(a->stream);
+    delete a;
+}
+
+int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, uint64_t nnz,
+                     uint32_t *d_rowptr, uint32_t *d_colind, void *d_values, spal_csr **out) {
+    spal_csr *a = new spal_csr;
+    a->device = device;
+    a->elem_size = elem_size;
+    a->nrows = nrows; a->ncols = ncols; a->nnz = nnz;
+    a->d_rowptr = d_rowptr; a->d_colind = d_colind; a->d_values = d_values;
+    hipError_t e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        csr_free(a);
+        return fail(SPAL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    int st = csr_plan_build(a);
+    if (st != SPAL_OK) { csr_free(a); return st; }
+    *out = a;
+    return SPAL_OK;
+}
+
+template <typename T>
+static int csr_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t *rowptr,
+                      uint64_t rowptr_len, const uint64_t *colind, uint64_t colind_len,
+                      const T *values, uint64_t values_len, spal_csr_t *out) {
+    if (!out) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_create: out is NULL");
+    *out = nullptr;
+    if (!rowptr || (!colind && colind_len) || (!values && values_len))
+        return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_create: null array");
+    int reason = 0;
+    SPAL_TRY(spal_csr_validate(nrows, ncols, rowptr, rowptr_len, colind, colind_len, values_len, &reason));
+    const uint64_t nnz = rowptr[nrows];
+    if (nrows >= 0xffffffffull || ncols > 0xffffffffull || nnz > 0xffffffffull)
+        return fail(SPAL_ERR_UNSUPPORTED,
+                    "shape %llu x %llu with %llu entries does not fit 32-bit device indices",
+                    (unsigned long long)nrows, (unsigned long long)ncols, (unsigned long long)nnz);
+    DeviceGuard guard(device);
+    if (guard.status != SPAL_OK) return guard.status;
+
+    // narrow usize -> u32 on the host (threads), then one upload per array
+    std::vector<uint32_t> rp32(nrows + 1), ci32(nnz);
+    parallel_for(nrows + 1, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t i = b; i < e; ++i) rp32[i] = (uint32_t)rowptr[i];
+    });
+    parallel_for(nnz, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t i = b; i < e; ++i) ci32[i] = (uint32_t)colind[i];
+    });
+    uint32_t *d_rp = nullptr, *d_ci = nullptr;
+    void *d_v = nullptr;
+    auto cleanup = [&] { (void)hipFree(d_rp); (void)hipFree(d_ci); (void)hipFree(d_v); };
+    hipError_t e = hipMalloc(&d_rp, (nrows + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_ci, std::max<uint64_t>(nnz, 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_v, std::max<uint64_t>(nnz, 1) * sizeof(T));
+    if (e == hipSuccess) e = hipMemcpy(d_rp, rp32.data(), (nrows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz) e = hipMemcpy(d_ci, ci32.data(), nnz * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz) e = hipMemcpy(d_v, values, nnz * sizeof(T), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(e == hipErrorOutOfMemory ? SPAL_ERR_OUT_OF_MEMORY : SPAL_ERR_HIP,
+                    "spal_csr_create: upload failed: %s", hipGetErrorString(e));
+    }
+    spal_csr *a = nullptr;
+    int st = csr_adopt_device(device, (int)sizeof(T), nrows, ncols, nnz, d_rp, d_ci, d_v, &a);
+    if (st != SPAL_OK) { cleanup(); return st; }
+    *out = a;
+    return SPAL_OK;
+}
+
+template <typename T>
+static int csr_spmv_host(spal_csr_t a, const T *x, uint64_t x_len, T *y, uint64_t y_len) {
+    if (!a) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_spmv: handle is NULL");
+    if (a->elem_size != (int)sizeof(T))
+        return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_spmv: handle holds %s values",
+                    a->elem_size == 8 ? "f64" : "f32");
+    if (x_len != a->ncols)
+        return fail(SPAL_ERR_INVALID_ARGUMENT,
+                    "dimension mismatch: x.len() = %llu but ncols = %llu (assert_eq!, csr/ops/mul.rs:9)",
+                    (unsigned long long)x_len, (unsigned long long)a->ncols);
+    if (y_len != a->nrows)
+        return fail(SPAL_ERR_INVALID_ARGUMENT, "y.len() = %llu but nrows = %llu",
+                    (unsigned long long)y_len, (unsigned long long)a->nrows);
+    if (!x || !y) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_spmv: null vector");
+    DeviceGuard guard(a->device);
+    if (guard.status != SPAL_OK) return guard.status;
+    std::lock_guard<std::mutex> lock(a->mu);
+    if (!a->d_x) SPAL_HIP_TRY(hipMalloc(&a->d_x, a->ncols * sizeof(T)));
+    if (!a->d_y) SPAL_HIP_TRY(hipMalloc(&a->d_y, a->nrows * sizeof(T)));
+    SPAL_HIP_TRY(hipMemcpyAsync(a->d_x, x, a->ncols * sizeof(T), hipMemcpyHostToDevice, a->stream));
+    SPAL_TRY(csr_launch(a, a->d_x, a->d_y, a->stream));
+    SPAL_HIP_TRY(hipMemcpyAsync(y, a->d_y, a->nrows * sizeof(T), hipMemcpyDeviceToHost, a->stream));
+    SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
+    return SPAL_OK;
+}
+
+template <typename T>
+static int csr_spmv_dev(spal_csr_t a, const T *x_dev, T *y_dev, void *stream) {
+    if (!a) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_spmv_dev: handle is NULL");
+    if (a->elem_size != (int)sizeof(T))
+        return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_spmv_dev: handle holds %s values",
+                    a->elem_size == 8 ? "f64" : "f32");
+    if (!x_dev || !y_dev) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_spmv_dev: null vector");
+    int cur = -1;
+    SPAL_HIP_TRY(hipGetDevice(&cur));
+    if (cur != a->device) {
+        DeviceGuard guard(a->device);
+        if (guard.status != SPAL_OK) return guard.status;
+        return csr_launch(a, x_dev, y_dev, (hipStream_t)stream);
+    }
+    return csr_launch(a, x_dev, y_dev, (hipStream_t)stream);
+}
+
+template <typename T>
+static int csr_download(spal_csr_t a, uint64_t *rowptr, uint64_t *colind, T *values) {
+    if (!a || !rowptr) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_download: null argument");
+    if (a->elem_size != (int)sizeof(T))
+        return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_download: handle holds %s values",
+                    a->elem_size == 8 ? "f64" : "f32");
+    if (a->nnz && (!colind || !values))
+        return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_download: null array");
+    DeviceGuard guard(a->device);
+    if (guard.status != SPAL_OK) return guard.status;
+    std::vector<uint32_t> rp(a->nrows + 1), ci(a->nnz);
+    SPAL_HIP_TRY(hipMemcpy(rp.data(), a->d_rowptr, rp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (a->nnz) {
+        SPAL_HIP_TRY(hipMemcpy(ci.data(), a->d_colind, ci.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        SPAL_HIP_TRY(hipMemcpy(values, a->d_values, a->nnz * sizeof(T), hipMemcpyDeviceToHost));
+    }
+    for (uint64_t i = 0; i <= a->nrows; ++i) rowptr[i] = rp[i];
+    for (uint64_t i = 0; i < a->nnz; ++i) colind[i] = ci[i];
+    return SPAL_OK;
+}
+
+}  // namespace spal
+
+using namespace spal;
+
+extern "C" {
+
+int spal_device_count(int *count) {
+    if (!count) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_device_count: count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return SPAL_OK;
+}
+
+int spal_csr_create_f64(int device, uint64_t nrows, uint64_t ncols, const uint64_t *rowptr,
+                        uint64_t rowptr_len, const uint64_t *colind, uint64_t colind_len,
+                        const double *values, uint64_t values_len, spal_csr_t *out) {
+    return csr_create<double>(device, nrows, ncols, rowptr, rowptr_len, colind, colind_len, values,
+                              values_len, out);
+}
+int spal_csr_create_f32(int device, uint64_t nrows, uint64_t ncols, const uint64_t *rowptr,
+                        uint64_t rowptr_len, const uint64_t *colind, uint64_t colind_len,
+                        const float *values, uint64_t values_len, spal_csr_t *out) {
+    return csr_create<float>(device, nrows, ncols, rowptr, rowptr_len, colind, colind_len, values,
+                             values_len, out);
+}
+
+int spal_csr_destroy(spal_csr_t a) {
+    if (!a) return SPAL_OK;
+    DeviceGuard guard(a->device);
+    csr_free(a);
+    return SPAL_OK;
+}
+
+int spal_csr_shape(spal_csr_t a, uint64_t *nrows, uint64_t *ncols, uint64_t *nnz, int *elem_size) {
+    if (!a) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_shape: handle is NULL");
+    if (nrows) *nrows = a->nrows;
+    if (ncols) *ncols = a->ncols;
+    if (nnz) *nnz = a->nnz;
+    if (elem_size) *elem_size = a->elem_size;
+    return SPAL_OK;
+}
+
+int spal_csr_spmv_f64(spal_csr_t a, const double *x, uint64_t x_len, double *y, uint64_t y_len) {
+    return csr_spmv_host<double>(a, x, x_len, y, y_len);
+}
+int spal_csr_spmv_f32(spal_csr_t a, const float *x, uint64_t x_len, float *y, uint64_t y_len) {
+    return csr_spmv_host<float>(a, x, x_len, y, y_len);
+}
+int spal_csr_spmv_dev_f64(spal_csr_t a, const double *x_dev, double *y_dev, void *stream) {
+    return csr_spmv_dev<double>(a, x_dev, y_dev, stream);
+}
+int spal_csr_spmv_dev_f32(spal_csr_t a, const float *x_dev, float *y_dev, void *stream) {
+    return csr_spmv_dev<float>(a, x_dev, y_dev, stream);
+}
+int spal_csr_download_f64(spal_csr_t a, uint64_t *rowptr, uint64_t *colind, double *values) {
+    return csr_download<double>(a, rowptr, colind, values);
+}
+int spal_csr_download_f32(spal_csr_t a, uint64_t *rowptr, uint64_t *colind, float *values) {
+    return csr_download<float>(a, rowptr, colind, values);
+}
+
+int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
+    if (!a || !key) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_set_option: null argument");
+    DeviceGuard guard(a->device);
+    if (guard.status != SPAL_OK) return guard.status;
+    std::lock_guard<std::mutex> lock(a->mu);
+    CsrPlan saved = a->plan;
+    CsrPlan &p = a->plan;
+    if (!strcmp(key, "kernel")) {
+        if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "kernel must be 0 or 1");
+        if (value == 0) {
+            p.user_rows_per_block = p.user_lanes = p.user_lds = p.user_unroll = p.user_threads = false;
+        }
+    } else if (!strcmp(key, "rows_per_block")) {
+        if (value == 0) p.user_rows_per_block = false;
+        else if (value < 64 || value > 65536 || (value & (value - 1)))
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "rows_per_block must be a power of two in [64, 65536]");
+        else { p.rows_per_block = (int)value; p.user_rows_per_block = true; }
+    } else if (!strcmp(key, "lanes_per_row")) {
+        if (value == 0) p.user_lanes = false;
+        else if (value < 2 || value > 64 || (value & (value - 1)))
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "lanes_per_row must be one of 2,4,8,16,32,64");
+        else { p.lanes_per_row = (int)value; p.user_lanes = true; }
+    } else if (!strcmp(key, "lds_x")) {
+        if (value < -1 || value > 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "lds_x must be -1 (auto), 0 or 1");
+        if (value < 0) p.user_lds = false;
+        else { p.lds_x = (int)value; p.user_lds = true; }
+    } else if (!strcmp(key, "unroll")) {
+        if (value == 0) p.user_unroll = false;
+        else if (value != 1 && value != 2 && value != 4)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "unroll must be 1, 2 or 4");
+        else { p.unroll = (int)value; p.user_unroll = true; }
+    } else if (!strcmp(key, "threads")) {
+        if (value == 0) p.user_threads = false;
+        else if (value != 512 && value != 1024)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "threads must be 512 or 1024");
+        else { p.threads = (int)value; p.user_threads = true; }
+    } else {
+        return fail(SPAL_ERR_INVALID_ARGUMENT, "unknown option '%s'", key);
+    }
+    int st = csr_plan_build(a);
+    if (st != SPAL_OK) { a->plan = saved; (void)csr_plan_build(a); }
+    return st;
+}
+
+int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
+    if (!a || !buf || !buf_len) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_describe: null argument");
+    const CsrPlan &p = a->plan;
+    snprintf(buf, buf_len,
+             "{\"format\": \"csr\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"nnz\": %llu, "
+             "\"index_bits\": 32, \"kernel\": \"vector\", \"lanes_per_row\": %d, \"unroll\": %d, "
+             "\"rows_per_block\": %d, \"blocks\": %u, \"threads_per_block\": %d, \"lds_x\": %d, "
+             "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f}",
+             a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
+             (unsigned long long)a->ncols, (unsigned long long)a->nnz, p.lanes_per_row, p.unroll,
+             p.rows_per_block, p.nblocks, p.threads, p.lds_x,
+             (unsigned long long)p.lds_entries * (unsigned long long)a->elem_size, p.lds_row_fraction);
+    return SPAL_OK;
+}
+
+// ---- device memory helpers ---------------------------------------------------
+int spal_dev_malloc(int device, size_t bytes, void **ptr) {
+    if (!ptr) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_dev_malloc: ptr is NULL");
+    *ptr = nullptr;
+    DeviceGuard guard(device);
+    if (guard.status != SPAL_OK) return guard.status;
+    SPAL_HIP_TRY(hipMalloc(ptr, bytes ? bytes : 1));
+    return SPAL_OK;
+}
+int spal_dev_free(int device, void *ptr) {
+    if (!ptr) return SPAL_OK;
+    DeviceGuard guard(device);
+    if (guard.status != SPAL_OK) return guard.status;
+    SPAL_HIP_TRY(hipFree(ptr));
+    return SPAL_OK;
+}
+int spal_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes) {
+    if (bytes && (!dst_dev || !src_host)) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_memcpy_h2d: null pointer");
+    DeviceGuard guard(device);
+    if (guard.status != SPAL_OK) return guard.status;
+    if (bytes) SPAL_HIP_TRY(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return SPAL_OK;
+}
+int spal_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes) {
+    if (bytes && (!dst_host || !src_dev)) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_memcpy_d2h: null pointer");
+    DeviceGuard guard(device);
+    if (guard.status != SPAL_OK) return guard.status;
+    if (bytes) SPAL_HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return SPAL_OK;
+}
+int spal_device_synchronize(int device) {
+    DeviceGuard guard(device);
+    if (guard.status != SPAL_OK) return guard.status;
+    SPAL_HIP_TRY(hipDeviceSynchronize());
+    return SPAL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+// spal_internal.hpp -- shared declarations of libspal_hip.so (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/spal.h"
+
+namespace spal {
+
+// ---- thread-local error message -------------------------------------------
+std::string &last_error_ref();
+int fail(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define SPAL_HIP_TRY(expr)                                                          \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess) {                                                     \
+            int st_ = (e_ == hipErrorOutOfMemory) ? SPAL_ERR_OUT_OF_MEMORY          \
+                      : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice)     \
+                          ? SPAL_ERR_NO_DEVICE                                      \
+                          : SPAL_ERR_HIP;                                           \
+            return ::spal::fail(st_, "%s failed: %s (%s:%d)", #expr,                \
+                                hipGetErrorString(e_), __FILE__, __LINE__);         \
+        }                                                                           \
+    } while (0)
+
+#define SPAL_TRY(expr)                    \
+    do {                                  \
+        int st_ = (expr);                 \
+        if (st_ != SPAL_OK) return st_;   \
+    } while (0)
+
+// Selects `device` for the calling thread, restores the previous one on exit.
+struct DeviceGuard {
+    int prev = -1;
+    int status = SPAL_OK;
+    explicit DeviceGuard(int device);
+    ~DeviceGuard();
+};
+
+// ---- host helpers ------------------------------------------------------------
+unsigned host_threads();
+// fn(begin, end, tid) over [0, n) split into contiguous chunks, one per thread.
+void parallel_for(uint64_t n, const std::function<void(uint64_t, uint64_t, unsigned)> &fn,
+                  uint64_t min_chunk = 1u << 16);
+
+// Compressed-format invariants (src/csr.rs:144-156); reason ordinal or 0.
+int compressed_validate(uint64_t nrows, uint64_t ncols, bool major_is_rows,
+                        const uint64_t *ptr, uint64_t ptr_len, const uint64_t *ind,
+                        uint64_t ind_len, uint64_t val_len);
+const char *invariant_text(int reason, bool csr);
+
+// ---- device matrices ---------------------------------------------------------
+struct CsrPlan {
+    // kernel family: 1 = "vector" (L lanes per row, shuffle reduction, optional
+    // LDS-staged x window)
+    int kernel = 0;          // 0 = not planned yet
+    int lanes_per_row = 0;   // L in {2,4,8,16,32,64}
+    int unroll = 1;          // row groups in flight per wave iteration
+    int threads = 512;       // workgroup size: 512 or 1024
+    int rows_per_block = 0;  // R
+    int lds_x = 0;           // stage the block's x window in LDS
+    uint32_t lds_entries = 0;  // LDS window capacity (elements) when lds_x
+    uint32_t nblocks = 0;
+    double lds_row_fraction = 0.0;  // rows whose block window fits
+    bool user_rows_per_block = false, user_lanes = false, user_lds = false,
+         user_unroll = false, user_threads = false;
+};
+
+}  // namespace spal
+
+// The opaque handle types of spal.h.
+struct spal_csr {
+    int device = 0;
+    int elem_size = 8;  // 8 = f64, 4 = f32
+    uint64_t nrows = 0, ncols = 0, nnz = 0;
+    uint32_t *d_rowptr = nullptr;  // nrows + 1
+    uint32_t *d_colind = nullptr;  // nnz
+    void *d_values = nullptr;      // nnz * elem_size
+    uint2 *d_desc = nullptr;       // per row block {window base column, window length or 0}
+    spal::CsrPlan plan;
+    // host-convenience staging (spal_csr_spmv_*): guarded by mu
+    std::mutex mu;
+    void *d_x = nullptr, *d_y = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+struct spal_csc {
+    int device = 0;
+    int elem_size = 8;
+    uint64_t nrows = 0, ncols = 0, nnz = 0;
+    uint32_t *d_colptr = nullptr;  // ncols + 1
+    uint32_t *d_rowind = nullptr;  // nnz
+    void *d_values = nullptr;
+    int kernel = 0;
+    int lanes_per_col = 0;
+    std::mutex mu;
+    void *d_x = nullptr, *d_y = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+struct spal_coo {
+    int device = 0;
+    int elem_size = 8;
+    uint64_t nrows = 0, ncols = 0, len = 0;
+    uint32_t *d_rows = nullptr, *d_cols = nullptr;
+    void *d_vals = nullptr;
+};
+
+namespace spal {
+// implemented in spal_csr.hip
+int csr_plan_build(spal_csr *a);
+int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream);
+// builds a handle around device arrays it takes ownership of (used by the COO
+// assembly, which produces CSR directly on the device)
+int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols,
+                     uint64_t nnz, uint32_t *d_rowptr, uint32_t *d_colind,
+                     void *d_values, spal_csr **out);
+}  // namespace spal

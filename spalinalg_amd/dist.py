@@ -1,0 +1,100 @@
+"""Row-partitioned y = A*x over the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on
+ROCm, "gloo" in the CPU tests).  Rows are cut into contiguous ranges with
+balanced stored entries; every rank owns its range's CSR arrays and a full
+copy of x.  The exchange steps are exactly two:
+
+  broadcast_x : x from rank 0 to everyone          (once per x)
+  spmv        : local kernel on the rank's rows, then an all-gather of the y
+                slices so every rank ends with the complete y (= the next x of
+                an iterative method)
+
+There is no data-path collective inside the local product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check
+
+
+def partition_rows(rowptr: np.ndarray, nparts: int) -> np.ndarray:
+    """nnz-balanced contiguous row ranges (library: spal_partition_rows)."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.uint64)
+    bounds = np.empty(nparts + 1, dtype=np.uint64)
+    check(_ffi.lib().spal_partition_rows(rowptr.ctypes.data_as(_ffi.u64p), C.c_uint64(rowptr.size - 1),
+                                         C.c_uint32(nparts), bounds.ctypes.data_as(_ffi.u64p)))
+    return bounds.astype(np.int64)
+
+
+def even_rows(nrows: int, nparts: int) -> np.ndarray:
+    """row ranges for a matrix with the same number of entries in every row"""
+    return np.array([(nrows * g) // nparts for g in range(nparts + 1)], dtype=np.int64)
+
+
+class RowPartitionedSpmv:
+    """The rank-local piece of a row-partitioned product.
+
+    local_spmv(x_full, out_local) computes this rank's rows; in the product it
+    is `DeviceCsr.spmv_torch` of the rank's shard (HIP kernel).  The CPU tests
+    inject the oracle here to exercise the partition / collective logic with
+    gloo -- the product itself never computes on the host.
+    """
+
+    def __init__(self, local_spmv, bounds, rank: int, world: int, dtype, device, group=None):
+        import torch
+        self.torch = torch
+        self.local_spmv = local_spmv
+        self.bounds = np.asarray(bounds, dtype=np.int64)
+        assert self.bounds.size == world + 1
+        self.rank, self.world = rank, world
+        self.group = group
+        self.nrows = int(self.bounds[-1])
+        self.r0, self.r1 = int(self.bounds[rank]), int(self.bounds[rank + 1])
+        sizes = np.diff(self.bounds)
+        self.max_rows = int(sizes.max())
+        self.equal = bool(np.all(sizes == sizes[0]))
+        self.y_local = torch.empty(self.max_rows, dtype=dtype, device=device)
+        self._gather = None if self.equal else torch.empty(world * self.max_rows, dtype=dtype, device=device)
+
+    @classmethod
+    def from_shard(cls, shard_dev, bounds, rank, world, device, group=None):
+        """shard_dev: DeviceCsr of rows [bounds[rank], bounds[rank+1])."""
+        import torch
+        tdt = torch.float64 if shard_dev.dtype == np.float64 else torch.float32
+        nloc = int(bounds[rank + 1] - bounds[rank])
+
+        def local(x_full, out_local):
+            shard_dev.spmv_torch(x_full, out=out_local[:nloc])
+
+        return cls(local, bounds, rank, world, tdt, device, group)
+
+    def broadcast_x(self, x):
+        """x: full-length vector on every rank; rank 0's content wins."""
+        if self.world > 1:
+            self.torch.distributed.broadcast(x, src=0, group=self.group)
+        return x
+
+    def local_only(self, x):
+        self.local_spmv(x, self.y_local)
+        return self.y_local[: self.r1 - self.r0]
+
+    def spmv(self, x, y_full):
+        """y_full (nrows, on every rank) = A * x."""
+        dist = self.torch.distributed
+        self.local_spmv(x, self.y_local)
+        if self.world == 1:
+            y_full.copy_(self.y_local[: self.nrows])
+            return y_full
+        if self.equal:
+            dist.all_gather_into_tensor(y_full, self.y_local, group=self.group)
+        else:
+            dist.all_gather_into_tensor(self._gather, self.y_local, group=self.group)
+            for g in range(self.world):
+                a, b = int(self.bounds[g]), int(self.bounds[g + 1])
+                y_full[a:b].copy_(self._gather[g * self.max_rows: g * self.max_rows + (b - a)])
+        return y_full

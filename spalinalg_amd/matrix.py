@@ -1,0 +1,386 @@
+"""Host-side mirror of the reference's matrix types over the C ABI.
+
+Names, argument meaning and error behaviour follow the reference
+(lokyhark/spalinalg; paths relative to its root):
+
+* ``CsrMatrix(nrows, ncols, rowptr, colind, values)``  == ``CsrMatrix::new``
+  (src/csr.rs:137-164) incl. its panics (-> :class:`Panic`),
+  ``nrows()/ncols()/rowptr()/colind()/values()/nnz()`` (src/csr.rs:200-289).
+* ``a * x`` / ``a @ x`` with a dense vector: the product the reference only
+  reaches through ``&a * &x_as_matrix`` (src/csr/ops/mul.rs:5-59); what a Rust
+  binding adds as ``impl Mul<&[T]> for &CsrMatrix<T>``.
+* ``CsrMatrix.from_coo(coo)`` == ``CsrMatrix::from(&coo)``
+  (src/csr/conv/coo.rs:3-116), assembled on the device.
+* ``CscMatrix`` / ``CooMatrix`` likewise (src/csc.rs, src/coo.rs).
+
+Host arrays stay numpy (``uint64`` indices like ``usize``, ``float64`` /
+``float32`` values like the two ``Scalar`` impls); a device copy is created
+on first use and owned by the :class:`DeviceCsr` / :class:`DeviceCsc` handle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import Panic, check, f32p, f64p, u64, u64p, vp
+
+
+def _scalar_dtype(values) -> np.dtype:
+    dt = np.asarray(values).dtype
+    if dt == np.float32:
+        return np.dtype(np.float32)
+    if dt == np.float64 or dt.kind in "iub":
+        return np.dtype(np.float64)
+    raise TypeError("Scalar is implemented for f32 and f64 only (src/scalar.rs:56-57)")
+
+
+def _sfx(dt: np.dtype) -> str:
+    return "f64" if dt == np.float64 else "f32"
+
+
+def _idx(a) -> np.ndarray:
+    arr = np.asarray(a)
+    if arr.size and arr.dtype.kind not in "iu":
+        raise TypeError("indices must be integers (usize)")
+    if arr.size and arr.dtype.kind == "i" and (arr < 0).any():
+        raise Panic(_ffi.SPAL_ERR_INVALID_ARGUMENT, "negative index (usize cannot be negative)")
+    return np.ascontiguousarray(arr, dtype=np.uint64)
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as({np.dtype(np.uint64): u64p, np.dtype(np.float64): f64p,
+                             np.dtype(np.float32): f32p}[a.dtype])
+
+
+def _stream_ptr(stream) -> vp:
+    if stream is None:
+        return vp(0)
+    if isinstance(stream, int):
+        return vp(stream)
+    return vp(int(stream.cuda_stream))  # torch.cuda.Stream
+
+
+# --------------------------------------------------------------------------
+# device handles
+# --------------------------------------------------------------------------
+class _DeviceMatrix:
+    _kind = ""  # "csr" | "csc"
+
+    def __init__(self, handle, dtype: np.dtype, device: int):
+        self._h = handle
+        self.dtype = np.dtype(dtype)
+        self.device = device
+
+    def _fn(self, name):
+        return getattr(_ffi.lib(), f"spal_{self._kind}_{name}")
+
+    def close(self):
+        if self._h is not None:
+            self._fn("destroy")(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shape(self):
+        nr, nc, nz, es = u64(), u64(), u64(), C.c_int()
+        check(self._fn("shape")(self._h, C.byref(nr), C.byref(nc), C.byref(nz), C.byref(es)))
+        return nr.value, nc.value, nz.value
+
+    def set_option(self, key: str, value: int) -> None:
+        check(self._fn("set_option")(self._h, key.encode(), C.c_int64(value)))
+
+    def describe(self) -> dict:
+        buf = C.create_string_buffer(1024)
+        check(self._fn("describe")(self._h, buf, C.c_size_t(len(buf))))
+        return json.loads(buf.value.decode())
+
+    def spmv(self, x) -> np.ndarray:
+        """Host vectors in, host vector out (H2D x, kernel, D2H y)."""
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        nrows = self.shape()[0]
+        y = np.empty(nrows, dtype=self.dtype)
+        check(self._fn(f"spmv_{_sfx(self.dtype)}")(self._h, _p(x), u64(x.size), _p(y), u64(y.size)))
+        return y
+
+    def spmv_dev(self, x_ptr: int, y_ptr: int, stream=None) -> None:
+        """Device pointers; enqueued on `stream`, not synchronised."""
+        check(self._fn(f"spmv_dev_{_sfx(self.dtype)}")(self._h, vp(x_ptr), vp(y_ptr), _stream_ptr(stream)))
+
+    def spmv_torch(self, x, out=None):
+        """x, out: torch tensors on this handle's device; runs on torch's
+        current stream (so torch.cuda.Event brackets it)."""
+        import torch
+        nrows, ncols, _ = self.shape()
+        tdt = torch.float64 if self.dtype == np.float64 else torch.float32
+        if x.dtype != tdt or not x.is_cuda or not x.is_contiguous() or x.numel() != ncols:
+            raise Panic(_ffi.SPAL_ERR_INVALID_ARGUMENT,
+                        f"x must be a contiguous {tdt} device vector of length ncols = {ncols}")
+        if out is None:
+            out = torch.empty(nrows, dtype=tdt, device=x.device)
+        elif out.dtype != tdt or not out.is_cuda or not out.is_contiguous() or out.numel() != nrows:
+            raise Panic(_ffi.SPAL_ERR_INVALID_ARGUMENT,
+                        f"out must be a contiguous {tdt} device vector of length nrows = {nrows}")
+        self.spmv_dev(x.data_ptr(), out.data_ptr(), torch.cuda.current_stream(x.device))
+        return out
+
+
+class DeviceCsr(_DeviceMatrix):
+    _kind = "csr"
+
+    def download(self):
+        nrows, _, nnz = self.shape()
+        rp = np.empty(nrows + 1, dtype=np.uint64)
+        ci = np.empty(nnz, dtype=np.uint64)
+        va = np.empty(nnz, dtype=self.dtype)
+        check(self._fn(f"download_{_sfx(self.dtype)}")(self._h, _p(rp), _p(ci), _p(va)))
+        return rp, ci, va
+
+
+class DeviceCsc(_DeviceMatrix):
+    _kind = "csc"
+
+
+# --------------------------------------------------------------------------
+# CsrMatrix / CscMatrix
+# --------------------------------------------------------------------------
+class _Compressed:
+    _kind = ""
+    _dev_cls = _DeviceMatrix
+
+    def __init__(self, nrows, ncols, ptr, ind, values):
+        dt = _scalar_dtype(values)
+        self._nrows, self._ncols = int(nrows), int(ncols)
+        if self._nrows < 0 or self._ncols < 0:
+            raise Panic(_ffi.SPAL_ERR_INVALID_ARGUMENT, "negative dimension")
+        self._ptr, self._ind = _idx(ptr), _idx(ind)
+        self._values = np.ascontiguousarray(values, dtype=dt)
+        # the constructor's assertions, checked by the library's host code
+        reason = C.c_int(0)
+        check(getattr(_ffi.lib(), f"spal_{self._kind}_validate")(
+            u64(self._nrows), u64(self._ncols), _p(self._ptr), u64(self._ptr.size),
+            _p(self._ind), u64(self._ind.size), u64(self._values.size), C.byref(reason)))
+        self._dev = {}
+
+    @classmethod
+    def _trusted(cls, nrows, ncols, ptr, ind, values):
+        """struct-literal construction (what the reference's conversions do,
+        e.g. src/csr/conv/coo.rs:108-114): no validation."""
+        self = cls.__new__(cls)
+        self._nrows, self._ncols = int(nrows), int(ncols)
+        self._ptr, self._ind, self._values = ptr, ind, values
+        self._dev = {}
+        return self
+
+    # accessors (src/csr.rs:200-289)
+    def nrows(self) -> int:
+        return self._nrows
+
+    def ncols(self) -> int:
+        return self._ncols
+
+    def values(self) -> np.ndarray:
+        return self._values
+
+    def nnz(self) -> int:
+        return int(self._ptr[-1])
+
+    @property
+    def dtype(self) -> np.dtype:
+        return self._values.dtype
+
+    def device(self, device: int = 0):
+        """The device-resident copy (created on first use)."""
+        h = self._dev.get(device)
+        if h is None or h._h is None:
+            out = vp()
+            check(getattr(_ffi.lib(), f"spal_{self._kind}_create_{_sfx(self.dtype)}")(
+                C.c_int(device), u64(self._nrows), u64(self._ncols), _p(self._ptr),
+                u64(self._ptr.size), _p(self._ind), u64(self._ind.size), _p(self._values),
+                u64(self._values.size), C.byref(out)))
+            h = self._dev_cls(out, self.dtype, device)
+            self._dev[device] = h
+        return h
+
+    def _mul_vec(self, x):
+        x = np.asarray(x)
+        if x.ndim != 1:
+            raise TypeError("right-hand side must be a dense vector")
+        if x.shape[0] != self._ncols:
+            # assert_eq!(self.ncols(), rhs.nrows())  src/csr/ops/mul.rs:9
+            raise Panic(_ffi.SPAL_ERR_INVALID_ARGUMENT,
+                        f"assertion failed: ncols == x.len() (left: {self._ncols}, right: {x.shape[0]})")
+        return self.device().spmv(x.astype(self.dtype, copy=False))
+
+    def __mul__(self, x):
+        return self._mul_vec(x)
+
+    __matmul__ = __mul__
+
+
+class CsrMatrix(_Compressed):
+    """Compressed sparse row matrix (reference src/csr.rs:66-72)."""
+    _kind = "csr"
+    _dev_cls = DeviceCsr
+
+    @classmethod
+    def new(cls, nrows, ncols, rowptr, colind, values):
+        return cls(nrows, ncols, rowptr, colind, values)
+
+    @classmethod
+    def eye(cls, size: int, dtype=np.float64):
+        """src/csr.rs:179-189"""
+        if not size > 0:
+            raise Panic(_ffi.SPAL_ERR_INVARIANT, "assertion failed: size > 0")
+        idx = np.arange(size + 1, dtype=np.uint64)
+        return cls._trusted(size, size, idx, idx[:-1].copy(), np.ones(size, dtype=dtype))
+
+    def rowptr(self) -> np.ndarray:
+        return self._ptr
+
+    def colind(self) -> np.ndarray:
+        return self._ind
+
+    def row_slice(self, row_begin: int, row_end: int) -> "CsrMatrix":
+        """Rows [row_begin, row_end) as a CsrMatrix of their own (a row range of
+        a valid CSR matrix is a valid CSR matrix after rebasing rowptr):
+        the per-GPU shard of the row-partitioned product."""
+        a0, a1 = int(self._ptr[row_begin]), int(self._ptr[row_end])
+        return CsrMatrix._trusted(row_end - row_begin, self._ncols,
+                                  self._ptr[row_begin:row_end + 1] - np.uint64(a0),
+                                  self._ind[a0:a1], self._values[a0:a1])
+
+    @classmethod
+    def from_coo(cls, coo: "CooMatrix", device: int = 0) -> "CsrMatrix":
+        """`CsrMatrix::from(&coo)` (src/csr/conv/coo.rs:3-116) on the device."""
+        dev = coo.assemble_csr(device)
+        rp, ci, va = dev.download()
+        out = cls._trusted(coo.nrows(), coo.ncols(), rp, ci, va)
+        out._dev[device] = dev
+        return out
+
+    @classmethod
+    def from_(cls, coo, device: int = 0):
+        return cls.from_coo(coo, device)
+
+
+class CscMatrix(_Compressed):
+    """Compressed sparse column matrix (reference src/csc.rs:66-72)."""
+    _kind = "csc"
+    _dev_cls = DeviceCsc
+
+    @classmethod
+    def new(cls, nrows, ncols, colptr, rowind, values):
+        return cls(nrows, ncols, colptr, rowind, values)
+
+    def colptr(self) -> np.ndarray:
+        return self._ptr
+
+    def rowind(self) -> np.ndarray:
+        return self._ind
+
+
+# --------------------------------------------------------------------------
+# CooMatrix (host container; reference src/coo.rs:53-57)
+# --------------------------------------------------------------------------
+class CooMatrix:
+    """Coordinate format: insertion order is significant (duplicates are
+    summed in that order by the conversion)."""
+
+    def __init__(self, nrows: int, ncols: int, dtype=np.float64):
+        if not nrows > 0:
+            raise Panic(_ffi.SPAL_ERR_INVARIANT, "assertion failed: nrows > 0")   # src/coo.rs:105
+        if not ncols > 0:
+            raise Panic(_ffi.SPAL_ERR_INVARIANT, "assertion failed: ncols > 0")   # src/coo.rs:106
+        self._nrows, self._ncols = int(nrows), int(ncols)
+        self._dtype = np.dtype(dtype)
+        self._rows = np.empty(0, dtype=np.uint64)
+        self._cols = np.empty(0, dtype=np.uint64)
+        self._vals = np.empty(0, dtype=self._dtype)
+        self._pending = []  # pushed one by one since the last flush
+
+    @classmethod
+    def new(cls, nrows, ncols, dtype=np.float64):
+        return cls(nrows, ncols, dtype)
+
+    @classmethod
+    def with_capacity(cls, nrows, ncols, capacity, dtype=np.float64):
+        return cls(nrows, ncols, dtype)
+
+    @classmethod
+    def with_triplets(cls, nrows, ncols, rowind, colind, values):
+        """src/coo.rs:260-288"""
+        dt = _scalar_dtype(values)
+        self = cls(nrows, ncols, dt)
+        rows, cols = _idx(rowind), _idx(colind)
+        vals = np.ascontiguousarray(values, dtype=dt)
+        if rows.size != vals.size:
+            raise Panic(_ffi.SPAL_ERR_INVARIANT, "assertion failed: rowind.len() == values.len()")
+        if cols.size != vals.size:
+            raise Panic(_ffi.SPAL_ERR_INVARIANT, "assertion failed: colind.len() == values.len()")
+        if rows.size and int(rows.max()) >= self._nrows:
+            raise Panic(_ffi.SPAL_ERR_INDEX_OUT_OF_BOUNDS, "assertion failed: *row < nrows")
+        if cols.size and int(cols.max()) >= self._ncols:
+            raise Panic(_ffi.SPAL_ERR_INDEX_OUT_OF_BOUNDS, "assertion failed: *col < ncols")
+        self._rows, self._cols, self._vals = rows, cols, vals
+        return self
+
+    @classmethod
+    def with_entries(cls, nrows, ncols, entries, dtype=np.float64):
+        """src/coo.rs:204-221"""
+        entries = list(entries)
+        return cls.with_triplets(nrows, ncols, [e[0] for e in entries], [e[1] for e in entries],
+                                 np.array([e[2] for e in entries], dtype=dtype))
+
+    def push(self, row: int, col: int, value) -> None:
+        """src/coo.rs:431-435"""
+        if not (0 <= row < self._nrows):
+            raise Panic(_ffi.SPAL_ERR_INDEX_OUT_OF_BOUNDS, "assertion failed: row < self.nrows")
+        if not (0 <= col < self._ncols):
+            raise Panic(_ffi.SPAL_ERR_INDEX_OUT_OF_BOUNDS, "assertion failed: col < self.ncols")
+        self._pending.append((row, col, value))
+
+    def _flush(self):
+        if self._pending:
+            r, c, v = zip(*self._pending)
+            self._rows = np.concatenate([self._rows, np.array(r, dtype=np.uint64)])
+            self._cols = np.concatenate([self._cols, np.array(c, dtype=np.uint64)])
+            self._vals = np.concatenate([self._vals, np.array(v, dtype=self._dtype)])
+            self._pending = []
+
+    def nrows(self) -> int:
+        return self._nrows
+
+    def ncols(self) -> int:
+        return self._ncols
+
+    def length(self) -> int:
+        return self._rows.size + len(self._pending)
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    def triplets(self):
+        """(rows, cols, values) in insertion order (what `iter()` yields,
+        src/coo.rs:491-495, unzipped)."""
+        self._flush()
+        return self._rows, self._cols, self._vals
+
+    def iter(self):
+        r, c, v = self.triplets()
+        return zip(r.tolist(), c.tolist(), v.tolist())
+
+    def assemble_csr(self, device: int = 0) -> DeviceCsr:
+        r, c, v = self.triplets()
+        out = vp()
+        check(getattr(_ffi.lib(), f"spal_coo_to_csr_{_sfx(self._dtype)}")(
+            C.c_int(device), u64(self._nrows), u64(self._ncols), u64(v.size), _p(r), _p(c), _p(v),
+            C.byref(out)))
+        return DeviceCsr(out, self._dtype, device)

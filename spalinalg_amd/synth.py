@@ -1,0 +1,84 @@
+"""Synthetic inputs of BASELINE.json's configs.
+
+Thin wrappers over the library's host generators (`spal_gen_*`, SplitMix64
+based, bit-exact across implementations; tests/test_synth.py re-implements
+them in pure Python for small sizes).  Also the algorithmic byte / flop
+counts the roofline figures are built from.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, u64
+from .matrix import _p, _sfx
+
+SEED_X = 0xC0FFEE
+HBM_PEAK_BYTES_PER_S = 8.0e12  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def matrix_seed(cfg: int) -> int:
+    return 0x5EED0000 + cfg
+
+
+def banded_csr(nrows, ncols, per_row, window, seed, dtype=np.float64, rows=None):
+    """Exactly `per_row` distinct sorted columns per row, drawn from a window of
+    `window` columns centred on the diagonal (window == ncols: uniform).
+    rows=(begin, end) generates only that row range (rowptr rebased to 0)."""
+    dtype = np.dtype(dtype)
+    r0, r1 = (0, nrows) if rows is None else rows
+    n = r1 - r0
+    rp = np.empty(n + 1, dtype=np.uint64)
+    ci = np.empty(n * per_row, dtype=np.uint64)
+    va = np.empty(n * per_row, dtype=dtype)
+    check(getattr(_ffi.lib(), f"spal_gen_banded_csr_rows_{_sfx(dtype)}")(
+        u64(nrows), u64(ncols), C.c_uint32(per_row), u64(window), u64(seed), u64(r0), u64(r1),
+        _p(rp), _p(ci), _p(va)))
+    return rp, ci, va
+
+
+def vector(n, seed=SEED_X, dtype=np.float64):
+    dtype = np.dtype(dtype)
+    x = np.empty(n, dtype=dtype)
+    check(getattr(_ffi.lib(), f"spal_gen_vector_{_sfx(dtype)}")(u64(n), u64(seed), _p(x)))
+    return x
+
+
+def coo(nrows, ncols, length, seed, dup_permille=0, cancel_permille=0, dtype=np.float64):
+    dtype = np.dtype(dtype)
+    r = np.empty(length, dtype=np.uint64)
+    c = np.empty(length, dtype=np.uint64)
+    v = np.empty(length, dtype=dtype)
+    check(getattr(_ffi.lib(), f"spal_gen_coo_{_sfx(dtype)}")(
+        u64(nrows), u64(ncols), u64(length), u64(seed), C.c_uint32(dup_permille),
+        C.c_uint32(cancel_permille), _p(r), _p(c), _p(v)))
+    return r, c, v
+
+
+# BASELINE.json configs as concrete inputs
+CONFIGS = {
+    1: dict(kind="coo->csr", nrows=10_000, ncols=10_000, length=100_000, dup_permille=0,
+            cancel_permille=0, note="CPU-runnable reference case"),
+    2: dict(kind="csr", nrows=1_000_000, ncols=1_000_000, per_row=14, window=4096),
+    3: dict(kind="csr", nrows=10_000_000, ncols=10_000_000, per_row=14, window=4096),
+    4: dict(kind="csc", nrows=1_000_000, ncols=1_000_000, per_row=14, window=4096),
+    5: dict(kind="coo->csr", nrows=5_000_000, ncols=5_000_000, length=50_000_000,
+            dup_permille=10, cancel_permille=1),
+}
+
+
+def spmv_bytes(nnz, nptr, nrows, ncols, elem_size):
+    """Algorithmic bytes of one SpMV: values + 32-bit
+    indices once, 32-bit pointer array once, x once, y once."""
+    return nnz * (elem_size + 4) + 4 * (nptr + 1) + elem_size * ncols + elem_size * nrows
+
+
+def spmv_flops(nnz):
+    return 2 * nnz
+
+
+def assembly_bytes(length, nnz_out, nrows, elem_size=8):
+    """Lower bound for COO->CSR: (u32, u32, T) in, CSR out."""
+    return length * (8 + elem_size) + nnz_out * (4 + elem_size) + 4 * (nrows + 1)

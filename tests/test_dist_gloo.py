@@ -1,0 +1,69 @@
+"""world_size-2 (and 3) CPU test of the row-partitioned product's host logic:
+partition, x broadcast, y all-gather.  The local kernel is replaced by the
+oracle HERE (tests only) because there is no GPU in this container; on the GPU
+box bench.py runs the same class with the HIP kernel."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, equal, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import oracle
+    import spalinalg_amd as sp
+    from spalinalg_amd.dist import RowPartitionedSpmv, partition_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 3000 if equal else 3001
+        if equal:
+            rp, ci, va = sp.synth.banded_csr(n, n, 14, 256, 42)
+        else:
+            rng = np.random.default_rng(1)          # same on every rank
+            lens = rng.integers(0, 30, n)
+            rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+            ci = np.concatenate([np.sort(rng.choice(n, k, replace=False)) for k in lens]).astype(np.uint64)
+            va = rng.uniform(-1, 1, ci.size)
+        bounds = partition_rows(rp, world)
+        a = sp.CsrMatrix(n, n, rp, ci, va)
+        shard = a.row_slice(int(bounds[rank]), int(bounds[rank + 1]))
+
+        def local(x_full, out_local):          # oracle stands in for the HIP kernel (test only)
+            y = oracle.csr_spmv(shard.rowptr(), shard.colind(), shard.values(), x_full.numpy())
+            out_local[: y.size].copy_(torch.from_numpy(y))
+
+        op = RowPartitionedSpmv(local, bounds, rank, world, torch.float64, "cpu")
+        x = torch.from_numpy(sp.synth.vector(n)) if rank == 0 else torch.zeros(n, dtype=torch.float64)
+        op.broadcast_x(x)
+        y = torch.empty(n, dtype=torch.float64)
+        op.spmv(x, y)
+        y_ref = oracle.csr_spmv(rp, ci, va, sp.synth.vector(n))
+        q.put((rank, bool(np.array_equal(y.numpy(), y_ref)), op.equal, bounds.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,equal", [(2, True), (2, False), (3, False)])
+def test_row_partitioned_spmv_gloo(world, equal):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + world * 3 + int(equal)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, equal, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(o[0] for o in out) == list(range(world))
+    assert all(o[1] for o in out), "every rank must end with the complete, identical y"
+    assert all(o[2] == equal for o in out)
+    assert all(o[3] == out[0][3] for o in out)

@@ -1,0 +1,148 @@
+"""GPU parity: CSC scatter SpMV and device COO -> CSR assembly vs the oracle."""
+import numpy as np
+import pytest
+
+import spalinalg_amd as sp
+from tests.util import assert_spmv_close, random_csr
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- CSC ---------------------------------------------------------------------
+def test_csc_kat_g5(kats):
+    g = kats["G5_csc_mul"]
+    a = g["lhs"]
+    m = sp.CscMatrix(a["nrows"], a["ncols"], a["colptr"], a["rowind"], np.array(a["values"]))
+    for case in g["spmv"]:
+        assert (m * np.array(case["x"])).tolist() == case["y"]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_csc_random(oracle, dtype):
+    rng = np.random.default_rng(17)
+    for nr, nc in [(1, 1), (40, 30), (3000, 2000), (2000, 3000)]:
+        rp, ci, va = random_csr(rng, nr, nc, density=min(0.3, 10.0 / nc), dtype=dtype)
+        cp, ri, cv = oracle.transpose(nr, nc, rp, ci, va)
+        x = rng.uniform(-1, 1, nc).astype(dtype)
+        m = sp.CscMatrix(nr, nc, cp, ri, cv)
+        y = m * x
+        y_ref = oracle.csc_spmv(nr, cp, ri, cv, x)
+        bound = oracle.csr_abs_bound(rp, ci, va.astype(np.float64), x.astype(np.float64))
+        assert_spmv_close(y, y_ref, bound, 1e-10 if dtype == np.float64 else 1e-4)
+
+
+def test_csc_config4(oracle):
+    """BASELINE config 4: CSC of the config-2 matrix, 1M x 1M."""
+    n = 1_000_000
+    rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, sp.synth.matrix_seed(2))
+    cp, ri, cv = oracle.transpose(n, n, rp, ci, va)
+    x = sp.synth.vector(n)
+    m = sp.CscMatrix(n, n, cp, ri, cv)
+    y = m * x
+    y_ref = oracle.csc_spmv(n, cp, ri, cv, x)
+    assert_spmv_close(y, y_ref, oracle.csr_abs_bound(rp, ci, va, x), 1e-10)
+    with pytest.raises(sp.Panic):
+        m * np.ones(n - 1)
+
+
+# ---- COO -> CSR ----------------------------------------------------------------
+def assemble_and_compare(oracle, nrows, ncols, r, c, v):
+    coo = sp.CooMatrix.with_triplets(nrows, ncols, r, c, v)
+    csr = sp.CsrMatrix.from_coo(coo)
+    p, i, w = oracle.coo_to_csr(nrows, ncols, r, c, v)
+    assert np.array_equal(csr.rowptr(), p)
+    assert np.array_equal(csr.colind(), i)
+    # bit-exact: same order of additions as the reference
+    assert np.array_equal(csr.values().view(np.uint64 if v.dtype == np.float64 else np.uint32),
+                          w.view(np.uint64 if v.dtype == np.float64 else np.uint32))
+    return csr
+
+
+def test_coo_kat_g1(kats, oracle):
+    g = kats["G1_coo_to_csr"]
+    coo = sp.CooMatrix(g["nrows"], g["ncols"])
+    for r, c, v in zip(g["rows"], g["cols"], g["vals"]):
+        coo.push(r, c, v)
+    csr = sp.CsrMatrix.from_coo(coo)
+    assert csr.rowptr().tolist() == g["rowptr"]
+    assert csr.colind().tolist() == g["colind"]
+    assert csr.values().tolist() == g["values"]
+    # and the assembled matrix multiplies
+    assert (csr * np.array([1.0, 1.0, 1.0])).tolist() == [10.0, 5.0]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_coo_random_with_duplicates(oracle, dtype):
+    rng = np.random.default_rng(23)
+    for nr, nc, n in [(1, 1, 1), (1, 1, 50), (5, 7, 400), (100, 90, 5000), (70_000, 3, 200_000),
+                      (3, 70_000, 200_000), (5000, 5000, 300_000)]:
+        r = rng.integers(0, nr, n).astype(np.uint64)
+        c = rng.integers(0, nc, n).astype(np.uint64)
+        v = rng.uniform(-1, 1, n).astype(dtype)
+        v[rng.random(n) < 0.05] = 0.0
+        assemble_and_compare(oracle, nr, nc, r, c, v)
+
+
+def test_coo_order_of_duplicate_sums_and_zero_drop(oracle):
+    big = 2.0 ** 53
+    r = np.array([0, 0, 0, 1, 1, 2, 2, 2], dtype=np.uint64)
+    c = np.array([1, 1, 1, 0, 0, 2, 2, 2], dtype=np.uint64)
+    v = np.array([big, 1.0, 1.0, -0.0, 0.0, np.nan, 1.0, 2.0])
+    csr = assemble_and_compare(oracle, 3, 3, r, c, v)
+    assert csr.values()[0] == big           # (big + 1) + 1, not big + (1 + 1)
+    assert csr.nnz() == 2 and np.isnan(csr.values()[1])
+
+
+def test_coo_empty_and_all_cancelled(oracle):
+    coo = sp.CooMatrix(4, 4)
+    csr = sp.CsrMatrix.from_coo(coo)
+    assert csr.nnz() == 0 and csr.rowptr().tolist() == [0] * 5
+    assert (csr * np.ones(4)).tolist() == [0.0] * 4
+    r = np.array([1, 1, 3, 3], dtype=np.uint64)
+    c = np.array([2, 2, 0, 0], dtype=np.uint64)
+    v = np.array([1.5, -1.5, 2.0, -2.0])
+    csr = assemble_and_compare(oracle, 4, 4, r, c, v)
+    assert csr.nnz() == 0
+
+
+def test_coo_long_runs_and_skew(oracle):
+    """one (row, col) repeated 20000 times, and one row holding half of all
+    entries: the sort and the run sums must not depend on balance."""
+    rng = np.random.default_rng(5)
+    n = 60_000
+    r = rng.integers(0, 50, n).astype(np.uint64)
+    c = rng.integers(0, 4000, n).astype(np.uint64)
+    r[:30_000] = 7
+    r[30_000:50_000] = 9
+    c[30_000:50_000] = 11
+    v = rng.uniform(-1, 1, n)
+    assemble_and_compare(oracle, 50, 4000, r, c, v)
+
+
+def test_coo_out_of_bounds_panics():
+    with pytest.raises(sp.Panic):
+        sp.CooMatrix.with_triplets(2, 2, [0, 2], [0, 0], np.array([1.0, 2.0]))
+    coo = sp.CooMatrix(2, 2)
+    with pytest.raises(sp.Panic):
+        coo.push(0, 2, 1.0)
+
+
+def test_config1_coo_to_csr_then_spmv(oracle):
+    """BASELINE config 1: 10k x 10k, 100k random triplets -> CSR -> SpMV."""
+    cfg = sp.synth.CONFIGS[1]
+    r, c, v = sp.synth.coo(cfg["nrows"], cfg["ncols"], cfg["length"], sp.synth.matrix_seed(1))
+    csr = assemble_and_compare(oracle, cfg["nrows"], cfg["ncols"], r, c, v)
+    assert 99_000 < csr.nnz() <= 100_000
+    x = sp.synth.vector(cfg["ncols"])
+    y = csr * x
+    y_ref = oracle.csr_spmv(csr.rowptr(), csr.colind(), csr.values(), x)
+    assert_spmv_close(y, y_ref, oracle.csr_abs_bound(csr.rowptr(), csr.colind(), csr.values(), x), 1e-10)
+
+
+def test_config5_scaled_assembly(oracle):
+    """BASELINE config 5 generator (1 % duplicates, 0.1 % cancelling pairs) at
+    2M entries, bit-exact against the oracle."""
+    nr = nc = 200_000
+    r, c, v = sp.synth.coo(nr, nc, 2_000_000, sp.synth.matrix_seed(5), 10, 1)
+    csr = assemble_and_compare(oracle, nr, nc, r, c, v)
+    assert csr.nnz() < 2_000_000

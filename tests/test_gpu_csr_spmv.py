@@ -1,0 +1,181 @@
+"""GPU parity: CSR y = A*x through the C ABI vs the CPU oracle.
+
+Tolerance: f64 1e-10 relative (north_star), f32 1e-4; both normwise (inf
+norm) and componentwise against sum|a||x|."""
+import numpy as np
+import pytest
+
+import spalinalg_amd as sp
+from tests.util import assert_spmv_close, random_csr
+
+pytestmark = pytest.mark.gpu
+TOL = {np.dtype(np.float64): 1e-10, np.dtype(np.float32): 1e-4}
+
+
+def check(oracle, rp, ci, va, x, ncols, **opts):
+    a = sp.CsrMatrix(rp.size - 1, ncols, rp, ci, va)
+    dev = a.device()
+    for k, v in opts.items():
+        dev.set_option(k, v)
+    y = dev.spmv(x)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    bound = oracle.csr_abs_bound(rp, ci, va.astype(np.float64), np.nan_to_num(x.astype(np.float64), posinf=0, neginf=0))
+    assert y.dtype == va.dtype
+    assert_spmv_close(y, y_ref, bound, TOL[va.dtype])
+    return dev
+
+
+def test_reference_kat_vectors_g5(kats, oracle):
+    g = kats["G5_csc_mul"]
+    a = g["lhs"]
+    vals = np.array(a["values"])
+    rp, ci, rv = oracle.transpose(a["ncols"], a["nrows"], a["colptr"], a["rowind"], vals)
+    m = sp.CsrMatrix(a["nrows"], a["ncols"], rp, ci, rv)
+    for case in g["spmv"]:
+        y = m * np.array(case["x"])
+        assert y.tolist() == case["y"]          # small integers: exact
+    g8 = kats["G8_dok_matrix"]
+    m = sp.CsrMatrix(g8["nrows"], g8["ncols"], g8["rowptr"], g8["colind"], np.array(g8["values"]))
+    assert (m @ np.array([1.0, 2.0, 3.0])).tolist() == [21.0, 15.0]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(1, 1), (1, 50), (50, 1), (37, 41), (300, 200), (5000, 3000)])
+def test_random_small(oracle, dtype, shape):
+    rng = np.random.default_rng(hash(shape) % 2**32)
+    nr, nc = shape
+    rp, ci, va = random_csr(rng, nr, nc, density=min(0.2, 8.0 / nc), dtype=dtype)
+    x = rng.uniform(-1, 1, nc).astype(dtype)
+    check(oracle, rp, ci, va, x, nc)
+
+
+def test_empty_matrix_and_empty_rows(oracle):
+    rp = np.zeros(101, dtype=np.uint64)
+    a = sp.CsrMatrix(100, 7, rp, np.empty(0, dtype=np.uint64), np.empty(0))
+    y = a * np.ones(7)
+    assert y.tolist() == [0.0] * 100
+    # only the last row stores something
+    rp[-1] = 2
+    a = sp.CsrMatrix(100, 7, rp, [1, 5], np.array([2.0, 3.0]))
+    y = a * np.arange(7.0)
+    assert y[:-1].tolist() == [0.0] * 99 and y[-1] == 2.0 + 15.0
+
+
+@pytest.mark.parametrize("lanes", [2, 4, 8, 16, 32, 64])
+@pytest.mark.parametrize("unroll", [1, 2, 4])
+def test_every_lane_width_and_unroll(oracle, lanes, unroll):
+    """rows shorter, equal to and longer than L, incl. a 5000-entry row."""
+    rng = np.random.default_rng(lanes * 10 + unroll)
+    nr, nc = 3000, 6000
+    lens = lambda r: r.choice([0, 1, 2, 7, 14, 16, 17, 31, 33, 64, 65, 130, 700])
+    rp, ci, va = random_csr(rng, nr, nc, row_len=lens, empty_rows=0.0)
+    # append one very long row
+    long_cols = np.sort(rng.choice(nc, 5000, replace=False)).astype(np.uint64)
+    rp = np.concatenate([rp, [rp[-1] + 5000]]).astype(np.uint64)
+    ci = np.concatenate([ci, long_cols])
+    va = np.concatenate([va, rng.uniform(-1, 1, 5000)])
+    x = rng.uniform(-1, 1, nc)
+    for threads in (512, 1024):
+        for lds in (0, 1):
+            check(oracle, rp, ci, va, x, nc, lanes_per_row=lanes, unroll=unroll, threads=threads, lds_x=lds)
+
+
+@pytest.mark.parametrize("rows_per_block", [64, 512, 2048, 4096, 16384])
+def test_rows_per_block_and_window_fallback(oracle, rows_per_block):
+    """banded blocks use the LDS window; a few wide rows force the per-block
+    global-gather fallback inside the same launch."""
+    nr = nc = 40_000
+    rp, ci, va = sp.synth.banded_csr(nr, nc, 14, 1024, 99)
+    rng = np.random.default_rng(3)
+    # overwrite the column pattern of rows 10000..10009 with full-width rows
+    for r in range(10_000, 10_010):
+        lo = int(rp[r])
+        ci[lo:lo + 14] = np.sort(rng.choice(nc, 14, replace=False))
+    x = sp.synth.vector(nc)
+    dev = check(oracle, rp, ci, va, x, nc, rows_per_block=rows_per_block)
+    d = dev.describe()
+    assert d["rows_per_block"] == rows_per_block
+
+
+def test_nan_inf_in_x_stay_local(oracle):
+    """NaN / Inf in x reach exactly the rows that reference them (idle lanes
+    and clamped loads must not leak them)."""
+    nr = nc = 5000
+    rp, ci, va = sp.synth.banded_csr(nr, nc, 14, 256, 5)
+    x = sp.synth.vector(nc)
+    x[0] = np.nan
+    x[2500] = np.inf
+    x[4999] = -np.inf
+    a = sp.CsrMatrix(nr, nc, rp, ci, va)
+    for lanes in (4, 16, 64):
+        dev = a.device()
+        dev.set_option("lanes_per_row", lanes)
+        y = dev.spmv(x)
+        y_ref = oracle.csr_spmv(rp, ci, va, x)
+        assert np.array_equal(np.isnan(y), np.isnan(y_ref))
+        assert np.array_equal(np.isinf(y), np.isinf(y_ref))
+        ok = np.isfinite(y_ref)
+        np.testing.assert_allclose(y[ok], y_ref[ok], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("window", [4096, None])
+def test_config2_banded_and_uniform(oracle, dtype, window):
+    """BASELINE config 2: 1M x 1M, 14 per row; banded (headline) and uniform."""
+    n = 1_000_000
+    rp, ci, va = sp.synth.banded_csr(n, n, 14, window or n, sp.synth.matrix_seed(2), dtype=dtype)
+    x = sp.synth.vector(n, dtype=dtype)
+    dev = check(oracle, rp, ci, va, x, n)
+    d = dev.describe()
+    assert d["lds_x"] == (1 if window else 0)
+
+
+def test_dimension_mismatch_panics():
+    a = sp.CsrMatrix(2, 3, [0, 1, 3], [0, 1, 2], np.array([1.0, 2.0, 3.0]))
+    with pytest.raises(sp.Panic):
+        a * np.ones(2)
+    with pytest.raises(sp.Panic):
+        a.device().spmv(np.ones(4))
+
+
+def test_device_path_with_torch_stream(oracle):
+    """the timed entry point: device pointers + torch's current stream."""
+    torch = pytest.importorskip("torch")
+    n = 200_000
+    rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, 1234)
+    x = sp.synth.vector(n)
+    dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    xd = torch.from_numpy(x).cuda()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        yd = dev.spmv_torch(xd)
+        yd2 = dev.spmv_torch(xd)
+    s.synchronize()
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    np.testing.assert_allclose(yd.cpu().numpy(), y_ref, rtol=1e-10, atol=1e-13)
+    assert torch.equal(yd, yd2)        # deterministic run to run
+
+
+def test_full_size_config3_properties():
+    """BASELINE config 3 (10M x 10M, 140M nnz) at full size: checked through
+    size-independent properties (the oracle comparison lives in the smaller
+    tests): y for x = e (row sums), linearity, and determinism."""
+    torch = pytest.importorskip("torch")
+    n = 10_000_000
+    rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, sp.synth.matrix_seed(3))
+    dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
+    ones = torch.ones(n, dtype=torch.float64, device="cuda")
+    y1 = dev.spmv_torch(ones).cpu().numpy()
+    rowsum = va.reshape(n, 14).sum(axis=1)
+    np.testing.assert_allclose(y1, rowsum, rtol=0, atol=1e-13)
+    x = torch.from_numpy(sp.synth.vector(n)).cuda()
+    z = torch.from_numpy(sp.synth.vector(n, seed=77)).cuda()
+    ax, az = dev.spmv_torch(x), dev.spmv_torch(z)
+    comb = dev.spmv_torch(2.0 * x - 0.5 * z)
+    assert torch.allclose(comb, 2.0 * ax - 0.5 * az, rtol=0, atol=1e-12)
+    assert torch.equal(dev.spmv_torch(x), ax)
+    # spot rows against a direct numpy evaluation
+    xs = x.cpu().numpy()
+    for r in (0, 1, 4_999_999, 9_999_999):
+        lo, hi = int(rp[r]), int(rp[r + 1])
+        assert abs(float(ax[r]) - float(np.dot(va[lo:hi], xs[ci[lo:hi].astype(np.int64)]))) < 1e-13
