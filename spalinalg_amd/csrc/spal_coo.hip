@@ -356,7 +356,7 @@ static int coo_assemble_t(spal_coo *c, hipStream_t st, spal_csr **out) {
         SPAL_HIP_TRY(hipGetLastError());
         SPAL_HIP_TRY(hipStreamSynchronize(st));
         spal_csr *a = nullptr;
-        SPAL_TRY(csr_adopt_device(c->device, (int)sizeof(T), c->nrows, c->ncols, nnz,
+        SPAL_TRY(csr_adopt_device(c->device, (int)sizeof(T), c->nrows, c->ncols, nnz, nnz,
                                   rowptr.as<uint32_t>(), ocol.as<uint32_t>(), oval.p, &a));
         rowptr.release(); ocol.release(); oval.release();
         *out = a;
@@ -370,7 +370,7 @@ static int coo_assemble_t(spal_coo *c, hipStream_t st, spal_csr **out) {
     SPAL_HIP_TRY(hipMemsetAsync(rowptr.p, 0, (c->nrows + 1) * 4, st));
     SPAL_HIP_TRY(hipStreamSynchronize(st));
     spal_csr *a = nullptr;
-    SPAL_TRY(csr_adopt_device(c->device, (int)sizeof(T), c->nrows, c->ncols, 0,
+    SPAL_TRY(csr_adopt_device(c->device, (int)sizeof(T), c->nrows, c->ncols, 0, 0,
                               rowptr.as<uint32_t>(), ocol.as<uint32_t>(), oval.p, &a));
     rowptr.release(); ocol.release(); oval.release();
     *out = a;

@@ -58,14 +58,57 @@ __global__ __launch_bounds__(256) void csr_block_windows(
 }
 
 // ---- plan -------------------------------------------------------------------
-// LDS budget for the x window.  160 KiB per CU; 64 KiB per workgroup keeps two
-// 512-thread workgroups (16 waves) resident, smaller windows admit more.
+// LDS budget for the x window of the vector kernel.  160 KiB per CU; 64 KiB per
+// workgroup keeps two workgroups resident, smaller windows admit more.
 static constexpr uint32_t kLdsBudgetBytes = 64 * 1024;
+// stream kernel: 4 product strips (kStreamTileNnz each) + a window of at most
+// 40 KiB -> 72 KiB per workgroup (f64), two workgroups per CU.
+static constexpr uint32_t kStreamWindowBytes = 40 * 1024;
+
+// One thread per super-tile: every 64-row tile must fit the product strip.
+__global__ __launch_bounds__(256) void csr_stream_check(const uint32_t *__restrict__ rowptr,
+                                                        uint32_t nrows, uint32_t nblocks,
+                                                        uint32_t *__restrict__ ok) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint32_t row0 = b * kStreamRows, row1 = min(row0 + (uint32_t)kStreamRows, nrows);
+    uint32_t good = 1;
+    for (uint32_t r0 = row0; r0 < row1; r0 += kStreamTileRows) {
+        const uint32_t rl = min(r0 + (uint32_t)kStreamTileRows, row1);
+        const uint32_t n = rowptr[rl] - (rowptr[r0] & ~1u);
+        if (n > (uint32_t)kStreamTileNnz) good = 0;
+    }
+    ok[b] = good;
+}
+
+// One workgroup per super-tile: 16-bit columns relative to the window base.
+__global__ __launch_bounds__(256) void csr_encode_col16(const uint32_t *__restrict__ rowptr,
+                                                        const uint32_t *__restrict__ colind,
+                                                        const uint4 *__restrict__ desc,
+                                                        uint16_t *__restrict__ col16,
+                                                        uint32_t nrows) {
+    const uint4 d = desc[blockIdx.x];
+    if (d.z != kModeStream) return;
+    const uint32_t row0 = blockIdx.x * kStreamRows, row1 = min(row0 + (uint32_t)kStreamRows, nrows);
+    const uint32_t p0 = rowptr[row0], p1 = rowptr[row1];
+    for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256) col16[p] = (uint16_t)(colind[p] - d.x);
+}
 
 static int pick_lanes(double mean_row) {
     int L = 2;
     while (L < 64 && (double)L < mean_row) L <<= 1;
     return L;
+}
+
+template <typename K>
+static hipError_t raise_lds_cap(K kern, int device, size_t lds, std::atomic<uint64_t> &configured) {
+    if (lds <= 48 * 1024) return hipSuccess;
+    const uint64_t bit = 1ull << (device & 63);
+    if (configured.load(std::memory_order_relaxed) & bit) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       128 * 1024);
+    if (e == hipSuccess) configured.fetch_or(bit, std::memory_order_relaxed);
+    return e;
 }
 
 template <typename T, int L, int U, bool LDSX, int BLOCK>
@@ -74,18 +117,9 @@ static hipError_t launch_vec(const spal_csr *a, const void *x, void *y, hipStrea
     const uint32_t per_xcd = (p.nblocks + 7) / 8;
     const size_t lds = LDSX ? (size_t)p.lds_entries * sizeof(T) : 0;
     auto kern = csr_spmv_vector<T, L, U, LDSX, true, BLOCK>;
-    if (lds > 48 * 1024) {
-        // raise the dynamic-LDS cap once per kernel instance and device
-        static std::atomic<uint64_t> configured{0};
-        const uint64_t bit = 1ull << (a->device & 63);
-        if (!(configured.load(std::memory_order_relaxed) & bit)) {
-            hipError_t e = hipFuncSetAttribute((const void *)kern,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)kLdsBudgetBytes);
-            if (e != hipSuccess) return e;
-            configured.fetch_or(bit, std::memory_order_relaxed);
-        }
-    }
+    static std::atomic<uint64_t> configured{0};
+    hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(BLOCK), lds, st, a->d_rowptr, a->d_colind,
                        (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc, (uint32_t)a->nrows,
                        (uint32_t)a->nnz, (uint32_t)p.rows_per_block, p.nblocks, per_xcd);
@@ -114,15 +148,31 @@ static hipError_t launch_vec_unroll(const spal_csr *a, const void *x, void *y, h
     }
 }
 
+// stream kernel; its vector fallback for non-streamable super-tiles uses U = 2
+template <typename T, int L>
+static hipError_t launch_stream(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    const CsrPlan &p = a->plan;
+    const uint32_t per_xcd = (p.nblocks + 7) / 8;
+    const size_t lds = ((size_t)kStreamWaves * kStreamTileNnz + p.lds_entries) * sizeof(T);
+    auto kern = csr_spmv_stream<T, L, 2, true>;
+    static std::atomic<uint64_t> configured{0};
+    hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
+                       a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc,
+                       (uint32_t)a->nrows, (uint32_t)a->nnz, p.nblocks, per_xcd);
+    return hipGetLastError();
+}
+
 template <typename T>
-static hipError_t launch_vec_lanes(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+static hipError_t launch_lanes(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    const bool stream = a->plan.kernel == 2;
     switch (a->plan.lanes_per_row) {
-        case 2: return launch_vec_unroll<T, 2>(a, x, y, st);
-        case 4: return launch_vec_unroll<T, 4>(a, x, y, st);
-        case 8: return launch_vec_unroll<T, 8>(a, x, y, st);
-        case 16: return launch_vec_unroll<T, 16>(a, x, y, st);
-        case 32: return launch_vec_unroll<T, 32>(a, x, y, st);
-        case 64: return launch_vec_unroll<T, 64>(a, x, y, st);
+#define SPAL_LANES_CASE(LL) \
+    case LL: return stream ? launch_stream<T, LL>(a, x, y, st) : launch_vec_unroll<T, LL>(a, x, y, st);
+        SPAL_LANES_CASE(2) SPAL_LANES_CASE(4) SPAL_LANES_CASE(8) SPAL_LANES_CASE(16)
+        SPAL_LANES_CASE(32) SPAL_LANES_CASE(64)
+#undef SPAL_LANES_CASE
         default: return hipErrorInvalidValue;
     }
 }
@@ -139,18 +189,76 @@ int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream) 
         SPAL_HIP_TRY(hipGetLastError());
         return SPAL_OK;
     }
-    hipError_t e = a->elem_size == 8 ? launch_vec_lanes<double>(a, x_dev, y_dev, stream)
-                                     : launch_vec_lanes<float>(a, x_dev, y_dev, stream);
+    hipError_t e = a->elem_size == 8 ? launch_lanes<double>(a, x_dev, y_dev, stream)
+                                     : launch_lanes<float>(a, x_dev, y_dev, stream);
     if (e != hipSuccess)
         return fail(SPAL_ERR_HIP, "csr spmv launch failed: %s", hipGetErrorString(e));
     return SPAL_OK;
 }
 
-// Chooses lanes per row, rows per block and whether the x window goes through
-// LDS, then builds the per-block window table on the device.
+// per-row-block column windows for block size R -> host vector {cmin, cmax + 1}
+static int block_windows(spal_csr *a, uint32_t R, std::vector<uint2> &win) {
+    const uint32_t nb = (uint32_t)((a->nrows + R - 1) / R);
+    uint2 *d_win = nullptr;
+    SPAL_HIP_TRY(hipMalloc(&d_win, (size_t)nb * sizeof(uint2)));
+    hipLaunchKernelGGL(csr_block_windows, dim3(nb), dim3(256), 0, a->stream, a->d_rowptr,
+                       a->d_colind, (uint32_t)a->nrows, R, d_win);
+    win.resize(nb);
+    hipError_t e = hipMemcpyAsync(win.data(), d_win, (size_t)nb * sizeof(uint2),
+                                  hipMemcpyDeviceToHost, a->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
+    (void)hipFree(d_win);
+    SPAL_HIP_TRY(e);
+    return SPAL_OK;
+}
+
+// Stream plan: super-tiles of kStreamRows rows; returns the fraction of rows
+// that can be streamed and fills `desc`.
+static int stream_plan(spal_csr *a, std::vector<uint4> &desc, uint32_t &cap, double &frac) {
+    const uint32_t nb = (uint32_t)((a->nrows + kStreamRows - 1) / kStreamRows);
+    std::vector<uint2> win;
+    SPAL_TRY(block_windows(a, kStreamRows, win));
+    uint32_t *d_ok = nullptr;
+    SPAL_HIP_TRY(hipMalloc(&d_ok, (size_t)nb * 4));
+    hipLaunchKernelGGL(csr_stream_check, dim3((nb + 255) / 256), dim3(256), 0, a->stream, a->d_rowptr,
+                       (uint32_t)a->nrows, nb, d_ok);
+    std::vector<uint32_t> ok(nb);
+    hipError_t e = hipMemcpyAsync(ok.data(), d_ok, (size_t)nb * 4, hipMemcpyDeviceToHost, a->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
+    (void)hipFree(d_ok);
+    SPAL_HIP_TRY(e);
+    const uint32_t budget = kStreamWindowBytes / (uint32_t)a->elem_size;
+    const uint32_t valign = 16u / (uint32_t)a->elem_size;
+    desc.assign(nb, make_uint4(0, 0, kModeVectorGlobal, 0));
+    uint64_t rows_stream = 0;
+    cap = 0;
+    for (uint32_t b = 0; b < nb; ++b) {
+        const uint64_t rows = std::min<uint64_t>(kStreamRows, a->nrows - (uint64_t)b * kStreamRows);
+        uint2 w = win[b];
+        if (w.y == 0) {  // nothing stored: stream mode with a 1-element window writes the zeros
+            desc[b] = make_uint4(0, valign, kModeStream, 0);
+            cap = std::max(cap, valign);
+            rows_stream += rows;
+            continue;
+        }
+        const uint32_t cb = w.x & ~(valign - 1);
+        const uint32_t len = w.y - cb;
+        if (len > budget) continue;  // vector kernel, x from global
+        cap = std::max(cap, len);
+        if (ok[b] && len <= 65536u) {
+            desc[b] = make_uint4(cb, len, kModeStream, 0);
+            rows_stream += rows;
+        } else {
+            desc[b] = make_uint4(cb, len, kModeVectorLds, 0);
+        }
+    }
+    frac = a->nrows ? (double)rows_stream / (double)a->nrows : 0.0;
+    return SPAL_OK;
+}
+
+// Chooses the kernel and its parameters and builds the per-block tables.
 int csr_plan_build(spal_csr *a) {
     CsrPlan &p = a->plan;
-    p.kernel = 1;
     const double mean = a->nrows ? (double)a->nnz / (double)a->nrows : 0.0;
     if (!p.user_lanes) p.lanes_per_row = pick_lanes(mean);
     if (!p.user_unroll) p.unroll = 4;
@@ -159,59 +267,91 @@ int csr_plan_build(spal_csr *a) {
         SPAL_HIP_TRY(hipFree(a->d_desc));
         a->d_desc = nullptr;
     }
+    p.stream_row_fraction = 0.0;
     if (a->nnz == 0) {
+        p.kernel = 1;
         p.rows_per_block = 1024;
         p.nblocks = (uint32_t)((a->nrows + 1023) / 1024);
         p.lds_x = 0;
         return SPAL_OK;
     }
-    const uint32_t budget = kLdsBudgetBytes / (uint32_t)a->elem_size;  // elements
     const uint32_t valign = 16u / (uint32_t)a->elem_size;
+
+    // ---- stream kernel: short rows whose windows fit (auto: at least half the rows)
+    if (p.user_kernel == 0 || p.user_kernel == 2) {
+        std::vector<uint4> desc;
+        uint32_t cap = 0;
+        double frac = 0.0;
+        SPAL_TRY(stream_plan(a, desc, cap, frac));
+        if (p.user_kernel == 2 || frac >= 0.5) {
+            p.kernel = 2;
+            p.rows_per_block = kStreamRows;
+            p.threads = kStreamBlock;
+            p.nblocks = (uint32_t)desc.size();
+            p.lds_x = cap > 0;
+            p.lds_entries = (std::max(cap, valign) + valign - 1) & ~(valign - 1);
+            p.stream_row_fraction = frac;
+            uint64_t lds_rows = 0;
+            for (uint32_t b = 0; b < p.nblocks; ++b)
+                if (desc[b].z != kModeVectorGlobal)
+                    lds_rows += std::min<uint64_t>(kStreamRows, a->nrows - (uint64_t)b * kStreamRows);
+            p.lds_row_fraction = (double)lds_rows / (double)a->nrows;
+            SPAL_HIP_TRY(hipMalloc(&a->d_desc, (size_t)p.nblocks * sizeof(uint4)));
+            SPAL_HIP_TRY(hipMemcpyAsync(a->d_desc, desc.data(), (size_t)p.nblocks * sizeof(uint4),
+                                        hipMemcpyHostToDevice, a->stream));
+            if (!a->d_col16) {
+                SPAL_HIP_TRY(hipMalloc(&a->d_col16, (size_t)a->cap_entries * sizeof(uint16_t)));
+                SPAL_HIP_TRY(hipMemsetAsync(a->d_col16, 0, (size_t)a->cap_entries * sizeof(uint16_t), a->stream));
+            }
+            hipLaunchKernelGGL(csr_encode_col16, dim3(p.nblocks), dim3(256), 0, a->stream, a->d_rowptr,
+                               a->d_colind, a->d_desc, a->d_col16, (uint32_t)a->nrows);
+            SPAL_HIP_TRY(hipGetLastError());
+            SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
+            return SPAL_OK;
+        }
+    }
+
+    // ---- vector kernel
+    p.kernel = 1;
+    if (!p.user_threads && p.threads != 512 && p.threads != 1024) p.threads = 1024;
+    if (p.threads != 512 && p.threads != 1024) p.threads = 1024;
+    const uint32_t budget = kLdsBudgetBytes / (uint32_t)a->elem_size;  // elements
     const uint32_t cand_all[] = {4096, 2048, 1024, 512};
     std::vector<uint32_t> cands;
     if (p.user_rows_per_block) cands.push_back((uint32_t)p.rows_per_block);
     else cands.assign(cand_all, cand_all + 4);
 
-    std::vector<uint2> best_desc;
+    std::vector<uint4> best_desc;
     uint32_t best_R = 0, best_cap = 0;
     double best_frac = -1.0;
     const bool want_lds = p.user_lds ? p.lds_x != 0 : true;
     for (uint32_t R : cands) {
-        const uint32_t nb = (uint32_t)((a->nrows + R - 1) / R);
-        uint2 *d_win = nullptr;
-        SPAL_HIP_TRY(hipMalloc(&d_win, (size_t)nb * sizeof(uint2)));
-        hipLaunchKernelGGL(csr_block_windows, dim3(nb), dim3(256), 0, a->stream, a->d_rowptr,
-                           a->d_colind, (uint32_t)a->nrows, R, d_win);
-        std::vector<uint2> win(nb);
-        hipError_t e = hipMemcpyAsync(win.data(), d_win, (size_t)nb * sizeof(uint2),
-                                      hipMemcpyDeviceToHost, a->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
-        (void)hipFree(d_win);
-        SPAL_HIP_TRY(e);
+        std::vector<uint2> win;
+        SPAL_TRY(block_windows(a, R, win));
+        const uint32_t nb = (uint32_t)win.size();
+        std::vector<uint4> desc(nb, make_uint4(0, 0, kModeVectorGlobal, 0));
         uint64_t fit_rows = 0;
         uint32_t cap = 0;
         for (uint32_t b = 0; b < nb; ++b) {
-            uint2 w = win[b];
-            if (w.y == 0) {  // block stores nothing: trivially fits with an empty window
-                win[b] = make_uint2(0, 0);
-                fit_rows += std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
+            const uint2 w = win[b];
+            const uint64_t rows = std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
+            if (w.y == 0) {  // block stores nothing: no window needed
+                fit_rows += rows;
                 continue;
             }
             const uint32_t cb = w.x & ~(valign - 1);
             const uint32_t len = w.y - cb;
             if (want_lds && len <= budget) {
-                win[b] = make_uint2(cb, len);
+                desc[b] = make_uint4(cb, len, kModeVectorLds, 0);
                 cap = std::max(cap, len);
-                fit_rows += std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
-            } else {
-                win[b] = make_uint2(0, 0);
+                fit_rows += rows;
             }
         }
         const double frac = (double)fit_rows / (double)a->nrows;
         // prefer the largest R whose blocks (nearly) all fit; otherwise the best coverage
         const bool good = frac >= 0.9;
         if (best_R == 0 || (good && best_frac < 0.9) || (!good && best_frac < 0.9 && frac > best_frac)) {
-            best_R = R; best_frac = frac; best_cap = cap; best_desc.swap(win);
+            best_R = R; best_frac = frac; best_cap = cap; best_desc.swap(desc);
         }
         if (good) break;
     }
@@ -224,9 +364,9 @@ int csr_plan_build(spal_csr *a) {
     p.lds_x = use_lds ? 1 : 0;
     p.lds_entries = use_lds ? ((best_cap + valign - 1) & ~(valign - 1)) : 0;
     if (!use_lds)
-        for (auto &d : best_desc) d = make_uint2(0, 0);
-    SPAL_HIP_TRY(hipMalloc(&a->d_desc, (size_t)p.nblocks * sizeof(uint2)));
-    SPAL_HIP_TRY(hipMemcpy(a->d_desc, best_desc.data(), (size_t)p.nblocks * sizeof(uint2),
+        for (auto &d : best_desc) d = make_uint4(0, 0, kModeVectorGlobal, 0);
+    SPAL_HIP_TRY(hipMalloc(&a->d_desc, (size_t)p.nblocks * sizeof(uint4)));
+    SPAL_HIP_TRY(hipMemcpy(a->d_desc, best_desc.data(), (size_t)p.nblocks * sizeof(uint4),
                            hipMemcpyHostToDevice));
     return SPAL_OK;
 }
@@ -237,6 +377,7 @@ static void csr_free(spal_csr *a) {
     (void)hipFree(a->d_colind);
     (void)hipFree(a->d_values);
     (void)hipFree(a->d_desc);
+    (void)hipFree(a->d_col16);
     (void)hipFree(a->d_x);
     (void)hipFree(a->d_y);
     if (a->stream) (void)hipStreamDestroy(a->stream);
@@ -244,19 +385,53 @@ static void csr_free(spal_csr *a) {
 }
 
 int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, uint64_t nnz,
-                     uint32_t *d_rowptr, uint32_t *d_colind, void *d_values, spal_csr **out) {
+                     uint64_t cap_entries, uint32_t *d_rowptr, uint32_t *d_colind, void *d_values,
+                     spal_csr **out) {
     spal_csr *a = new spal_csr;
     a->device = device;
     a->elem_size = elem_size;
     a->nrows = nrows; a->ncols = ncols; a->nnz = nnz;
     a->d_rowptr = d_rowptr; a->d_colind = d_colind; a->d_values = d_values;
-    hipError_t e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
+    a->cap_entries = cap_entries;
+    auto bail = [&](int st) {
+        // the caller keeps ownership of the arrays it passed in on failure
+        if (a->d_rowptr == d_rowptr) a->d_rowptr = nullptr;
+        if (a->d_colind == d_colind) a->d_colind = nullptr;
+        if (a->d_values == d_values) a->d_values = nullptr;
         csr_free(a);
-        return fail(SPAL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        return st;
+    };
+    hipError_t e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return bail(fail(SPAL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)));
+    // the stream kernel reads whole 128-entry steps: keep kStreamPad spare entries
+    const uint64_t need = nnz + kStreamPad;
+    if (cap_entries < need) {
+        uint32_t *ci = nullptr;
+        void *va = nullptr;
+        e = hipMalloc(&ci, need * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&va, need * (size_t)elem_size);
+        if (e == hipSuccess) e = hipMemsetAsync(ci, 0, need * sizeof(uint32_t), a->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(va, 0, need * (size_t)elem_size, a->stream);
+        if (e == hipSuccess && nnz) e = hipMemcpyAsync(ci, d_colind, nnz * sizeof(uint32_t), hipMemcpyDeviceToDevice, a->stream);
+        if (e == hipSuccess && nnz) e = hipMemcpyAsync(va, d_values, nnz * (size_t)elem_size, hipMemcpyDeviceToDevice, a->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(ci); (void)hipFree(va);
+            return bail(fail(e == hipErrorOutOfMemory ? SPAL_ERR_OUT_OF_MEMORY : SPAL_ERR_HIP,
+                             "csr_adopt_device: %s", hipGetErrorString(e)));
+        }
+        a->d_colind = ci; a->d_values = va; a->cap_entries = need;
     }
     int st = csr_plan_build(a);
-    if (st != SPAL_OK) { csr_free(a); return st; }
+    if (st != SPAL_OK) {
+        const bool swapped = a->d_colind != d_colind;
+        if (swapped) { (void)hipFree(a->d_colind); (void)hipFree(a->d_values); a->d_colind = d_colind; a->d_values = d_values; }
+        return bail(st);
+    }
+    if (a->d_colind != d_colind) {  // the padded copies replaced the caller's arrays
+        (void)hipFree(d_colind);
+        (void)hipFree(d_values);
+    }
     *out = a;
     return SPAL_OK;
 }
@@ -290,9 +465,12 @@ static int csr_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t
     uint32_t *d_rp = nullptr, *d_ci = nullptr;
     void *d_v = nullptr;
     auto cleanup = [&] { (void)hipFree(d_rp); (void)hipFree(d_ci); (void)hipFree(d_v); };
+    const uint64_t cap = nnz + kStreamPad;  // spare entries for the stream kernel's whole-step reads
     hipError_t e = hipMalloc(&d_rp, (nrows + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_ci, std::max<uint64_t>(nnz, 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_v, std::max<uint64_t>(nnz, 1) * sizeof(T));
+    if (e == hipSuccess) e = hipMalloc(&d_ci, cap * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&d_v, cap * sizeof(T));
+    if (e == hipSuccess) e = hipMemset((char *)d_ci + nnz * sizeof(uint32_t), 0, kStreamPad * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset((char *)d_v + nnz * sizeof(T), 0, kStreamPad * sizeof(T));
     if (e == hipSuccess) e = hipMemcpy(d_rp, rp32.data(), (nrows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && nnz) e = hipMemcpy(d_ci, ci32.data(), nnz * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && nnz) e = hipMemcpy(d_v, values, nnz * sizeof(T), hipMemcpyHostToDevice);
@@ -302,7 +480,7 @@ static int csr_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t
                     "spal_csr_create: upload failed: %s", hipGetErrorString(e));
     }
     spal_csr *a = nullptr;
-    int st = csr_adopt_device(device, (int)sizeof(T), nrows, ncols, nnz, d_rp, d_ci, d_v, &a);
+    int st = csr_adopt_device(device, (int)sizeof(T), nrows, ncols, nnz, cap, d_rp, d_ci, d_v, &a);
     if (st != SPAL_OK) { cleanup(); return st; }
     *out = a;
     return SPAL_OK;
@@ -443,7 +621,9 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
     CsrPlan saved = a->plan;
     CsrPlan &p = a->plan;
     if (!strcmp(key, "kernel")) {
-        if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "kernel must be 0 or 1");
+        if (value < 0 || value > 2)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "kernel must be 0 (auto), 1 (vector) or 2 (stream)");
+        p.user_kernel = (int)value;
         if (value == 0) {
             p.user_rows_per_block = p.user_lanes = p.user_lds = p.user_unroll = p.user_threads = false;
         }
@@ -484,13 +664,15 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
     const CsrPlan &p = a->plan;
     snprintf(buf, buf_len,
              "{\"format\": \"csr\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"nnz\": %llu, "
-             "\"index_bits\": 32, \"kernel\": \"vector\", \"lanes_per_row\": %d, \"unroll\": %d, "
+             "\"index_bits\": %d, \"kernel\": \"%s\", \"lanes_per_row\": %d, \"unroll\": %d, "
              "\"rows_per_block\": %d, \"blocks\": %u, \"threads_per_block\": %d, \"lds_x\": %d, "
-             "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f}",
+             "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
-             (unsigned long long)a->ncols, (unsigned long long)a->nnz, p.lanes_per_row, p.unroll,
+             (unsigned long long)a->ncols, (unsigned long long)a->nnz, p.kernel == 2 ? 16 : 32,
+             p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
              p.rows_per_block, p.nblocks, p.threads, p.lds_x,
-             (unsigned long long)p.lds_entries * (unsigned long long)a->elem_size, p.lds_row_fraction);
+             (unsigned long long)p.lds_entries * (unsigned long long)a->elem_size, p.lds_row_fraction,
+             p.stream_row_fraction);
     return SPAL_OK;
 }
 

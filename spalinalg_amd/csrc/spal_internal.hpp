@@ -65,8 +65,10 @@ const char *invariant_text(int reason, bool csr);
 // ---- device matrices ---------------------------------------------------------
 struct CsrPlan {
     // kernel family: 1 = "vector" (L lanes per row, shuffle reduction, optional
-    // LDS-staged x window)
+    // LDS-staged x window); 2 = "stream" (lane per row, products through LDS,
+    // 16-bit window-relative columns; vector fallback per super-tile)
     int kernel = 0;          // 0 = not planned yet
+    int user_kernel = 0;     // 0 = auto
     int lanes_per_row = 0;   // L in {2,4,8,16,32,64}
     int unroll = 1;          // row groups in flight per wave iteration
     int threads = 512;       // workgroup size: 512 or 1024
@@ -75,6 +77,7 @@ struct CsrPlan {
     uint32_t lds_entries = 0;  // LDS window capacity (elements) when lds_x
     uint32_t nblocks = 0;
     double lds_row_fraction = 0.0;  // rows whose block window fits
+    double stream_row_fraction = 0.0;  // rows handled by the stream path (kernel 2)
     bool user_rows_per_block = false, user_lanes = false, user_lds = false,
          user_unroll = false, user_threads = false;
 };
@@ -89,7 +92,9 @@ struct spal_csr {
     uint32_t *d_rowptr = nullptr;  // nrows + 1
     uint32_t *d_colind = nullptr;  // nnz
     void *d_values = nullptr;      // nnz * elem_size
-    uint2 *d_desc = nullptr;       // per row block {window base column, window length or 0}
+    uint16_t *d_col16 = nullptr;   // nnz (+pad): window-relative columns of streamable super-tiles
+    uint4 *d_desc = nullptr;       // per row block {window base column, window length or 0, mode, 0}
+    uint64_t cap_entries = 0;      // allocated entries of d_colind / d_values (>= nnz + pad)
     spal::CsrPlan plan;
     // host-convenience staging (spal_csr_spmv_*): guarded by mu
     std::mutex mu;
@@ -125,7 +130,9 @@ int csr_plan_build(spal_csr *a);
 int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream);
 // builds a handle around device arrays it takes ownership of (used by the COO
 // assembly, which produces CSR directly on the device)
+// (cap_entries = allocated entries of d_colind / d_values; re-allocated with
+// padding when smaller than nnz + the kernels' over-read margin)
 int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols,
-                     uint64_t nnz, uint32_t *d_rowptr, uint32_t *d_colind,
-                     void *d_values, spal_csr **out);
+                     uint64_t nnz, uint64_t cap_entries, uint32_t *d_rowptr,
+                     uint32_t *d_colind, void *d_values, spal_csr **out);
 }  // namespace spal

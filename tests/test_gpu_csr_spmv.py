@@ -61,6 +61,55 @@ def test_empty_matrix_and_empty_rows(oracle):
     assert y[:-1].tolist() == [0.0] * 99 and y[-1] == 2.0 + 15.0
 
 
+def test_stream_kernel_is_bit_identical_to_the_reference_order(oracle):
+    """Rows handled by the stream kernel are summed left to right with
+    separately rounded mul and add, exactly like the reference
+    (src/csr/ops/mul.rs:31-38): results are bit-for-bit the oracle's."""
+    rng = np.random.default_rng(2)
+    for dtype in (np.float64, np.float32):
+        n = 300_000
+        rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, 11, dtype=dtype)
+        x = sp.synth.vector(n, dtype=dtype)
+        dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+        d = dev.describe()
+        assert d["kernel"] == "stream" and d["stream_row_fraction"] == 1.0 and d["index_bits"] == 16
+        y = dev.spmv(x)
+        assert np.array_equal(y, oracle.csr_spmv(rp, ci, va, x))
+        # ragged rows (0..40 entries), odd tile starts, a short last super-tile
+        nr, nc = 70_001, 3000
+        rp, ci, va = random_csr(rng, nr, nc, row_len=lambda r: r.integers(0, 41), dtype=dtype)
+        x = rng.uniform(-1, 1, nc).astype(dtype)
+        x[7] = 0.0
+        dev = sp.CsrMatrix(nr, nc, rp, ci, va).device()
+        d = dev.describe()
+        assert d["kernel"] == "stream" and d["stream_row_fraction"] > 0.99
+        y = dev.spmv(x)
+        y_ref = oracle.csr_spmv(rp, ci, va, x)
+        assert np.array_equal(y, y_ref)
+        assert np.array_equal(np.signbit(y), np.signbit(y_ref))     # -0.0 from a lone -v * 0.0 included
+
+
+def test_stream_kernel_mixed_supertiles(oracle):
+    """a few heavy rows make single super-tiles fall back to the vector path
+    inside the same launch; one wide row forces the global-gather mode."""
+    rng = np.random.default_rng(4)
+    n = 20_000
+    rp, ci, va = sp.synth.banded_csr(n, n, 14, 2048, 13)
+    rp, ci, va = rp.astype(np.int64), list(np.split(ci, rp[1:-1].astype(np.int64))), list(np.split(va, rp[1:-1].astype(np.int64)))
+    for r, k, span in [(5000, 3000, 4000), (5001, 1500, 4000), (12_345, 200, n), (19_999, 1100, 3000)]:
+        lo = max(0, min(r - span // 2, n - span))
+        ci[r] = (lo + np.sort(rng.choice(span, k, replace=False))).astype(np.uint64)
+        va[r] = rng.uniform(-1, 1, k)
+    lens = np.array([c.size for c in ci])
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    ci, va = np.concatenate(ci), np.concatenate(va)
+    x = sp.synth.vector(n)
+    dev = check(oracle, rp, ci, va, x, n, kernel=2)
+    d = dev.describe()
+    assert d["kernel"] == "stream" and 0.5 < d["stream_row_fraction"] < 1.0
+    check(oracle, rp, ci, va, x, n, kernel=1)
+
+
 @pytest.mark.parametrize("lanes", [2, 4, 8, 16, 32, 64])
 @pytest.mark.parametrize("unroll", [1, 2, 4])
 def test_every_lane_width_and_unroll(oracle, lanes, unroll):
@@ -77,7 +126,9 @@ def test_every_lane_width_and_unroll(oracle, lanes, unroll):
     x = rng.uniform(-1, 1, nc)
     for threads in (512, 1024):
         for lds in (0, 1):
-            check(oracle, rp, ci, va, x, nc, lanes_per_row=lanes, unroll=unroll, threads=threads, lds_x=lds)
+            check(oracle, rp, ci, va, x, nc, kernel=1, lanes_per_row=lanes, unroll=unroll, threads=threads, lds_x=lds)
+    if unroll == 1:
+        check(oracle, rp, ci, va, x, nc, kernel=2, lanes_per_row=lanes)
 
 
 @pytest.mark.parametrize("rows_per_block", [64, 512, 2048, 4096, 16384])
@@ -92,9 +143,9 @@ def test_rows_per_block_and_window_fallback(oracle, rows_per_block):
         lo = int(rp[r])
         ci[lo:lo + 14] = np.sort(rng.choice(nc, 14, replace=False))
     x = sp.synth.vector(nc)
-    dev = check(oracle, rp, ci, va, x, nc, rows_per_block=rows_per_block)
+    dev = check(oracle, rp, ci, va, x, nc, kernel=1, rows_per_block=rows_per_block)
     d = dev.describe()
-    assert d["rows_per_block"] == rows_per_block
+    assert d["rows_per_block"] == rows_per_block and d["kernel"] == "vector"
 
 
 def test_nan_inf_in_x_stay_local(oracle):
@@ -107,8 +158,9 @@ def test_nan_inf_in_x_stay_local(oracle):
     x[2500] = np.inf
     x[4999] = -np.inf
     a = sp.CsrMatrix(nr, nc, rp, ci, va)
-    for lanes in (4, 16, 64):
+    for kernel, lanes in ((1, 4), (1, 16), (1, 64), (2, 16)):
         dev = a.device()
+        dev.set_option("kernel", kernel)
         dev.set_option("lanes_per_row", lanes)
         y = dev.spmv(x)
         y_ref = oracle.csr_spmv(rp, ci, va, x)
@@ -128,6 +180,8 @@ def test_config2_banded_and_uniform(oracle, dtype, window):
     dev = check(oracle, rp, ci, va, x, n)
     d = dev.describe()
     assert d["lds_x"] == (1 if window else 0)
+    assert d["kernel"] == ("stream" if window else "vector")
+    check(oracle, rp, ci, va, x, n, kernel=1)
 
 
 def test_dimension_mismatch_panics():

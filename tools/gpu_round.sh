@@ -1,0 +1,28 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): smoke, GPU parity tests, kernel lab, bench.
+# A step that times out / is killed stops the script (no further GPU work).
+set -u
+mkdir -p gpurun_out
+step() {  # step <seconds> <logfile> <cmd...>
+    local secs=$1 log=$2; shift 2
+    echo "=== $* (limit ${secs}s)" | tee -a gpurun_out/steps.log
+    timeout -k 10 "$secs" "$@" > "gpurun_out/$log" 2>&1
+    local rc=$?
+    echo "    rc=$rc" | tee -a gpurun_out/steps.log
+    tail -n 12 "gpurun_out/$log"
+    if [ $rc -ge 124 ]; then echo "step killed/timed out: stopping"; exit $rc; fi
+    return 0
+}
+: > gpurun_out/steps.log
+rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | sort | uniq -c | head -4 | tee -a gpurun_out/steps.log
+nproc | tee -a gpurun_out/steps.log
+for s in "$@"; do
+  case $s in
+    smoke)  step 300 smoke.log python -c "import __graft_entry__ as g; g.smoke()" ;;
+    tests)  step 900 pytest_gpu.log python -m pytest tests -x -q -m gpu ;;
+    testsall) step 900 pytest_gpu.log python -m pytest tests -q -m gpu ;;
+    lab)    step 600 lab.log python tools/lab_csr.py --out gpurun_out/lab.json ;;
+    bench)  step 400 bench.log python bench.py ;;
+    *) echo "unknown step $s" ;;
+  esac
+done

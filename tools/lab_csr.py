@@ -64,7 +64,7 @@ def main():
     del big, dst
 
     # reference result with a conservative plan
-    dev.set_option("kernel", 0)
+    dev.set_option("kernel", 1)
     dev.set_option("lds_x", 0)
     dev.set_option("unroll", 1)
     dev.set_option("threads", 512)
@@ -72,18 +72,29 @@ def main():
     dev.set_option("kernel", 0)
 
     if args.sweep == "default":
-        grid = dict(threads=[512, 1024], rows_per_block=[1024, 2048, 4096], unroll=[1, 2, 4],
-                    lanes_per_row=[8, 16], lds_x=[1])
+        grid = dict(threads=[512, 1024], rows_per_block=[1024, 4096], unroll=[2, 4],
+                    lanes_per_row=[16], lds_x=[1])
         extra = [dict(threads=512, rows_per_block=1024, unroll=2, lanes_per_row=16, lds_x=0),
                  dict(threads=1024, rows_per_block=4096, unroll=4, lanes_per_row=16, lds_x=0)]
     else:
         grid = json.loads(args.sweep)
         extra = []
     combos = [dict(zip(grid, v)) for v in itertools.product(*grid.values())] + extra
+    # the stream kernel (fixed geometry)
+    try:
+        dev.set_option("kernel", 2)
+        t = timeit(lambda: dev.spmv_torch(x, out=y), args.iters)
+        ok = bool(torch.allclose(y, yref, rtol=1e-10 if esz == 8 else 1e-4, atol=1e-11 if esz == 8 else 1e-4))
+        gbs = B / t / 1e6
+        print(f"stream kernel: {t*1e3:9.1f} us {gbs:8.1f} GB/s {100*gbs/8000:6.2f} %peak ok={ok} {dev.describe()}", flush=True)
+        results.append(dict(kernel=2, us=t * 1e3, gbs=gbs, ok=ok, plan=dev.describe()))
+    except Exception as e:  # noqa: BLE001
+        print("stream kernel FAILED", e, flush=True)
+    dev.set_option("kernel", 1)
     print(f"{'threads':>7} {'R':>6} {'U':>2} {'L':>3} {'lds':>3} | {'us':>9} {'GB/s':>8} {'%peak':>6}  ok")
     for c in combos:
         try:
-            dev.set_option("kernel", 0)
+            dev.set_option("kernel", 1)
             for k, v in c.items():
                 dev.set_option(k, v)
             t = timeit(lambda: dev.spmv_torch(x, out=y), args.iters)
