@@ -75,9 +75,9 @@ def test_stream_kernel_is_bit_identical_to_the_reference_order(oracle):
         assert d["kernel"] == "stream" and d["stream_row_fraction"] == 1.0 and d["index_bits"] == 16
         y = dev.spmv(x)
         assert np.array_equal(y, oracle.csr_spmv(rp, ci, va, x))
-        # ragged rows (0..40 entries), odd tile starts, a short last super-tile
+        # ragged rows (0..24 entries), odd tile starts, a short last super-tile
         nr, nc = 70_001, 3000
-        rp, ci, va = random_csr(rng, nr, nc, row_len=lambda r: r.integers(0, 41), dtype=dtype)
+        rp, ci, va = random_csr(rng, nr, nc, row_len=lambda r: r.integers(0, 25), dtype=dtype)
         x = rng.uniform(-1, 1, nc).astype(dtype)
         x[7] = 0.0
         dev = sp.CsrMatrix(nr, nc, rp, ci, va).device()

@@ -23,6 +23,12 @@ for s in "$@"; do
     testsall) step 900 pytest_gpu.log python -m pytest tests -q -m gpu ;;
     lab)    step 600 lab.log python tools/lab_csr.py --out gpurun_out/lab.json ;;
     bench)  step 400 bench.log python bench.py ;;
+    prof)   # per-kernel time (stats) and, in separate passes, the HBM counters
+            export TMPDIR=/tmp
+            step 400 prof_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -o bench -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline
+            step 400 prof_fetch.log rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -o bench -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
+            step 400 prof_write.log rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -o bench -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
+            ;;
     *) echo "unknown step $s" ;;
   esac
 done
