@@ -267,8 +267,8 @@ __global__ __launch_bounds__(BLOCK, 8) void csr_spmv_vector(
 // ---- the "stream" kernel: one lane per row, products parked in LDS ----------
 // (CSR-Adaptive's CSR-Stream, re-tiled for wave64 / 160 KB LDS.)
 //
-// A workgroup (4 waves) owns a SUPER-TILE of up to kStreamRows = 1024 rows and
-// stages its x window in LDS once.  Each wave owns 4 TILES of 64 consecutive
+// A workgroup (4 waves) owns a SUPER-TILE of 256 * TPW rows (TPW = 4: 1024) and
+// stages its x window in LDS once.  Each wave owns TPW TILES of 64 consecutive
 // rows.  For a tile the wave
 //   1. loads the tile's values and 16-bit window-relative columns with wide,
 //      perfectly coalesced loads: lane l, step j holds entries
@@ -289,9 +289,9 @@ __global__ __launch_bounds__(BLOCK, 8) void csr_spmv_vector(
 // done by vector_rows() in the same launch (block-uniform branch).
 constexpr int kStreamBlock = 256;
 constexpr int kStreamWaves = kStreamBlock / kWave;                          // 4
-constexpr int kStreamTilesPerWave = 4;
 constexpr int kStreamTileRows = 64;
-constexpr int kStreamRows = kStreamWaves * kStreamTilesPerWave * kStreamTileRows;  // 1024
+// rows of a super-tile when every wave owns TPW tiles (TPW = 4: 1024, 8: 2048)
+constexpr int stream_rows(int tpw) { return kStreamWaves * tpw * kStreamTileRows; }
 constexpr int kStreamSteps = 8;                                             // 128 entries per step
 constexpr int kStreamTileNnz = kStreamSteps * 128;                          // 1024 incl. alignment slack
 constexpr int kStreamPad = 256;  // device arrays are over-allocated by this many entries
@@ -320,10 +320,8 @@ __device__ __forceinline__ void stream_load(StreamTile<T> &t, const uint32_t *__
     const uint32_t rlast = min(row0 + kStreamTileRows, row1);
     t.start = b & ~1u;
     t.steps = (e - t.start + 127u) >> 7;
-    const uint32_t r = min(row0 + lane, rlast - 1);
-    t.rp0 = rowptr[r];
-    t.rp1 = (row0 + lane < rlast) ? rowptr[r + 1] : t.rp0;
     const uint32_t e0 = t.start + lane * 2;
+    // the HBM stream first ...
 #pragma unroll
     for (int j = 0; j < kStreamSteps; ++j) {
         if ((uint32_t)j < t.steps) {  // uniform
@@ -331,6 +329,11 @@ __device__ __forceinline__ void stream_load(StreamTile<T> &t, const uint32_t *__
             t.c[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(col16 + e0 + j * 128));
         }
     }
+    // ... then this lane's row bounds (needed only by the reduction).  Both
+    // loads are unconditional: lanes past the tile's last row read
+    // rowptr[rlast] twice, i.e. an empty row -- no select, hence no wait here.
+    t.rp0 = rowptr[min(row0 + lane, rlast)];
+    t.rp1 = rowptr[min(row0 + lane + 1, rlast)];
 }
 
 template <typename T>
@@ -358,17 +361,28 @@ __device__ __forceinline__ void stream_compute(const StreamTile<T> &t, const T *
     __builtin_amdgcn_wave_barrier();
     const uint32_t off = t.rp0 - t.start;
     const uint32_t len = t.rp1 - t.rp0;
+    // left-to-right sum; the reads of four products go out together, the adds
+    // stay in stored order (the order is the contract, the batching is not)
     T acc = T(0);
     if (len) {
         acc = prod[off];
-        for (uint32_t k = 1; k < len; ++k) acc = acc + prod[off + k];
+        uint32_t k = 1;
+        for (; k + 4 <= len; k += 4) {
+            const T p0 = prod[off + k], p1 = prod[off + k + 1], p2 = prod[off + k + 2],
+                    p3 = prod[off + k + 3];
+            acc = acc + p0;
+            acc = acc + p1;
+            acc = acc + p2;
+            acc = acc + p3;
+        }
+        for (; k < len; ++k) acc = acc + prod[off + k];
     }
     __builtin_amdgcn_wave_barrier();  // the next tile's products overwrite this strip
     if (row0 + lane < min(row0 + kStreamTileRows, row1)) y[row0 + lane] = acc;
 }
 
 // desc[b] = {window base column, window length, mode, 0}
-template <typename T, int L, int U, bool USE_DPP>
+template <typename T, int L, int U, bool USE_DPP, int TPW>
 __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
     const uint16_t *__restrict__ col16, const T *__restrict__ vals, const T *__restrict__ x,
@@ -381,8 +395,9 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
 
     const uint32_t b = xcd_contiguous_block(blockIdx.x, per_xcd);
     if (b >= nblocks) return;
-    const uint32_t row0 = b * kStreamRows;
-    const uint32_t row1 = min(row0 + kStreamRows, nrows);
+    constexpr uint32_t kRows = stream_rows(TPW);
+    const uint32_t row0 = b * kRows;
+    const uint32_t row1 = min(row0 + kRows, nrows);
     const uint4 d = desc[b];  // block-uniform
 
     if (d.z == kModeStream) {
@@ -390,13 +405,13 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
         const uint32_t wave = threadIdx.x / kWave;
         T *prod = prod_all + wave * kStreamTileNnz;
         // this wave's tiles: rows row0 + (wave*4 + k) * 64
-        const uint32_t wrow = row0 + wave * (kStreamTilesPerWave * kStreamTileRows);
+        const uint32_t wrow = row0 + wave * (TPW * kStreamTileRows);
         // entry offsets of this wave's tile boundaries, fetched once (lane k holds
         // boundary k) so that no tile's loads wait on a row-pointer round trip
-        const uint32_t tb_lane = rowptr[min(wrow + min(lane, (uint32_t)kStreamTilesPerWave) * kStreamTileRows, row1)];
-        uint32_t tb[kStreamTilesPerWave + 1];
+        const uint32_t tb_lane = rowptr[min(wrow + min(lane, (uint32_t)TPW) * kStreamTileRows, row1)];
+        uint32_t tb[TPW + 1];
 #pragma unroll
-        for (int k = 0; k <= kStreamTilesPerWave; ++k) tb[k] = __builtin_amdgcn_readlane(tb_lane, k);
+        for (int k = 0; k <= TPW; ++k) tb[k] = __builtin_amdgcn_readlane(tb_lane, k);
         StreamTile<T> cur, nxt;
         const bool has0 = wrow < row1;  // wave-uniform
         if (has0) stream_load<T>(cur, rowptr, col16, vals, wrow, row1, tb[0], tb[1], lane);  // overlaps the staging
@@ -405,12 +420,12 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
         if (!has0) return;
         const uint32_t wmax = d.y - 1;
 #pragma unroll
-        for (int k = 0; k < kStreamTilesPerWave; ++k) {
+        for (int k = 0; k < TPW; ++k) {
             const uint32_t r0 = wrow + k * kStreamTileRows;
             if (r0 >= row1) break;  // wave-uniform
             const uint32_t rn = r0 + kStreamTileRows;
-            const bool more = (k + 1 < kStreamTilesPerWave) && rn < row1;
-            if (more) stream_load<T>(nxt, rowptr, col16, vals, rn, row1, tb[k + 1], tb[k + 2 <= kStreamTilesPerWave ? k + 2 : k + 1], lane);
+            const bool more = (k + 1 < TPW) && rn < row1;
+            if (more) stream_load<T>(nxt, rowptr, col16, vals, rn, row1, tb[k + 1], tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
             stream_compute<T>(cur, xw, wmax, prod, y, r0, row1, lane);
             if (more) cur = nxt;
         }

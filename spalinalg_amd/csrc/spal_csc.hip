@@ -5,24 +5,129 @@
 // give 0.0.  On the GPU the adds into one y[i] arrive in no fixed order
 // (hardware f64/f32 atomics), so parity with the sequential CPU order is to
 // rounding (<= 1e-10 relative, tested), not bitwise.
+//
+// Two scatter paths in one launch, chosen per SUPER-TILE of 1024 columns:
+//   LDS-privatised : the rows a super-tile touches form a window
+//                    [rmin, rmax]; when it fits LDS the adds go to an LDS copy
+//                    of that window (ds_add_f64: conflicts cost cycles, not
+//                    memory round trips) and the window is flushed once with
+//                    contiguous global atomics (full-rate shape: 256 B per
+//                    wave instruction).  Entries are streamed coalesced with a
+//                    packed 32-bit (row - rmin | (col - k0) << 16) per entry.
+//   global scatter : one global atomic per entry (windows that do not fit).
 #include "csr_kernels.hpp"
 #include "spal_internal.hpp"
 
 namespace spal {
 
-// L lanes share a column: x[k] is read once per lane group, rowind/values are
-// streamed coalesced, every product goes out as one no-return atomic add.
+constexpr int kCscBlock = 256;
+constexpr int kCscCols = 1024;                 // columns per super-tile
+constexpr uint32_t kCscWindowBytes = 48 * 1024;  // LDS y window budget (+ 8 KiB x tile)
+constexpr uint32_t kCscModeGlobal = 0, kCscModeLds = 1;
+
+// ---- plan-time kernels ---------------------------------------------------------
+// (rowind is strictly increasing inside a column, src/csc.rs:152-156: the first
+// and last entry of a column bound its rows)
+__global__ __launch_bounds__(256) void csc_block_windows(const uint32_t *__restrict__ colptr,
+                                                         const uint32_t *__restrict__ rowind,
+                                                         uint32_t ncols, uint2 *__restrict__ out) {
+    __shared__ uint32_t s_min, s_max;
+    if (threadIdx.x == 0) { s_min = 0xffffffffu; s_max = 0u; }
+    __syncthreads();
+    const uint32_t k0 = blockIdx.x * kCscCols, k1 = min(k0 + (uint32_t)kCscCols, ncols);
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (uint32_t k = k0 + threadIdx.x; k < k1; k += 256) {
+        const uint32_t a0 = colptr[k], a1 = colptr[k + 1];
+        if (a0 < a1) {
+            lo = min(lo, rowind[a0]);
+            hi = max(hi, rowind[a1 - 1] + 1u);
+        }
+    }
+    atomicMin(&s_min, lo);
+    atomicMax(&s_max, hi);
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = make_uint2(s_min, s_max);
+}
+
+// meta[p] = (row - rbase) | (col - k0) << 16 for LDS-mode super-tiles
+__global__ __launch_bounds__(256) void csc_encode_meta(const uint32_t *__restrict__ colptr,
+                                                       const uint32_t *__restrict__ rowind,
+                                                       const uint4 *__restrict__ desc,
+                                                       uint32_t *__restrict__ meta, uint32_t ncols) {
+    const uint4 d = desc[blockIdx.x];
+    if (d.z != kCscModeLds) return;
+    const uint32_t k0 = blockIdx.x * kCscCols, k1 = min(k0 + (uint32_t)kCscCols, ncols);
+    for (uint32_t k = k0 + threadIdx.x; k < k1; k += 256)
+        for (uint32_t p = colptr[k]; p < colptr[k + 1]; ++p)
+            meta[p] = (rowind[p] - d.x) | ((k - k0) << 16);
+}
+
+// ---- the scatter kernel ------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void lds_add(T *p, T v) {
+    // relaxed, workgroup scope: ds_add_f64 / ds_add_f32, no return value
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// desc[b] = {window base row, window length, mode, 0}
 template <typename T, int L>
-__global__ __launch_bounds__(256) void csc_spmv_scatter(
+__global__ __launch_bounds__(kCscBlock, 2) void csc_spmv_scatter(
     const uint32_t *__restrict__ colptr, const uint32_t *__restrict__ rowind,
-    const T *__restrict__ vals, const T *__restrict__ x, T *__restrict__ y, uint32_t ncols) {
-    constexpr uint32_t G = 256 / L;  // columns per workgroup pass
+    const uint32_t *__restrict__ meta, const T *__restrict__ vals, const T *__restrict__ x,
+    T *__restrict__ y, const uint4 *__restrict__ desc, uint32_t ncols, uint32_t nblocks,
+    uint32_t per_xcd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
+    using pair_t = typename Pair<T>::type;
+    using u2_t = __attribute__((ext_vector_type(2))) uint32_t;
+    T *xt = reinterpret_cast<T *>(spal_smem);  // x of the super-tile's columns
+    T *yw = xt + kCscCols;                     // y window accumulators
+
+    const uint32_t b = xcd_contiguous_block(blockIdx.x, per_xcd);
+    if (b >= nblocks) return;
+    const uint32_t k0 = b * kCscCols, k1 = min(k0 + (uint32_t)kCscCols, ncols);
+    const uint4 d = desc[b];  // block-uniform
+
+    if (d.z == kCscModeLds) {
+        const uint32_t p0 = colptr[k0], p1 = colptr[k1];  // uniform
+        for (uint32_t i = threadIdx.x; i < d.y; i += kCscBlock) yw[i] = T(0);
+        for (uint32_t i = threadIdx.x; i < k1 - k0; i += kCscBlock) xt[i] = x[k0 + i];
+        __syncthreads();
+        // entries in pairs from an even start; each workgroup pass covers 512 entries
+        constexpr uint32_t U = 4;
+        const uint32_t pa = p0 & ~1u;
+        for (uint32_t base = pa + threadIdx.x * 2; base < p1; base += kCscBlock * 2 * U) {
+            pair_t v[U];
+            u2_t m[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t e = base + u * (kCscBlock * 2);  // the arrays are padded: no clamp
+                v[u] = __builtin_nontemporal_load(reinterpret_cast<const pair_t *>(vals + e));
+                m[u] = __builtin_nontemporal_load(reinterpret_cast<const u2_t *>(meta + e));
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t e = base + u * (kCscBlock * 2);
+                if (e >= p0 && e < p1) lds_add(&yw[m[u].x & 0xffffu], v[u].x * xt[m[u].x >> 16]);
+                if (e + 1 >= p0 && e + 1 < p1) lds_add(&yw[m[u].y & 0xffffu], v[u].y * xt[m[u].y >> 16]);
+            }
+        }
+        __syncthreads();
+        // flush: contiguous, one atomic per touched row (adding 0.0 changes nothing)
+        for (uint32_t i = threadIdx.x; i < d.y; i += kCscBlock) {
+            const T s = yw[i];
+            if (s != T(0) || s != s) atomicAdd(&y[d.x + i], s);
+        }
+        return;
+    }
+
+    // global scatter: L lanes per column
+    constexpr uint32_t G = kCscBlock / L;
     const uint32_t g = threadIdx.x / L, s = threadIdx.x % L;
-    for (uint32_t k = blockIdx.x * G + g; k < ncols; k += gridDim.x * G) {
-        const uint32_t p0 = colptr[k], p1 = colptr[k + 1];
-        if (p0 == p1) continue;
+    for (uint32_t k = k0 + g; k < k1; k += G) {
+        const uint32_t a0 = colptr[k], a1 = colptr[k + 1];
+        if (a0 == a1) continue;
         const T xk = x[k];
-        for (uint32_t p = p0 + s; p < p1; p += L) {
+        for (uint32_t p = a0 + s; p < a1; p += L) {
             const uint32_t i = load_stream(rowind + p);
             const T v = load_stream(vals + p);
             atomicAdd(&y[i], v * xk);  // -munsafe-fp-atomics: global_atomic_add_f64 / _f32
@@ -36,27 +141,40 @@ static int pick_lanes_csc(double mean) {
     return L;
 }
 
+template <typename T, int L>
+static hipError_t csc_launch_l(const spal_csc *a, const void *x, void *y, hipStream_t st) {
+    const uint32_t per_xcd = (a->nblocks + 7) / 8;
+    const size_t lds = ((size_t)kCscCols + a->lds_entries) * sizeof(T);
+    auto kern = csc_spmv_scatter<T, L>;
+    static std::atomic<uint64_t> configured{0};
+    if (lds > 48 * 1024) {
+        const uint64_t bit = 1ull << (a->device & 63);
+        if (!(configured.load(std::memory_order_relaxed) & bit)) {
+            hipError_t e = hipFuncSetAttribute((const void *)kern,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return e;
+            configured.fetch_or(bit, std::memory_order_relaxed);
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(kCscBlock), lds, st, a->d_colptr, a->d_rowind,
+                       a->d_meta, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc,
+                       (uint32_t)a->ncols, a->nblocks, per_xcd);
+    return hipGetLastError();
+}
+
 template <typename T>
 static hipError_t csc_launch_t(const spal_csc *a, const void *x, void *y, hipStream_t st) {
     hipError_t e = hipMemsetAsync(y, 0, a->nrows * sizeof(T), st);
     if (e != hipSuccess || a->nnz == 0) return e;
-    const int L = a->lanes_per_col;
-    const uint32_t G = 256 / L;
-    const uint64_t want = (a->ncols + G - 1) / G;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(want, 256ull * 8 * 4);
-#define SPAL_CSC_CASE(LL)                                                                         \
-    case LL:                                                                                      \
-        hipLaunchKernelGGL((csc_spmv_scatter<T, LL>), dim3(grid), dim3(256), 0, st, a->d_colptr, \
-                           a->d_rowind, (const T *)a->d_values, (const T *)x, (T *)y,            \
-                           (uint32_t)a->ncols);                                                   \
-        break;
-    switch (L) {
-        SPAL_CSC_CASE(2) SPAL_CSC_CASE(4) SPAL_CSC_CASE(8) SPAL_CSC_CASE(16) SPAL_CSC_CASE(32)
-        SPAL_CSC_CASE(64)
+    switch (a->lanes_per_col) {
+        case 2: return csc_launch_l<T, 2>(a, x, y, st);
+        case 4: return csc_launch_l<T, 4>(a, x, y, st);
+        case 8: return csc_launch_l<T, 8>(a, x, y, st);
+        case 16: return csc_launch_l<T, 16>(a, x, y, st);
+        case 32: return csc_launch_l<T, 32>(a, x, y, st);
+        case 64: return csc_launch_l<T, 64>(a, x, y, st);
         default: return hipErrorInvalidValue;
     }
-#undef SPAL_CSC_CASE
-    return hipGetLastError();
 }
 
 static int csc_launch(spal_csc *a, const void *x, void *y, hipStream_t st) {
@@ -66,11 +184,61 @@ static int csc_launch(spal_csc *a, const void *x, void *y, hipStream_t st) {
     return SPAL_OK;
 }
 
+// Per-super-tile windows and modes; packed metadata for the LDS mode.
+static int csc_plan_build(spal_csc *a) {
+    a->nblocks = (uint32_t)((a->ncols + kCscCols - 1) / kCscCols);
+    if (a->d_desc) { SPAL_HIP_TRY(hipFree(a->d_desc)); a->d_desc = nullptr; }
+    a->lds_entries = 0;
+    a->lds_col_fraction = 0.0;
+    std::vector<uint4> desc(a->nblocks, make_uint4(0, 0, kCscModeGlobal, 0));
+    if (a->nnz && a->use_lds) {
+        uint2 *d_win = nullptr;
+        SPAL_HIP_TRY(hipMalloc(&d_win, (size_t)a->nblocks * sizeof(uint2)));
+        hipLaunchKernelGGL(csc_block_windows, dim3(a->nblocks), dim3(256), 0, a->stream, a->d_colptr,
+                           a->d_rowind, (uint32_t)a->ncols, d_win);
+        std::vector<uint2> win(a->nblocks);
+        hipError_t e = hipMemcpyAsync(win.data(), d_win, (size_t)a->nblocks * sizeof(uint2),
+                                      hipMemcpyDeviceToHost, a->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
+        (void)hipFree(d_win);
+        SPAL_HIP_TRY(e);
+        const uint32_t budget = std::min<uint32_t>(kCscWindowBytes / (uint32_t)a->elem_size, 65536u);
+        uint64_t cols_lds = 0;
+        for (uint32_t b = 0; b < a->nblocks; ++b) {
+            const uint2 w = win[b];
+            if (w.y == 0) continue;  // no entries: the global path finds nothing to do
+            const uint32_t len = w.y - w.x;
+            if (len <= budget) {
+                desc[b] = make_uint4(w.x, len, kCscModeLds, 0);
+                a->lds_entries = std::max(a->lds_entries, len);
+                cols_lds += std::min<uint64_t>(kCscCols, a->ncols - (uint64_t)b * kCscCols);
+            }
+        }
+        a->lds_col_fraction = (double)cols_lds / (double)a->ncols;
+    }
+    SPAL_HIP_TRY(hipMalloc(&a->d_desc, (size_t)a->nblocks * sizeof(uint4)));
+    SPAL_HIP_TRY(hipMemcpyAsync(a->d_desc, desc.data(), (size_t)a->nblocks * sizeof(uint4),
+                                hipMemcpyHostToDevice, a->stream));
+    if (a->lds_entries) {
+        if (!a->d_meta) {
+            SPAL_HIP_TRY(hipMalloc(&a->d_meta, (size_t)(a->nnz + kStreamPad) * sizeof(uint32_t)));
+            SPAL_HIP_TRY(hipMemsetAsync(a->d_meta, 0, (size_t)(a->nnz + kStreamPad) * sizeof(uint32_t), a->stream));
+        }
+        hipLaunchKernelGGL(csc_encode_meta, dim3(a->nblocks), dim3(256), 0, a->stream, a->d_colptr,
+                           a->d_rowind, a->d_desc, a->d_meta, (uint32_t)a->ncols);
+        SPAL_HIP_TRY(hipGetLastError());
+    }
+    SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
+    return SPAL_OK;
+}
+
 static void csc_free(spal_csc *a) {
     if (!a) return;
     (void)hipFree(a->d_colptr);
     (void)hipFree(a->d_rowind);
     (void)hipFree(a->d_values);
+    (void)hipFree(a->d_meta);
+    (void)hipFree(a->d_desc);
     (void)hipFree(a->d_x);
     (void)hipFree(a->d_y);
     if (a->stream) (void)hipStreamDestroy(a->stream);
@@ -107,9 +275,11 @@ static int csc_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t
     a->nrows = nrows; a->ncols = ncols; a->nnz = nnz;
     a->kernel = 1;
     a->lanes_per_col = pick_lanes_csc(ncols ? (double)nnz / (double)ncols : 0.0);
+    const uint64_t cap = nnz + kStreamPad;  // whole-step reads of the LDS-mode stream
     hipError_t e = hipMalloc(&a->d_colptr, (ncols + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&a->d_rowind, std::max<uint64_t>(nnz, 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&a->d_values, std::max<uint64_t>(nnz, 1) * sizeof(T));
+    if (e == hipSuccess) e = hipMalloc(&a->d_rowind, cap * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&a->d_values, cap * sizeof(T));
+    if (e == hipSuccess) e = hipMemset((char *)a->d_values + nnz * sizeof(T), 0, kStreamPad * sizeof(T));
     if (e == hipSuccess) e = hipMemcpy(a->d_colptr, cp32.data(), (ncols + 1) * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && nnz) e = hipMemcpy(a->d_rowind, ri32.data(), nnz * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && nnz) e = hipMemcpy(a->d_values, values, nnz * sizeof(T), hipMemcpyHostToDevice);
@@ -119,6 +289,8 @@ static int csc_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t
         return fail(e == hipErrorOutOfMemory ? SPAL_ERR_OUT_OF_MEMORY : SPAL_ERR_HIP,
                     "spal_csc_create: upload failed: %s", hipGetErrorString(e));
     }
+    int st = csc_plan_build(a);
+    if (st != SPAL_OK) { csc_free(a); return st; }
     *out = a;
     return SPAL_OK;
 }
@@ -207,6 +379,9 @@ int spal_csc_spmv_dev_f32(spal_csc_t a, const float *x_dev, float *y_dev, void *
 }
 int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value) {
     if (!a || !key) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csc_set_option: null argument");
+    DeviceGuard guard(a->device);
+    if (guard.status != SPAL_OK) return guard.status;
+    std::lock_guard<std::mutex> lock(a->mu);
     if (!strcmp(key, "lanes_per_col")) {
         if (value == 0) {
             a->lanes_per_col = pick_lanes_csc(a->ncols ? (double)a->nnz / (double)a->ncols : 0.0);
@@ -217,15 +392,24 @@ int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value) {
         a->lanes_per_col = (int)value;
         return SPAL_OK;
     }
+    if (!strcmp(key, "lds")) {
+        if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "lds must be 0 or 1");
+        a->use_lds = (int)value;
+        return csc_plan_build(a);
+    }
     return fail(SPAL_ERR_INVALID_ARGUMENT, "unknown option '%s'", key);
 }
 int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len) {
     if (!a || !buf || !buf_len) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csc_describe: null argument");
     snprintf(buf, buf_len,
              "{\"format\": \"csc\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"nnz\": %llu, "
-             "\"index_bits\": 32, \"kernel\": \"atomic_scatter\", \"lanes_per_col\": %d}",
+             "\"kernel\": \"%s\", \"cols_per_block\": %d, \"blocks\": %u, \"lanes_per_col\": %d, "
+             "\"lds_window_bytes\": %llu, \"lds_col_fraction\": %.4f}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
-             (unsigned long long)a->ncols, (unsigned long long)a->nnz, a->lanes_per_col);
+             (unsigned long long)a->ncols, (unsigned long long)a->nnz,
+             a->lds_entries ? "lds_privatised_scatter" : "atomic_scatter", kCscCols, a->nblocks,
+             a->lanes_per_col, (unsigned long long)a->lds_entries * (unsigned long long)a->elem_size,
+             a->lds_col_fraction);
     return SPAL_OK;
 }
 

@@ -61,17 +61,17 @@ __global__ __launch_bounds__(256) void csr_block_windows(
 // LDS budget for the x window of the vector kernel.  160 KiB per CU; 64 KiB per
 // workgroup keeps two workgroups resident, smaller windows admit more.
 static constexpr uint32_t kLdsBudgetBytes = 64 * 1024;
-// stream kernel: 4 product strips (kStreamTileNnz each) + a window of at most
-// 40 KiB -> 72 KiB per workgroup (f64), two workgroups per CU.
-static constexpr uint32_t kStreamWindowBytes = 40 * 1024;
+// stream kernel: 4 product strips (kStreamTileNnz each, 32 KiB f64) + a window of
+// at most 48 KiB -> at most 80 KiB per workgroup, two workgroups per CU.
+static constexpr uint32_t kStreamWindowBytes = 48 * 1024;
 
 // One thread per super-tile: every 64-row tile must fit the product strip.
 __global__ __launch_bounds__(256) void csr_stream_check(const uint32_t *__restrict__ rowptr,
                                                         uint32_t nrows, uint32_t nblocks,
-                                                        uint32_t *__restrict__ ok) {
+                                                        uint32_t R, uint32_t *__restrict__ ok) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nblocks) return;
-    const uint32_t row0 = b * kStreamRows, row1 = min(row0 + (uint32_t)kStreamRows, nrows);
+    const uint32_t row0 = b * R, row1 = min(row0 + R, nrows);
     uint32_t good = 1;
     for (uint32_t r0 = row0; r0 < row1; r0 += kStreamTileRows) {
         const uint32_t rl = min(r0 + (uint32_t)kStreamTileRows, row1);
@@ -86,10 +86,10 @@ __global__ __launch_bounds__(256) void csr_encode_col16(const uint32_t *__restri
                                                         const uint32_t *__restrict__ colind,
                                                         const uint4 *__restrict__ desc,
                                                         uint16_t *__restrict__ col16,
-                                                        uint32_t nrows) {
+                                                        uint32_t nrows, uint32_t R) {
     const uint4 d = desc[blockIdx.x];
     if (d.z != kModeStream) return;
-    const uint32_t row0 = blockIdx.x * kStreamRows, row1 = min(row0 + (uint32_t)kStreamRows, nrows);
+    const uint32_t row0 = blockIdx.x * R, row1 = min(row0 + R, nrows);
     const uint32_t p0 = rowptr[row0], p1 = rowptr[row1];
     for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256) col16[p] = (uint16_t)(colind[p] - d.x);
 }
@@ -149,12 +149,12 @@ static hipError_t launch_vec_unroll(const spal_csr *a, const void *x, void *y, h
 }
 
 // stream kernel; its vector fallback for non-streamable super-tiles uses U = 2
-template <typename T, int L>
-static hipError_t launch_stream(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+template <typename T, int L, int TPW>
+static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     const CsrPlan &p = a->plan;
     const uint32_t per_xcd = (p.nblocks + 7) / 8;
     const size_t lds = ((size_t)kStreamWaves * kStreamTileNnz + p.lds_entries) * sizeof(T);
-    auto kern = csr_spmv_stream<T, L, 2, true>;
+    auto kern = csr_spmv_stream<T, L, 2, true, TPW>;
     static std::atomic<uint64_t> configured{0};
     hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
     if (e != hipSuccess) return e;
@@ -162,6 +162,12 @@ static hipError_t launch_stream(const spal_csr *a, const void *x, void *y, hipSt
                        a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc,
                        (uint32_t)a->nrows, (uint32_t)a->nnz, p.nblocks, per_xcd);
     return hipGetLastError();
+}
+
+template <typename T, int L>
+static hipError_t launch_stream(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    return a->plan.tiles_per_wave == 8 ? launch_stream_tpw<T, L, 8>(a, x, y, st)
+                                       : launch_stream_tpw<T, L, 4>(a, x, y, st);
 }
 
 template <typename T>
@@ -212,16 +218,16 @@ static int block_windows(spal_csr *a, uint32_t R, std::vector<uint2> &win) {
     return SPAL_OK;
 }
 
-// Stream plan: super-tiles of kStreamRows rows; returns the fraction of rows
+// Stream plan: super-tiles of R rows; returns the fraction of rows
 // that can be streamed and fills `desc`.
-static int stream_plan(spal_csr *a, std::vector<uint4> &desc, uint32_t &cap, double &frac) {
-    const uint32_t nb = (uint32_t)((a->nrows + kStreamRows - 1) / kStreamRows);
+static int stream_plan(spal_csr *a, uint32_t R, std::vector<uint4> &desc, uint32_t &cap, double &frac) {
+    const uint32_t nb = (uint32_t)((a->nrows + R - 1) / R);
     std::vector<uint2> win;
-    SPAL_TRY(block_windows(a, kStreamRows, win));
+    SPAL_TRY(block_windows(a, R, win));
     uint32_t *d_ok = nullptr;
     SPAL_HIP_TRY(hipMalloc(&d_ok, (size_t)nb * 4));
     hipLaunchKernelGGL(csr_stream_check, dim3((nb + 255) / 256), dim3(256), 0, a->stream, a->d_rowptr,
-                       (uint32_t)a->nrows, nb, d_ok);
+                       (uint32_t)a->nrows, nb, R, d_ok);
     std::vector<uint32_t> ok(nb);
     hipError_t e = hipMemcpyAsync(ok.data(), d_ok, (size_t)nb * 4, hipMemcpyDeviceToHost, a->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
@@ -233,7 +239,7 @@ static int stream_plan(spal_csr *a, std::vector<uint4> &desc, uint32_t &cap, dou
     uint64_t rows_stream = 0;
     cap = 0;
     for (uint32_t b = 0; b < nb; ++b) {
-        const uint64_t rows = std::min<uint64_t>(kStreamRows, a->nrows - (uint64_t)b * kStreamRows);
+        const uint64_t rows = std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
         uint2 w = win[b];
         if (w.y == 0) {  // nothing stored: stream mode with a 1-element window writes the zeros
             desc[b] = make_uint4(0, valign, kModeStream, 0);
@@ -282,10 +288,12 @@ int csr_plan_build(spal_csr *a) {
         std::vector<uint4> desc;
         uint32_t cap = 0;
         double frac = 0.0;
-        SPAL_TRY(stream_plan(a, desc, cap, frac));
+        if (p.tiles_per_wave != 4 && p.tiles_per_wave != 8) p.tiles_per_wave = 4;
+        const uint32_t R = (uint32_t)stream_rows(p.tiles_per_wave);
+        SPAL_TRY(stream_plan(a, R, desc, cap, frac));
         if (p.user_kernel == 2 || frac >= 0.5) {
             p.kernel = 2;
-            p.rows_per_block = kStreamRows;
+            p.rows_per_block = (int)R;
             p.threads = kStreamBlock;
             p.nblocks = (uint32_t)desc.size();
             p.lds_x = cap > 0;
@@ -294,7 +302,7 @@ int csr_plan_build(spal_csr *a) {
             uint64_t lds_rows = 0;
             for (uint32_t b = 0; b < p.nblocks; ++b)
                 if (desc[b].z != kModeVectorGlobal)
-                    lds_rows += std::min<uint64_t>(kStreamRows, a->nrows - (uint64_t)b * kStreamRows);
+                    lds_rows += std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
             p.lds_row_fraction = (double)lds_rows / (double)a->nrows;
             SPAL_HIP_TRY(hipMalloc(&a->d_desc, (size_t)p.nblocks * sizeof(uint4)));
             SPAL_HIP_TRY(hipMemcpyAsync(a->d_desc, desc.data(), (size_t)p.nblocks * sizeof(uint4),
@@ -304,7 +312,7 @@ int csr_plan_build(spal_csr *a) {
                 SPAL_HIP_TRY(hipMemsetAsync(a->d_col16, 0, (size_t)a->cap_entries * sizeof(uint16_t), a->stream));
             }
             hipLaunchKernelGGL(csr_encode_col16, dim3(p.nblocks), dim3(256), 0, a->stream, a->d_rowptr,
-                               a->d_colind, a->d_desc, a->d_col16, (uint32_t)a->nrows);
+                               a->d_colind, a->d_desc, a->d_col16, (uint32_t)a->nrows, R);
             SPAL_HIP_TRY(hipGetLastError());
             SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
             return SPAL_OK;
@@ -646,6 +654,9 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         else if (value != 1 && value != 2 && value != 4)
             return fail(SPAL_ERR_INVALID_ARGUMENT, "unroll must be 1, 2 or 4");
         else { p.unroll = (int)value; p.user_unroll = true; }
+    } else if (!strcmp(key, "tiles_per_wave")) {
+        if (value != 4 && value != 8) return fail(SPAL_ERR_INVALID_ARGUMENT, "tiles_per_wave must be 4 or 8");
+        p.tiles_per_wave = (int)value;
     } else if (!strcmp(key, "threads")) {
         if (value == 0) p.user_threads = false;
         else if (value != 512 && value != 1024)

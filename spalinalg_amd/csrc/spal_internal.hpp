@@ -72,6 +72,7 @@ struct CsrPlan {
     int lanes_per_row = 0;   // L in {2,4,8,16,32,64}
     int unroll = 1;          // row groups in flight per wave iteration
     int threads = 512;       // workgroup size: 512 or 1024
+    int tiles_per_wave = 4;  // stream kernel: 64-row tiles per wave (4 or 8)
     int rows_per_block = 0;  // R
     int lds_x = 0;           // stage the block's x window in LDS
     uint32_t lds_entries = 0;  // LDS window capacity (elements) when lds_x
@@ -107,8 +108,14 @@ struct spal_csc {
     int elem_size = 8;
     uint64_t nrows = 0, ncols = 0, nnz = 0;
     uint32_t *d_colptr = nullptr;  // ncols + 1
-    uint32_t *d_rowind = nullptr;  // nnz
-    void *d_values = nullptr;
+    uint32_t *d_rowind = nullptr;  // nnz (+pad)
+    void *d_values = nullptr;      // nnz (+pad)
+    uint32_t *d_meta = nullptr;    // nnz (+pad): (row - window base) | (col - tile base) << 16
+    uint4 *d_desc = nullptr;       // per 1024-column super-tile {window base row, length, mode, 0}
+    uint32_t nblocks = 0;
+    uint32_t lds_entries = 0;      // largest LDS y window (elements); 0 = global scatter only
+    double lds_col_fraction = 0.0;
+    int use_lds = 1;
     int kernel = 0;
     int lanes_per_col = 0;
     std::mutex mu;

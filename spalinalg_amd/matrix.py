@@ -147,6 +147,32 @@ class DeviceCsc(_DeviceMatrix):
     _kind = "csc"
 
 
+class DeviceCoo:
+    """Device-resident COO triplets (SoA, 32-bit indices): the input of the
+    timed assembly path."""
+
+    def __init__(self, handle, dtype, device, nrows, ncols, length):
+        self._h, self.dtype, self.device = handle, np.dtype(dtype), device
+        self.nrows, self.ncols, self.length = nrows, ncols, length
+
+    def assemble_csr(self, stream=None) -> DeviceCsr:
+        """COO -> CSR on the device (one host sync for the output size)."""
+        out = vp()
+        check(_ffi.lib().spal_coo_assemble_csr(self._h, _stream_ptr(stream), C.byref(out)))
+        return DeviceCsr(out, self.dtype, self.device)
+
+    def close(self):
+        if self._h is not None:
+            _ffi.lib().spal_coo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # --------------------------------------------------------------------------
 # CsrMatrix / CscMatrix
 # --------------------------------------------------------------------------
@@ -376,6 +402,14 @@ class CooMatrix:
     def iter(self):
         r, c, v = self.triplets()
         return zip(r.tolist(), c.tolist(), v.tolist())
+
+    def upload(self, device: int = 0) -> DeviceCoo:
+        r, c, v = self.triplets()
+        out = vp()
+        check(getattr(_ffi.lib(), f"spal_coo_upload_{_sfx(self._dtype)}")(
+            C.c_int(device), u64(self._nrows), u64(self._ncols), u64(v.size), _p(r), _p(c), _p(v),
+            C.byref(out)))
+        return DeviceCoo(out, self._dtype, device, self._nrows, self._ncols, v.size)
 
     def assemble_csr(self, device: int = 0) -> DeviceCsr:
         r, c, v = self.triplets()

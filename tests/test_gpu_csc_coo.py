@@ -31,6 +31,40 @@ def test_csc_random(oracle, dtype):
         assert_spmv_close(y, y_ref, bound, 1e-10 if dtype == np.float64 else 1e-4)
 
 
+def test_csc_lds_and_global_paths(oracle):
+    """banded columns use the LDS-privatised scatter; a few full-height columns
+    force single super-tiles onto the global-atomic path; both must agree with
+    the oracle, as must the forced global path."""
+    rng = np.random.default_rng(8)
+    n = 30_000
+    rp, ci, va = sp.synth.banded_csr(n, n, 14, 2048, 21)
+    cp, ri, cv = oracle.transpose(n, n, rp, ci, va)        # CSC of a banded matrix
+    cols = [ri[int(cp[k]):int(cp[k + 1])] for k in range(n)]
+    vals = [cv[int(cp[k]):int(cp[k + 1])] for k in range(n)]
+    for k in (5, 12_000, 29_999):                           # tall columns: window too large for LDS
+        cols[k] = np.sort(rng.choice(n, 3000, replace=False)).astype(np.uint64)
+        vals[k] = rng.uniform(-1, 1, 3000)
+    cp = np.concatenate([[0], np.cumsum([c.size for c in cols])]).astype(np.uint64)
+    ri, cv = np.concatenate(cols), np.concatenate(vals)
+    x = sp.synth.vector(n)
+    x[12_000] = np.inf
+    m = sp.CscMatrix(n, n, cp, ri, cv)
+    rp2, ci2, va2 = oracle.transpose(n, n, cp, ri, cv)      # rows again, for the error bound
+    y_ref = oracle.csc_spmv(n, cp, ri, cv, x)
+    bound = oracle.csr_abs_bound(rp2, ci2, va2, np.nan_to_num(x, posinf=0.0))
+    dev = m.device()
+    d = dev.describe()
+    assert d["kernel"] == "lds_privatised_scatter" and 0.8 < d["lds_col_fraction"] < 1.0
+    assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10)
+    dev.set_option("lds", 0)
+    assert dev.describe()["kernel"] == "atomic_scatter"
+    assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10)
+    dev.set_option("lds", 1)
+    for lanes in (2, 64):
+        dev.set_option("lanes_per_col", lanes)
+        assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10)
+
+
 def test_csc_config4(oracle):
     """BASELINE config 4: CSC of the config-2 matrix, 1M x 1M."""
     n = 1_000_000
@@ -41,6 +75,9 @@ def test_csc_config4(oracle):
     y = m * x
     y_ref = oracle.csc_spmv(n, cp, ri, cv, x)
     assert_spmv_close(y, y_ref, oracle.csr_abs_bound(rp, ci, va, x), 1e-10)
+    assert m.device().describe()["lds_col_fraction"] > 0.99
+    y32 = sp.CscMatrix(n, n, cp, ri, cv.astype(np.float32)) * x.astype(np.float32)
+    assert_spmv_close(y32, y_ref, oracle.csr_abs_bound(rp, ci, va, x), 1e-4)
     with pytest.raises(sp.Panic):
         m * np.ones(n - 1)
 

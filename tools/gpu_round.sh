@@ -22,6 +22,10 @@ for s in "$@"; do
     tests)  step 900 pytest_gpu.log python -m pytest tests -x -q -m gpu ;;
     testsall) step 900 pytest_gpu.log python -m pytest tests -q -m gpu ;;
     lab)    step 600 lab.log python tools/lab_csr.py --out gpurun_out/lab.json ;;
+    other)  step 900 lab_other.log python tools/lab_other.py $OTHER_ARGS ;;
+    profother) export TMPDIR=/tmp
+            step 600 prof_other.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_other -o other -- python3 tools/lab_other.py $OTHER_ARGS ;;
+    ab)     step 600 lab_ab.log python tools/lab_ab.py $AB_ARGS ;;
     bench)  step 400 bench.log python bench.py ;;
     prof)   # per-kernel time (stats) and, in separate passes, the HBM counters
             export TMPDIR=/tmp

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of CSR SpMV plan variants in ONE process on ONE device
+(N variants x M rounds, median and min reported): the only way to see
+differences smaller than the run-to-run / box-to-box spread.  Development tool.
+
+  python tools/lab_ab.py "kernel=2,tiles_per_wave=4" "kernel=2,tiles_per_wave=8"
+"""
+import os
+import statistics
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import spalinalg_amd as sp  # noqa: E402
+
+
+def main():
+    variants = [a for a in sys.argv[1:] if "=" in a]
+    flags = [a for a in sys.argv[1:] if "=" not in a]
+    n = 10_000_000
+    window = None if "uniform" in flags else 4096
+    dtype = np.float32 if "f32" in flags else np.float64
+    rounds, iters = 7, 25
+    rp, ci, va = sp.synth.banded_csr(n, n, 14, window or n, sp.synth.matrix_seed(3), dtype=dtype)
+    devs = []
+    for v in variants:  # one handle per variant: no re-planning inside the timed rounds
+        d = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
+        for kv in v.split(","):
+            k, val = kv.split("=")
+            d.set_option(k, int(val))
+        devs.append(d)
+    x = torch.from_numpy(sp.synth.vector(n, dtype=dtype)).cuda()
+    y = torch.empty_like(x)
+    yref = devs[0].spmv_torch(x).clone()
+    B = sp.synth.spmv_bytes(n * 14, n, n, n, np.dtype(dtype).itemsize)
+    times = [[] for _ in variants]
+    for r in range(rounds):
+        for i, d in enumerate(devs):
+            for _ in range(3):
+                d.spmv_torch(x, out=y)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                d.spmv_torch(x, out=y)
+            e1.record()
+            torch.cuda.synchronize()
+            times[i].append(e0.elapsed_time(e1) / iters * 1e3)
+    for v, t, d in zip(variants, times, devs):
+        ok = bool(torch.equal(d.spmv_torch(x), yref))
+        med, mn = statistics.median(t), min(t)
+        print(f"{v:48s} median {med:7.1f} us  min {mn:7.1f} us  {B/med/1e3:7.1f} GB/s ({100*B/med/1e3/8000:5.2f} %)  "
+              f"bit-equal-to-first={ok}  rounds={[round(q) for q in t]}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
