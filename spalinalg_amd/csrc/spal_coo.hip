@@ -1,19 +1,31 @@
-// spal_coo.hip -- COO upload and device-side COO -> CSR assembly.
+// spal_coo.hip -- COO upload, device-side COO -> CSR assembly, and the stable
+// radix sort it is built on.
 //
 // Contract (reference src/csr/conv/coo.rs:4-115):
 //   order entries by (row, col), STABLY w.r.t. insertion order;
 //   sum every run of equal (row, col) left to right (separately rounded adds);
 //   drop sums that compare equal to zero (-0.0 dropped, NaN kept);
 //   emit CSR (columns strictly increasing inside a row).
-// rowptr / colind / values are bit-identical to the reference's result: the
-// sort is a stable LSD radix sort and each run is summed by ONE thread in
-// insertion order.
+// rowptr / colind / values are bit-identical to the reference's result: every
+// reordering step is stable and each run is summed by ONE thread in insertion
+// order.
 //
-// Pipeline (all on the device, one host sync for the data-dependent size):
-//   key = row << cbits | col  (u64), payload = insertion index (u32)
-//   ceil((rbits + cbits) / 8) radix passes: histogram -> scan -> stable scatter
-//   run heads + sequential run sums -> keep flags -> scan -> compaction
-//   rowptr[r] = lower_bound(row of kept entries, r)
+// Pipeline (device only; one host sync for the data-dependent output size):
+//   1. stable LSD radix sort by ROW only (ceil(rbits / 8) passes), carrying
+//      (col, value) as payload -- entries of a row end up contiguous, still in
+//      insertion order.  Each pass: per-tile digit histogram -> scan -> scatter
+//      that first reorders the tile in LDS so every digit leaves as one
+//      contiguous, coalesced run.
+//   2. row offsets by binary search in the sorted rows.
+//   3. per 64-row tile (one wave, entries staged in LDS): each lane sorts its
+//      row by column with a stable insertion sort, sums runs of equal columns
+//      in order, drops zeros, compacts its row in place, counts what is left.
+//   4. scan of the per-row counts = rowptr; the tiles are compacted into the
+//      final colind / values.
+// If some 64-row tile holds more than 1024 entries (a very long row) the local
+// sort does not fit LDS: the assembly then runs the general route -- LSD passes
+// over the column bits first, then the row bits -- and a lane-sequential run
+// summation, which is correct for any input, only slower.
 #include "spal_internal.hpp"
 
 namespace spal {
@@ -85,9 +97,11 @@ __global__ __launch_bounds__(kScanThreads) void scan_sums_inplace(uint32_t *sums
     if (grand && threadIdx.x == 0) *grand = carry;
 }
 
+// out[i] = prefix; when `closing` is set out[n] = grand total as well
 __global__ __launch_bounds__(kScanThreads) void scan_apply(const uint32_t *__restrict__ in,
                                                            uint32_t *__restrict__ out, uint64_t n,
-                                                           const uint32_t *__restrict__ sums) {
+                                                           const uint32_t *__restrict__ sums,
+                                                           int closing) {
     // thread owns kScanItems CONSECUTIVE elements so the scan order is the array order
     const uint64_t t0 = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
     uint32_t v[kScanItems];
@@ -103,47 +117,40 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply(const uint32_t *__res
     for (int j = 0; j < kScanItems; ++j) {
         if (t0 + j < n) out[t0 + j] = ex;
         ex += v[j];
+        if (closing && t0 + j + 1 == n) out[n] = ex;
     }
 }
 
-// out[i] = sum in[0..i) ; *d_total (device, may be NULL) = sum of all.  `sums`
-// must hold ceil(n / kScanTile) u32.  in == out allowed.
+// out[i] = sum in[0..i); *d_total (device, may be NULL) = sum of all; with
+// `closing`, out must have n + 1 entries and out[n] = the total.  `sums` must
+// hold ceil(n / kScanTile) u32.  in == out allowed.
 static hipError_t exclusive_scan_u32(const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *sums,
-                                     uint32_t *d_total, hipStream_t st) {
+                                     uint32_t *d_total, hipStream_t st, bool closing = false) {
     if (n == 0) {
-        if (d_total) return hipMemsetAsync(d_total, 0, sizeof(uint32_t), st);
-        return hipSuccess;
+        hipError_t e = hipSuccess;
+        if (d_total) e = hipMemsetAsync(d_total, 0, sizeof(uint32_t), st);
+        if (e == hipSuccess && closing) e = hipMemsetAsync(out, 0, sizeof(uint32_t), st);
+        return e;
     }
     const uint32_t tiles = (uint32_t)((n + kScanTile - 1) / kScanTile);
     hipLaunchKernelGGL(scan_tile_sums, dim3(tiles), dim3(kScanThreads), 0, st, in, n, sums);
     hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(kScanThreads), 0, st, sums, tiles, d_total);
-    hipLaunchKernelGGL(scan_apply, dim3(tiles), dim3(kScanThreads), 0, st, in, out, n, sums);
+    hipLaunchKernelGGL(scan_apply, dim3(tiles), dim3(kScanThreads), 0, st, in, out, n, sums,
+                       closing ? 1 : 0);
     return hipGetLastError();
 }
 
 // --------------------------------------------------------------------------
-// stable LSD radix sort of (u64 key, u32 payload), 8 bits per pass
+// stable LSD radix sort: (u32 key, u32 aux, T value), 8 bits per pass
 // --------------------------------------------------------------------------
 constexpr int kSortThreads = 256;
 constexpr int kSortWaves = kSortThreads / 64;
 constexpr int kSortItems = 16;                            // per thread
-constexpr int kSortTile = kSortThreads * kSortItems;      // 4096 keys per workgroup
-constexpr int kWaveChunk = 64 * kSortItems;               // 1024 consecutive keys per wave
-
-__global__ __launch_bounds__(256) void coo_make_keys(const uint32_t *__restrict__ rows,
-                                                     const uint32_t *__restrict__ cols,
-                                                     uint64_t *__restrict__ keys,
-                                                     uint32_t *__restrict__ idx, uint64_t len,
-                                                     uint32_t cbits) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < len) {
-        keys[i] = ((uint64_t)rows[i] << cbits) | (uint64_t)cols[i];
-        idx[i] = (uint32_t)i;
-    }
-}
+constexpr int kSortTile = kSortThreads * kSortItems;      // 4096 entries per workgroup
+constexpr int kWaveChunk = 64 * kSortItems;               // 1024 consecutive entries per wave
 
 // counts[d * nblk + blk] = number of keys of tile blk with digit d
-__global__ __launch_bounds__(kSortThreads) void radix_hist(const uint64_t *__restrict__ keys,
+__global__ __launch_bounds__(kSortThreads) void radix_hist(const uint32_t *__restrict__ keys,
                                                            uint64_t len, uint32_t shift,
                                                            uint32_t *__restrict__ counts,
                                                            uint32_t nblk) {
@@ -154,46 +161,58 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist(const uint64_t *__res
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {
         const uint64_t i = t0 + (uint64_t)j * kSortThreads + threadIdx.x;
-        if (i < len) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 0xffu], 1u);
+        if (i < len) atomicAdd(&h[(keys[i] >> shift) & 0xffu], 1u);
     }
     __syncthreads();
     counts[(uint64_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
 }
 
-// Stable scatter.  Wave w of a workgroup owns the tile's keys [w*1024, (w+1)*1024)
+// Stable scatter of one tile.  Wave w owns the tile's entries [w*1024, (w+1)*1024)
 // and walks them 64 at a time, so tile order = (wave, round, lane).  The rank
-// of a key among equal digits is
-//   offs[d][blk] (scanned counts) + keys of earlier waves + keys of earlier
-//   rounds of this wave + earlier lanes of this round,
-// all computed without atomics, hence deterministic and stable.
+// of an entry among the tile's entries with the same digit is
+//   entries of earlier waves + entries of earlier rounds of this wave +
+//   earlier lanes of this round,
+// computed from ballots and per-wave counters without atomics: deterministic
+// and stable.  The tile is first written to LDS in digit order, then copied out
+// linearly, so each digit leaves the workgroup as ONE contiguous run
+// (coalesced stores) that starts at the scanned global offset of (digit, tile).
+template <typename T>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter(
-    const uint64_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint64_t *__restrict__ kout,
-    uint32_t *__restrict__ vout, uint64_t len, uint32_t shift, const uint32_t *__restrict__ offs,
-    uint32_t nblk) {
+    const uint32_t *__restrict__ kin, const uint32_t *__restrict__ ain, const T *__restrict__ vin,
+    uint32_t *__restrict__ kout, uint32_t *__restrict__ aout, T *__restrict__ vout, uint64_t len,
+    uint32_t shift, const uint32_t *__restrict__ offs, uint32_t nblk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char spal_sort_smem[];
+    T *s_val = reinterpret_cast<T *>(spal_sort_smem);                       // kSortTile
+    uint32_t *s_key = reinterpret_cast<uint32_t *>(s_val + kSortTile);      // kSortTile
+    uint32_t *s_aux = s_key + kSortTile;                                    // kSortTile
     // volatile: lanes of a wave hand counts to each other through this array
     // between two rounds; the compiler must re-read it every round
-    __shared__ uint32_t cnt_store[kSortWaves][256];
-    volatile uint32_t (*cnt)[256] = cnt_store;
+    volatile uint32_t *cnt = s_aux + kSortTile;                             // [kSortWaves][256]
+    uint32_t *s_start = const_cast<uint32_t *>(cnt) + kSortWaves * 256;      // [256] tile-local digit start
+    uint32_t *s_delta = s_start + 256;                                       // [256] global - local
+
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (uint32_t i = threadIdx.x; i < kSortWaves * 256; i += kSortThreads) (&cnt_store[0][0])[i] = 0;
+    for (uint32_t i = threadIdx.x; i < kSortWaves * 256; i += kSortThreads) cnt[i] = 0;
     __syncthreads();
 
-    const uint64_t w0 = (uint64_t)blockIdx.x * kSortTile + (uint64_t)w * kWaveChunk;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * kSortTile;
+    const uint64_t w0 = tile0 + (uint64_t)w * kWaveChunk;
     const uint64_t lt = (1ull << lane) - 1ull;
-    uint64_t key[kSortItems];
-    uint32_t val[kSortItems], rank[kSortItems];
+    uint32_t key[kSortItems], aux[kSortItems], rank[kSortItems];
+    T val[kSortItems];
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {
         const uint64_t i = w0 + (uint64_t)j * 64 + lane;
         const bool ok = i < len;
-        key[j] = ok ? kin[i] : 0ull;
-        val[j] = ok ? vin[i] : 0u;
+        key[j] = ok ? kin[i] : 0u;
+        aux[j] = ok ? ain[i] : 0u;
+        val[j] = ok ? vin[i] : T(0);
     }
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {
         const uint64_t i = w0 + (uint64_t)j * 64 + lane;
         const bool ok = i < len;
-        const uint32_t d = (uint32_t)(key[j] >> shift) & 0xffu;
+        const uint32_t d = (key[j] >> shift) & 0xffu;
         // lanes of this round with the same digit (inactive tail lanes excluded)
         uint64_t peers = __ballot(ok);
 #pragma unroll
@@ -201,88 +220,100 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(
             const uint64_t m = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? m : ~m;
         }
-        const uint32_t before = ok ? cnt[w][d] : 0u;
+        const uint32_t before = ok ? cnt[w * 256 + d] : 0u;
         rank[j] = before + (uint32_t)__popcll(peers & lt);
         // the lowest peer lane publishes the new count (one writer per digit)
-        if (ok && (peers & lt) == 0) cnt[w][d] = before + (uint32_t)__popcll(peers);
+        if (ok && (peers & lt) == 0) cnt[w * 256 + d] = before + (uint32_t)__popcll(peers);
     }
     __syncthreads();
-    // exclusive prefix over the waves, per digit, plus the tile's global offset
+    // per digit: exclusive prefix over the waves; tile-local start of the digit;
+    // distance between the digit's global run and its place in the tile
     {
         const uint32_t d = threadIdx.x;  // 256 threads = 256 digits
-        uint32_t run = offs[(uint64_t)d * nblk + blockIdx.x];
+        uint32_t run = 0;
 #pragma unroll
         for (int ww = 0; ww < kSortWaves; ++ww) {
-            const uint32_t c = cnt[ww][d];
-            cnt[ww][d] = run;
+            const uint32_t c = cnt[ww * 256 + d];
+            cnt[ww * 256 + d] = run;
             run += c;
         }
+        uint32_t total;
+        const uint32_t start = block_exclusive_scan(run, &total);
+        s_start[d] = start;
+        s_delta[d] = offs[(uint64_t)d * nblk + blockIdx.x] - start;
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {
         const uint64_t i = w0 + (uint64_t)j * 64 + lane;
         if (i < len) {
-            const uint32_t d = (uint32_t)(key[j] >> shift) & 0xffu;
-            const uint32_t pos = cnt[w][d] + rank[j];
-            kout[pos] = key[j];
-            vout[pos] = val[j];
+            const uint32_t d = (key[j] >> shift) & 0xffu;
+            const uint32_t lp = s_start[d] + cnt[w * 256 + d] + rank[j];
+            s_key[lp] = key[j];
+            s_aux[lp] = aux[j];
+            s_val[lp] = val[j];
+        }
+    }
+    __syncthreads();
+    const uint32_t n_tile = (uint32_t)min((uint64_t)kSortTile, len - tile0);
+#pragma unroll
+    for (int j = 0; j < kSortItems; ++j) {
+        const uint32_t lp = j * kSortThreads + threadIdx.x;
+        if (lp < n_tile) {
+            const uint32_t k = s_key[lp];
+            const uint32_t gp = s_delta[(k >> shift) & 0xffu] + lp;
+            kout[gp] = k;
+            aout[gp] = s_aux[lp];
+            vout[gp] = s_val[lp];
         }
     }
 }
 
-// --------------------------------------------------------------------------
-// runs of equal keys: sequential sums in insertion order, zero drop
-// --------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void coo_run_sums(const uint64_t *__restrict__ keys,
-                                                    const uint32_t *__restrict__ idx,
-                                                    const T *__restrict__ vals, uint64_t len,
-                                                    T *__restrict__ runsum,
-                                                    uint32_t *__restrict__ keep) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= len) return;
-    const uint64_t k = keys[i];
-    uint32_t flag = 0;
-    if (i == 0 || keys[i - 1] != k) {
-        // coo.rs:42-46: colval[prev] += val, one entry after the other
-        T acc = vals[idx[i]];
-        for (uint64_t j = i + 1; j < len && keys[j] == k; ++j) acc = acc + vals[idx[j]];
-        runsum[i] = acc;
-        flag = (acc != T(0)) ? 1u : 0u;  // coo.rs:64  `colval[ptr] != T::zero()`
-    }
-    keep[i] = flag;
-}
+struct SortBuffers {
+    uint32_t *key[2] = {nullptr, nullptr};
+    uint32_t *aux[2] = {nullptr, nullptr};
+    T *val[2] = {nullptr, nullptr};
+    uint32_t *counts = nullptr;  // 256 * nblk
+    uint32_t *sums = nullptr;    // scan scratch
+};
 
 template <typename T>
-__global__ __launch_bounds__(256) void coo_compact(const uint64_t *__restrict__ keys,
-                                                   const T *__restrict__ runsum,
-                                                   const uint32_t *__restrict__ keep,
-                                                   const uint32_t *__restrict__ pos, uint64_t len,
-                                                   uint32_t cbits, uint32_t *__restrict__ out_row,
-                                                   uint32_t *__restrict__ out_col,
-                                                   T *__restrict__ out_val) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= len || !keep[i]) return;
-    const uint32_t q = pos[i];
-    const uint64_t k = keys[i];
-    out_row[q] = (uint32_t)(k >> cbits);
-    out_col[q] = (uint32_t)(k & ((1ull << cbits) - 1ull));
-    out_val[q] = runsum[i];
+static size_t sort_lds_bytes() {
+    return (size_t)kSortTile * (sizeof(T) + 8) + (size_t)(kSortWaves * 256 + 512) * 4;
 }
 
-// rowptr[r] = first kept entry whose row is >= r   (r in [0, nrows])
-__global__ __launch_bounds__(256) void coo_rowptr(const uint32_t *__restrict__ out_row,
-                                                  uint32_t nnz, uint32_t nrows,
-                                                  uint32_t *__restrict__ rowptr) {
-    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r > nrows) return;
-    uint32_t lo = 0, hi = nnz;
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if ((uint64_t)out_row[mid] < r) lo = mid + 1; else hi = mid;
+// Sorts by bits [lo_bit, lo_bit + nbits) of key, stably.  The first pass reads
+// (k_in, a_in, v_in) when given (the caller's arrays, left untouched), else
+// buffer set `cur`; `cur` is updated to the set that holds the result.
+template <typename T>
+static hipError_t radix_sort_bits(SortBuffers<T> &b, uint64_t len, uint32_t lo_bit, uint32_t nbits,
+                                  int &cur, hipStream_t st, const uint32_t *k_in = nullptr,
+                                  const uint32_t *a_in = nullptr, const T *v_in = nullptr) {
+    if (len == 0) return hipSuccess;
+    const uint32_t nblk = (uint32_t)((len + kSortTile - 1) / kSortTile);
+    const uint64_t ncounts = 256ull * nblk;
+    const size_t lds = sort_lds_bytes<T>();
+    {  // > 64 KiB of dynamic LDS needs the cap raised (per device; cheap, so every call)
+        hipError_t e = hipFuncSetAttribute((const void *)radix_scatter<T>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return e;
     }
-    rowptr[r] = lo;
+    for (uint32_t shift = lo_bit; shift < lo_bit + nbits; shift += 8) {
+        const uint32_t *ki = k_in ? k_in : b.key[cur];
+        const uint32_t *ai = k_in ? a_in : b.aux[cur];
+        const T *vi = k_in ? v_in : b.val[cur];
+        const int dst = k_in ? cur : (cur ^ 1);
+        hipLaunchKernelGGL(radix_hist, dim3(nblk), dim3(kSortThreads), 0, st, ki, len, shift, b.counts,
+                           nblk);
+        hipError_t e = exclusive_scan_u32(b.counts, b.counts, ncounts, b.sums, nullptr, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(radix_scatter<T>, dim3(nblk), dim3(kSortThreads), lds, st, ki, ai, vi,
+                           b.key[dst], b.aux[dst], b.val[dst], len, shift, b.counts, nblk);
+        cur = dst;
+        k_in = nullptr;
+    }
+    return hipGetLastError();
 }
 
 static uint32_t bits_for(uint64_t n) {  // bits needed for values in [0, n)
@@ -299,86 +330,336 @@ struct DevBuf {
     void *release() { void *q = p; p = nullptr; return q; }
 };
 
+// --------------------------------------------------------------------------
+// after the row sort
+// --------------------------------------------------------------------------
+// start[r] = first sorted entry whose row is >= r   (r in [0, nrows])
+__global__ __launch_bounds__(256) void rows_lower_bound(const uint32_t *__restrict__ sorted_row,
+                                                        uint32_t n, uint32_t nrows,
+                                                        uint32_t *__restrict__ start) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r > nrows) return;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((uint64_t)sorted_row[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    start[r] = lo;
+}
+
+constexpr int kTileRows = 64;
+constexpr int kTileCap = 1024;  // entries a 64-row tile may hold for the LDS local sort
+
+// flag[0] = 1 if some 64-row tile holds more than kTileCap entries
+__global__ __launch_bounds__(256) void tiles_check(const uint32_t *__restrict__ start, uint32_t nrows,
+                                                   uint32_t *__restrict__ flag) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t r0 = t * kTileRows;
+    if (r0 >= nrows) return;
+    const uint32_t r1 = (uint32_t)min<uint64_t>(r0 + kTileRows, nrows);
+    if (start[r1] - start[r0] > (uint32_t)kTileCap) atomicOr(flag, 1u);
+}
+
+// One wave per 64-row tile.  The tile's (col, val) are staged in LDS; lane l
+// owns row (first + l): stable insertion sort by column, runs of equal columns
+// summed left to right (coo.rs:42-46), zero sums dropped (coo.rs:64), survivors
+// packed at the front of the row's segment; kept[row] = how many.  The tile is
+// written back in place.
+template <typename T>
+__global__ __launch_bounds__(256) void coo_tile_sort(const uint32_t *__restrict__ start,
+                                                     uint32_t *__restrict__ cols, T *__restrict__ vals,
+                                                     uint32_t nrows, uint32_t *__restrict__ kept) {
+    __shared__ uint32_t s_col[4][kTileCap];
+    __shared__ T s_val[4][kTileCap];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t tile = (uint64_t)blockIdx.x * 4 + w;
+    const uint64_t r0 = tile * kTileRows;
+    if (r0 >= nrows) return;  // wave-uniform
+    const uint32_t r1 = (uint32_t)min<uint64_t>(r0 + kTileRows, nrows);
+    const uint32_t e0 = start[r0], e1 = start[r1];
+    const uint32_t n = e1 - e0;  // <= kTileCap (checked by tiles_check)
+    uint32_t *c = s_col[w];
+    T *v = s_val[w];
+    for (uint32_t i = lane; i < n; i += 64) {
+        c[i] = cols[e0 + i];
+        v[i] = vals[e0 + i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t r = (uint32_t)r0 + lane;
+    if (r < r1) {
+        const uint32_t a = start[r] - e0, b = start[r + 1] - e0;
+        // stable insertion sort by column (rows are short)
+        for (uint32_t i = a + 1; i < b; ++i) {
+            const uint32_t ck = c[i];
+            const T vk = v[i];
+            uint32_t j = i;
+            while (j > a && c[j - 1] > ck) {
+                c[j] = c[j - 1];
+                v[j] = v[j - 1];
+                --j;
+            }
+            c[j] = ck;
+            v[j] = vk;
+        }
+        // runs of equal columns: left-to-right sums, drop zeros, pack
+        uint32_t out = a;
+        uint32_t i = a;
+        while (i < b) {
+            const uint32_t ck = c[i];
+            T acc = v[i];
+            for (++i; i < b && c[i] == ck; ++i) acc = acc + v[i];
+            if (acc != T(0)) {
+                c[out] = ck;
+                v[out] = acc;
+                ++out;
+            }
+        }
+        kept[r] = out - a;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < n; i += 64) {
+        cols[e0 + i] = c[i];
+        vals[e0 + i] = v[i];
+    }
+}
+
+// Packs the kept entries of every row at rowptr[row] (one wave per 64-row tile,
+// through LDS so that the writes are coalesced).
+template <typename T>
+__global__ __launch_bounds__(256) void coo_tile_pack(const uint32_t *__restrict__ start,
+                                                     const uint32_t *__restrict__ rowptr,
+                                                     const uint32_t *__restrict__ cols,
+                                                     const T *__restrict__ vals, uint32_t nrows,
+                                                     uint32_t *__restrict__ out_col,
+                                                     T *__restrict__ out_val) {
+    __shared__ uint32_t s_col[4][kTileCap];
+    __shared__ T s_val[4][kTileCap];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t tile = (uint64_t)blockIdx.x * 4 + w;
+    const uint64_t r0 = tile * kTileRows;
+    if (r0 >= nrows) return;
+    const uint32_t r1 = (uint32_t)min<uint64_t>(r0 + kTileRows, nrows);
+    const uint32_t o0 = rowptr[r0], o1 = rowptr[r1];
+    uint32_t *c = s_col[w];
+    T *v = s_val[w];
+    const uint32_t r = (uint32_t)r0 + lane;
+    if (r < r1) {
+        const uint32_t src = start[r], dst = rowptr[r] - o0, k = rowptr[r + 1] - rowptr[r];
+        for (uint32_t i = 0; i < k; ++i) {
+            c[dst + i] = cols[src + i];
+            v[dst + i] = vals[src + i];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < o1 - o0; i += 64) {
+        out_col[o0 + i] = c[i];
+        out_val[o0 + i] = v[i];
+    }
+}
+
+// ---- general route (any row length): entries fully sorted by (row, col) ------
+template <typename T>
+__global__ __launch_bounds__(256) void coo_run_sums(const uint32_t *__restrict__ row,
+                                                    const uint32_t *__restrict__ col,
+                                                    const T *__restrict__ vals, uint64_t len,
+                                                    T *__restrict__ runsum,
+                                                    uint32_t *__restrict__ keep) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    const uint32_t r = row[i], c = col[i];
+    uint32_t flag = 0;
+    if (i == 0 || row[i - 1] != r || col[i - 1] != c) {
+        // coo.rs:42-46: colval[prev] += val, one entry after the other
+        T acc = vals[i];
+        for (uint64_t j = i + 1; j < len && row[j] == r && col[j] == c; ++j) acc = acc + vals[j];
+        runsum[i] = acc;
+        flag = (acc != T(0)) ? 1u : 0u;  // coo.rs:64  `colval[ptr] != T::zero()`
+    }
+    keep[i] = flag;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void coo_compact(const uint32_t *__restrict__ row,
+                                                   const uint32_t *__restrict__ col,
+                                                   const T *__restrict__ runsum,
+                                                   const uint32_t *__restrict__ keep,
+                                                   const uint32_t *__restrict__ pos, uint64_t len,
+                                                   uint32_t *__restrict__ out_row,
+                                                   uint32_t *__restrict__ out_col,
+                                                   T *__restrict__ out_val) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len || !keep[i]) return;
+    const uint32_t q = pos[i];
+    out_row[q] = row[i];
+    out_col[q] = col[i];
+    out_val[q] = runsum[i];
+}
+
+// a typed view into the workspace (same accessors as DevBuf, owns nothing)
+struct DevView {
+    char *p;
+    template <typename U> U *as() { return reinterpret_cast<U *>(p); }
+};
+
+// One allocation for everything the assembly needs besides its output, made
+// when the COO matrix is uploaded (setup, not the timed path).
+struct CooWorkspace {
+    size_t bytes = 0;
+    size_t off_key[2], off_aux[2], off_val[2], off_counts, off_sums, off_start, off_kept, off_flag,
+        off_total;
+};
+static CooWorkspace coo_workspace_layout(uint64_t len, uint64_t nrows, size_t elem) {
+    CooWorkspace w;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 255) & ~(size_t)255; return r; };
+    const uint64_t nblk = (len + kSortTile - 1) / kSortTile;
+    const uint64_t ncounts = 256ull * std::max<uint64_t>(nblk, 1);
+    const uint64_t scan_n = std::max<uint64_t>(std::max<uint64_t>(ncounts, len), nrows + 1);
+    for (int i = 0; i < 2; ++i) {
+        w.off_key[i] = take(len * 4);
+        w.off_aux[i] = take(len * 4);
+        w.off_val[i] = take(len * elem);
+    }
+    w.off_counts = take(ncounts * 4);
+    w.off_sums = take(((scan_n + kScanTile - 1) / kScanTile) * 4);
+    w.off_start = take((nrows + 1) * 4);
+    w.off_kept = take((nrows + 1) * 4);
+    w.off_flag = take(4);
+    w.off_total = take(4);
+    w.bytes = o;
+    return w;
+}
+
 template <typename T>
 static int coo_assemble_t(spal_coo *c, hipStream_t st, spal_csr **out) {
     const uint64_t len = c->len;
+    const uint32_t nrows = (uint32_t)c->nrows;
     const uint32_t cbits = bits_for(c->ncols), rbits = bits_for(c->nrows);
-    const uint32_t nblk = (uint32_t)((len + kSortTile - 1) / kSortTile);
-    const uint64_t ncounts = 256ull * std::max<uint32_t>(nblk, 1);
-
-    DevBuf k0, k1, v0, v1, counts, sums, runsum, keep, total;
-    uint32_t nnz = 0;
-    if (len) {
-        SPAL_HIP_TRY(k0.alloc(len * 8));
-        SPAL_HIP_TRY(k1.alloc(len * 8));
-        SPAL_HIP_TRY(v0.alloc(len * 4));
-        SPAL_HIP_TRY(v1.alloc(len * 4));
-        SPAL_HIP_TRY(counts.alloc(ncounts * 4));
-        const uint64_t scan_n = std::max<uint64_t>(ncounts, len);
-        SPAL_HIP_TRY(sums.alloc(((scan_n + kScanTile - 1) / kScanTile) * 4));
-        SPAL_HIP_TRY(total.alloc(4));
-        const uint32_t g256 = (uint32_t)((len + 255) / 256);
-        hipLaunchKernelGGL(coo_make_keys, dim3(g256), dim3(256), 0, st, c->d_rows, c->d_cols,
-                           k0.as<uint64_t>(), v0.as<uint32_t>(), len, cbits);
-        uint64_t *ka = k0.as<uint64_t>(), *kb = k1.as<uint64_t>();
-        uint32_t *va = v0.as<uint32_t>(), *vb = v1.as<uint32_t>();
-        for (uint32_t shift = 0; shift < rbits + cbits; shift += 8) {
-            hipLaunchKernelGGL(radix_hist, dim3(nblk), dim3(kSortThreads), 0, st, ka, len, shift,
-                               counts.as<uint32_t>(), nblk);
-            SPAL_HIP_TRY(exclusive_scan_u32(counts.as<uint32_t>(), counts.as<uint32_t>(), ncounts,
-                                            sums.as<uint32_t>(), nullptr, st));
-            hipLaunchKernelGGL(radix_scatter, dim3(nblk), dim3(kSortThreads), 0, st, ka, va, kb, vb,
-                               len, shift, counts.as<uint32_t>(), nblk);
-            std::swap(ka, kb);
-            std::swap(va, vb);
-        }
-        SPAL_HIP_TRY(hipGetLastError());
-        // runs -> sums -> keep flags (the scratch key / payload buffers are free again)
-        SPAL_HIP_TRY(runsum.alloc(len * sizeof(T)));
-        uint32_t *d_keep = vb;                 // reuse: payload scratch
-        uint32_t *d_pos = reinterpret_cast<uint32_t *>(kb);  // reuse: key scratch (len*8 >= len*4)
-        hipLaunchKernelGGL(coo_run_sums<T>, dim3(g256), dim3(256), 0, st, ka, va,
-                           (const T *)c->d_vals, len, runsum.as<T>(), d_keep);
-        SPAL_HIP_TRY(exclusive_scan_u32(d_keep, d_pos, len, sums.as<uint32_t>(),
-                                        total.as<uint32_t>(), st));
-        SPAL_HIP_TRY(hipMemcpyAsync(&nnz, total.p, 4, hipMemcpyDeviceToHost, st));
-        SPAL_HIP_TRY(hipStreamSynchronize(st));  // the one data-dependent size
-
-        DevBuf orow, ocol, oval, rowptr;
-        SPAL_HIP_TRY(orow.alloc((size_t)nnz * 4));
-        SPAL_HIP_TRY(ocol.alloc((size_t)nnz * 4));
-        SPAL_HIP_TRY(oval.alloc((size_t)nnz * sizeof(T)));
-        SPAL_HIP_TRY(rowptr.alloc((c->nrows + 1) * 4));
-        hipLaunchKernelGGL(coo_compact<T>, dim3(g256), dim3(256), 0, st, ka, runsum.as<T>(), d_keep,
-                           d_pos, len, cbits, orow.as<uint32_t>(), ocol.as<uint32_t>(), oval.as<T>());
-        hipLaunchKernelGGL(coo_rowptr, dim3((uint32_t)((c->nrows + 1 + 255) / 256)), dim3(256), 0, st,
-                           orow.as<uint32_t>(), nnz, (uint32_t)c->nrows, rowptr.as<uint32_t>());
-        SPAL_HIP_TRY(hipGetLastError());
+    DevBuf rowptr;
+    SPAL_HIP_TRY(rowptr.alloc(((size_t)nrows + 1) * 4));
+    if (len == 0) {  // no entries at all: an empty CSR matrix
+        DevBuf ocol, oval;
+        SPAL_HIP_TRY(ocol.alloc(4));
+        SPAL_HIP_TRY(oval.alloc(sizeof(T)));
+        SPAL_HIP_TRY(hipMemsetAsync(rowptr.p, 0, ((size_t)nrows + 1) * 4, st));
         SPAL_HIP_TRY(hipStreamSynchronize(st));
         spal_csr *a = nullptr;
-        SPAL_TRY(csr_adopt_device(c->device, (int)sizeof(T), c->nrows, c->ncols, nnz, nnz,
+        SPAL_TRY(csr_adopt_device(c->device, (int)sizeof(T), c->nrows, c->ncols, 0, 0,
                                   rowptr.as<uint32_t>(), ocol.as<uint32_t>(), oval.p, &a));
         rowptr.release(); ocol.release(); oval.release();
         *out = a;
         return SPAL_OK;
     }
-    // no entries at all: an empty CSR matrix
-    DevBuf rowptr, ocol, oval;
-    SPAL_HIP_TRY(rowptr.alloc((c->nrows + 1) * 4));
-    SPAL_HIP_TRY(ocol.alloc(4));
-    SPAL_HIP_TRY(oval.alloc(sizeof(T)));
-    SPAL_HIP_TRY(hipMemsetAsync(rowptr.p, 0, (c->nrows + 1) * 4, st));
+
+    std::lock_guard<std::mutex> lock(c->mu);  // one assembly at a time per handle (shared workspace)
+    const CooWorkspace ws = coo_workspace_layout(len, nrows, sizeof(T));
+    if (!c->d_work || c->work_bytes < ws.bytes) {
+        if (c->d_work) { (void)hipFree(c->d_work); c->d_work = nullptr; }
+        SPAL_HIP_TRY(hipMalloc(&c->d_work, ws.bytes));
+        c->work_bytes = ws.bytes;
+    }
+    char *wb = (char *)c->d_work;
+    DevView start{wb + ws.off_start}, kept{wb + ws.off_kept}, flag{wb + ws.off_flag},
+        total{wb + ws.off_total}, sums{wb + ws.off_sums};
+    SortBuffers<T> sb;
+    for (int i = 0; i < 2; ++i) {
+        sb.key[i] = (uint32_t *)(wb + ws.off_key[i]);
+        sb.aux[i] = (uint32_t *)(wb + ws.off_aux[i]);
+        sb.val[i] = (T *)(wb + ws.off_val[i]);
+    }
+    sb.counts = (uint32_t *)(wb + ws.off_counts);
+    sb.sums = sums.as<uint32_t>();
+
+    // ---- 1. stable sort by row, (col, value) carried along; the first pass
+    // reads the uploaded triplets directly (they stay untouched)
+    int cur = 0;
+    SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, 0, rbits, cur, st, c->d_rows, c->d_cols,
+                                    (const T *)c->d_vals));
+    // ---- 2. row offsets, tile check
+    const uint32_t g_rows = (uint32_t)(((uint64_t)nrows + 1 + 255) / 256);
+    hipLaunchKernelGGL(rows_lower_bound, dim3(g_rows), dim3(256), 0, st, sb.key[cur], (uint32_t)len,
+                       nrows, start.as<uint32_t>());
+    SPAL_HIP_TRY(hipMemsetAsync(flag.p, 0, 4, st));
+    const uint32_t ntiles = (uint32_t)(((uint64_t)nrows + kTileRows - 1) / kTileRows);
+    hipLaunchKernelGGL(tiles_check, dim3((ntiles + 255) / 256), dim3(256), 0, st, start.as<uint32_t>(),
+                       nrows, flag.as<uint32_t>());
+    uint32_t too_long = 0;
+    SPAL_HIP_TRY(hipMemcpyAsync(&too_long, flag.p, 4, hipMemcpyDeviceToHost, st));
     SPAL_HIP_TRY(hipStreamSynchronize(st));
-    spal_csr *a = nullptr;
-    SPAL_TRY(csr_adopt_device(c->device, (int)sizeof(T), c->nrows, c->ncols, 0, 0,
-                              rowptr.as<uint32_t>(), ocol.as<uint32_t>(), oval.p, &a));
-    rowptr.release(); ocol.release(); oval.release();
-    *out = a;
+
+    uint32_t nnz = 0;
+    DevBuf ocol, oval;
+    if (!too_long) {
+        // ---- 3. per-row stable sort by column + run sums + zero drop, in LDS
+        hipLaunchKernelGGL(coo_tile_sort<T>, dim3((ntiles + 3) / 4), dim3(256), 0, st,
+                           start.as<uint32_t>(), sb.aux[cur], sb.val[cur], nrows, kept.as<uint32_t>());
+        // ---- 4. rowptr = scan of the kept counts; pack
+        SPAL_HIP_TRY(exclusive_scan_u32(kept.as<uint32_t>(), rowptr.as<uint32_t>(), nrows,
+                                        sums.as<uint32_t>(), total.as<uint32_t>(), st, true));
+        SPAL_HIP_TRY(hipMemcpyAsync(&nnz, total.p, 4, hipMemcpyDeviceToHost, st));
+        SPAL_HIP_TRY(hipStreamSynchronize(st));  // the one data-dependent size
+        const uint64_t cap = (uint64_t)nnz + 256;  // the stream kernel's over-read margin
+        SPAL_HIP_TRY(ocol.alloc(cap * 4));
+        SPAL_HIP_TRY(oval.alloc(cap * sizeof(T)));
+        SPAL_HIP_TRY(hipMemsetAsync((char *)ocol.p + (size_t)nnz * 4, 0, 256 * 4, st));
+        SPAL_HIP_TRY(hipMemsetAsync((char *)oval.p + (size_t)nnz * sizeof(T), 0, 256 * sizeof(T), st));
+        hipLaunchKernelGGL(coo_tile_pack<T>, dim3((ntiles + 3) / 4), dim3(256), 0, st,
+                           start.as<uint32_t>(), rowptr.as<uint32_t>(), sb.aux[cur], sb.val[cur], nrows,
+                           ocol.as<uint32_t>(), oval.as<T>());
+        SPAL_HIP_TRY(hipGetLastError());
+        SPAL_HIP_TRY(hipStreamSynchronize(st));
+        spal_csr *a = nullptr;
+        SPAL_TRY(csr_adopt_device(c->device, (int)sizeof(T), c->nrows, c->ncols, nnz, cap,
+                                  rowptr.as<uint32_t>(), ocol.as<uint32_t>(), oval.p, &a));
+        rowptr.release(); ocol.release(); oval.release();
+        *out = a;
+        return SPAL_OK;
+    }
+
+    // ---- general route: sort by column bits, then by row bits (LSD), with the
+    // column as key first (key <-> aux swapped for the column passes)
+    cur = 0;
+    SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, 0, cbits, cur, st, c->d_cols, c->d_rows,
+                                    (const T *)c->d_vals));
+    std::swap(sb.key[0], sb.aux[0]);  // now key = row, aux = col
+    std::swap(sb.key[1], sb.aux[1]);
+    SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, 0, rbits, cur, st));
+    uint32_t *s_row = sb.key[cur], *s_col = sb.aux[cur];
+    T *s_val = sb.val[cur];
+    uint32_t *d_keep = sb.key[cur ^ 1], *d_pos = sb.aux[cur ^ 1];  // scratch
+    T *runsum = sb.val[cur ^ 1];
+    const uint32_t g256 = (uint32_t)((len + 255) / 256);
+    hipLaunchKernelGGL(coo_run_sums<T>, dim3(g256), dim3(256), 0, st, s_row, s_col, s_val, len, runsum,
+                       d_keep);
+    SPAL_HIP_TRY(exclusive_scan_u32(d_keep, d_pos, len, sums.as<uint32_t>(), total.as<uint32_t>(), st));
+    SPAL_HIP_TRY(hipMemcpyAsync(&nnz, total.p, 4, hipMemcpyDeviceToHost, st));
+    SPAL_HIP_TRY(hipStreamSynchronize(st));
+    {
+        DevBuf orow;
+        const uint64_t cap = (uint64_t)nnz + 256;
+        SPAL_HIP_TRY(orow.alloc((size_t)nnz * 4));
+        SPAL_HIP_TRY(ocol.alloc(cap * 4));
+        SPAL_HIP_TRY(oval.alloc(cap * sizeof(T)));
+        SPAL_HIP_TRY(hipMemsetAsync((char *)ocol.p + (size_t)nnz * 4, 0, 256 * 4, st));
+        SPAL_HIP_TRY(hipMemsetAsync((char *)oval.p + (size_t)nnz * sizeof(T), 0, 256 * sizeof(T), st));
+        hipLaunchKernelGGL(coo_compact<T>, dim3(g256), dim3(256), 0, st, s_row, s_col, runsum, d_keep,
+                           d_pos, len, orow.as<uint32_t>(), ocol.as<uint32_t>(), oval.as<T>());
+        hipLaunchKernelGGL(rows_lower_bound, dim3(g_rows), dim3(256), 0, st, orow.as<uint32_t>(), nnz,
+                           nrows, rowptr.as<uint32_t>());
+        SPAL_HIP_TRY(hipGetLastError());
+        SPAL_HIP_TRY(hipStreamSynchronize(st));
+        spal_csr *a = nullptr;
+        SPAL_TRY(csr_adopt_device(c->device, (int)sizeof(T), c->nrows, c->ncols, nnz, cap,
+                                  rowptr.as<uint32_t>(), ocol.as<uint32_t>(), oval.p, &a));
+        rowptr.release(); ocol.release(); oval.release();
+        *out = a;
+    }
     return SPAL_OK;
 }
 
 static void coo_free(spal_coo *c) {
     if (!c) return;
+    (void)hipFree(c->d_work);
     (void)hipFree(c->d_rows);
     (void)hipFree(c->d_cols);
     (void)hipFree(c->d_vals);
@@ -395,7 +676,7 @@ static int coo_upload(int device, uint64_t nrows, uint64_t ncols, uint64_t len, 
     // CooMatrix::new asserts (src/coo.rs:105-106)
     if (!(nrows > 0)) return fail(SPAL_ERR_INVARIANT, "CooMatrix::new would panic: assertion failed: nrows > 0");
     if (!(ncols > 0)) return fail(SPAL_ERR_INVARIANT, "CooMatrix::new would panic: assertion failed: ncols > 0");
-    if (nrows > 0xffffffffull || ncols > 0xffffffffull || len >= 0xffffffffull)
+    if (nrows >= 0xffffffffull || ncols > 0xffffffffull || len >= 0xffffffffull)
         return fail(SPAL_ERR_UNSUPPORTED, "COO shape does not fit 32-bit device indices");
     // every entry inside the matrix (push asserts, src/coo.rs:432-433)
     std::vector<uint32_t> r32(len), c32(len);
@@ -421,6 +702,10 @@ static int coo_upload(int device, uint64_t nrows, uint64_t ncols, uint64_t len, 
     if (e == hipSuccess && len) e = hipMemcpy(c->d_rows, r32.data(), len * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess && len) e = hipMemcpy(c->d_cols, c32.data(), len * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess && len) e = hipMemcpy(c->d_vals, vals, len * sizeof(T), hipMemcpyHostToDevice);
+    if (e == hipSuccess && len) {  // the assembly's workspace: setup, not the timed path
+        c->work_bytes = coo_workspace_layout(len, nrows, sizeof(T)).bytes;
+        e = hipMalloc(&c->d_work, c->work_bytes);
+    }
     if (e != hipSuccess) {
         coo_free(c);
         return fail(e == hipErrorOutOfMemory ? SPAL_ERR_OUT_OF_MEMORY : SPAL_ERR_HIP,

@@ -129,6 +129,9 @@ struct spal_coo {
     uint64_t nrows = 0, ncols = 0, len = 0;
     uint32_t *d_rows = nullptr, *d_cols = nullptr;
     void *d_vals = nullptr;
+    void *d_work = nullptr;   // sort buffers + scratch of the assembly, allocated at upload
+    size_t work_bytes = 0;
+    std::mutex mu;            // serialises assemblies on one handle (shared workspace)
 };
 
 namespace spal {
