@@ -38,8 +38,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", type=int, default=3, choices=[2, 3],
-                    help="BASELINE config: 3 = 10Mx10M/140M nnz (headline), 2 = 1Mx1M/14M nnz")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
+                    help="BASELINE config: 3 = CSR 10Mx10M/140M nnz (headline, the default line), "
+                         "2 = CSR 1Mx1M/14M nnz, 4 = CSC scatter 1Mx1M, 5 = COO->CSR assembly 50M entries")
     ap.add_argument("--dist", default="banded", choices=["banded", "uniform"],
                     help="column distribution: banded W=4096 (headline) or uniform (stress row)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
@@ -49,8 +50,147 @@ def parse():
     return ap.parse_args()
 
 
+def timed(fn, steps, warmup, torch):
+    """K calls of fn between HIP events on torch's current stream (= the launch stream)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def bench_csc(args):
+    """BASELINE config 4: CscMatrix f64 SpMV (atomic scatter path), CSC of the config-2 matrix."""
+    import torch
+    import scipy.sparse as sps
+    import spalinalg_amd as sp
+    cfg = sp.synth.CONFIGS[4]
+    n, per_row = cfg["nrows"], cfg["per_row"]
+    np_dt = np.float64 if args.dtype == "f64" else np.float32
+    esz = np.dtype(np_dt).itemsize
+    rp, ci, va = sp.synth.banded_csr(n, n, per_row, cfg["window"], sp.synth.matrix_seed(2), dtype=np_dt)
+    csc = sps.csr_matrix((va, ci.astype(np.int64), rp.astype(np.int64)), shape=(n, n)).tocsc()
+    csc.sort_indices()
+    cp, ri, cv = csc.indptr.astype(np.uint64), csc.indices.astype(np.uint64), csc.data.astype(np_dt)
+    m = sp.CscMatrix(n, n, cp, ri, cv)
+    dev = m.device()
+    for kv in args.opt:
+        k, v = kv.split("=")
+        dev.set_option(k, int(v))
+    xh = sp.synth.vector(n, dtype=np_dt)
+    x = torch.from_numpy(xh).cuda()
+    y = torch.empty_like(x)
+    ms = timed(lambda: dev.spmv_torch(x, out=y), args.steps, args.warmup, torch)
+    nnz = n * per_row
+    B = sp.synth.spmv_bytes(nnz, n, n, n, esz)
+    out = base_record(args, "CSC SpMV GFLOP/s (f64, 1Mx1M, 14M nnz, atomic scatter)",
+                      sp.synth.spmv_flops(nnz) / (ms * 1e-3) / 1e9, "GFLOP/s", ms,
+                      f"CscMatrix {args.dtype} SpMV y=A*x by atomic scatter, {n}x{n}, {nnz} nnz, CSC of the "
+                      f"config-2 banded matrix (BASELINE configs[3]), single GPU", dev.describe())
+    out["roofline"] = {"bound": "hbm", "achieved": round(B / (ms * 1e-3) / 1e9, 2), "peak": 8000.0,
+                       "unit": "GB/s", "frac": round(B / (ms * 1e-3) / 8e12, 4), "traffic": None,
+                       "kernel": "csc_spmv_scatter (+ y memset)", "kernel_ms": round(ms, 6),
+                       "algorithmic_bytes_per_launch": B,
+                       "note": "bound in practice by LDS / global float-atomic rates, not by HBM"}
+    if not args.no_cpu_baseline:
+        import oracle  # CPU baseline leg only
+        t0, passes = time.perf_counter(), 0
+        while True:
+            yh = oracle.csc_spmv(n, cp, ri, cv, xh)
+            passes += 1
+            el = time.perf_counter() - t0
+            if el >= args.cpu_seconds or passes >= 50:
+                break
+        out["cpu_baseline"] = {"value": round(sp.synth.spmv_flops(nnz) * passes / el / 1e9, 4), "unit": "GFLOP/s",
+                               "cores": 1, "kind": "port",
+                               "sample": f"{passes} full passes over the same matrix in {el:.1f} s, 1 thread",
+                               "gpu_agrees_with_cpu": bool(np.allclose(y.cpu().numpy(), yh, rtol=1e-10 if esz == 8 else 1e-4,
+                                                                       atol=1e-12 if esz == 8 else 1e-5))}
+    print(json.dumps(out))
+
+
+def bench_coo(args):
+    """BASELINE config 5: CooMatrix -> CsrMatrix on the device, 50M random triplets
+    (+1 % duplicates, +0.1 % cancelling pairs) into 5M x 5M, then one SpMV on the result."""
+    import torch
+    import spalinalg_amd as sp
+    cfg = sp.synth.CONFIGS[5]
+    nr, length = cfg["nrows"], cfg["length"]
+    np_dt = np.float64 if args.dtype == "f64" else np.float32
+    esz = np.dtype(np_dt).itemsize
+    r, c, v = sp.synth.coo(nr, nr, length, sp.synth.matrix_seed(5), cfg["dup_permille"], cfg["cancel_permille"],
+                           dtype=np_dt)
+    coo = sp.CooMatrix.with_triplets(nr, nr, r, c, v)
+    d = coo.upload()      # triplets + workspace resident in HBM before the timed region
+    torch.cuda.synchronize()
+    steps = max(1, min(args.steps, 20))
+    warm = max(1, min(args.warmup, 3))
+    for _ in range(warm):
+        d.assemble_csr().close()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        csr = d.assemble_csr()      # includes its one host sync and the CSR handle's planning
+        nnz = csr.shape()[2]
+        if _ + 1 < steps:
+            csr.close()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    # the assembled matrix multiplies (the config's second half)
+    x = torch.from_numpy(sp.synth.vector(nr, dtype=np_dt)).cuda()
+    y = torch.empty_like(x)
+    spmv_ms = timed(lambda: csr.spmv_torch(x, out=y), 20, 3, torch)
+    lb = sp.synth.assembly_bytes(length, nnz, nr, esz)
+    args.steps, args.warmup = steps, warm
+    out = base_record(args, "COO->CSR assembly Mentries/s (f64, 50M triplets into 5Mx5M)",
+                      length / (ms * 1e-3) / 1e6, "Mentries/s", ms,
+                      f"CooMatrix->CsrMatrix device assembly, {length} random triplets (+1% duplicates, +0.1% "
+                      f"cancelling pairs) into {nr}x{nr} -> {nnz} stored entries (BASELINE configs[4]), single GPU",
+                      csr.describe())
+    out["roofline"] = {"bound": "hbm", "achieved": round(lb / (ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                       "frac": round(lb / (ms * 1e-3) / 8e12, 4), "traffic": None,
+                       "kernel": "radix_scatter x3 + coo_tile_sort + coo_tile_pack (whole assembly call)",
+                       "kernel_ms": round(ms, 6), "algorithmic_bytes_per_launch": lb,
+                       "note": "algorithmic = lower bound 16*len + 12*nnz_out + 4*(nrows+1); a multi-pass sort "
+                               "inherently moves several times this"}
+    out["spmv_on_result"] = {"ms": round(spmv_ms, 6),
+                             "gflops": round(sp.synth.spmv_flops(nnz) / (spmv_ms * 1e-3) / 1e9, 2)}
+    if not args.no_cpu_baseline:
+        import oracle  # CPU baseline leg only
+        sample = min(length, 5_000_000)
+        t0 = time.perf_counter()
+        p, i, w = oracle.coo_to_csr(nr, nr, r[:sample], c[:sample], v[:sample])
+        el = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(sample / el / 1e6, 3), "unit": "Mentries/s", "cores": 1, "kind": "port",
+                               "sample": f"the first {sample} of the {length} triplets (same {nr}x{nr} shape) in {el:.1f} s, "
+                                         f"1 thread (restatement of src/csr/conv/coo.rs:4-115)"}
+        # full-size bit-exact check of the GPU result against the CPU oracle would take ~10x the sample time;
+        # it is done at 2M entries in tests/test_gpu_csc_coo.py
+    print(json.dumps(out))
+
+
+def base_record(args, metric, value, unit, ms, workload, plan):
+    return {"metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 6), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": workload, "plan": plan}}
+
+
 def main():
     args = parse()
+    if args.config in (4, 5):
+        if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            sys.exit("configs 4 and 5 are single-GPU (BASELINE.json); only the CSR configs shard over GPUs")
+        import torch
+        import spalinalg_amd as sp
+        if not torch.cuda.is_available() or sp.device_count() < 1:
+            sys.exit("bench.py needs a GPU: libspal_hip has no CPU fallback")
+        return bench_csc(args) if args.config == 4 else bench_coo(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

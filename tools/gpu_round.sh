@@ -27,6 +27,9 @@ for s in "$@"; do
             step 600 prof_other.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_other -o other -- python3 tools/lab_other.py $OTHER_ARGS ;;
     ab)     step 600 lab_ab.log python tools/lab_ab.py $AB_ARGS ;;
     bench)  step 400 bench.log python bench.py ;;
+    bench4) step 400 bench4.log python bench.py --config 4 ;;
+    bench5) step 600 bench5.log python bench.py --config 5 ;;
+    bench2) step 400 bench2.log python bench.py --config 2 ;;
     prof)   # per-kernel time (stats) and, in separate passes, the HBM counters
             export TMPDIR=/tmp
             step 400 prof_stats.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -o bench -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline
