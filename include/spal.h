@@ -145,8 +145,27 @@ int spal_csc_spmv_dev_f64(spal_csc_t a, const double *x_dev, double *y_dev,
                           void *stream);
 int spal_csc_spmv_dev_f32(spal_csc_t a, const float *x_dev, float *y_dev,
                           void *stream);
+int spal_csc_download_f64(spal_csc_t a, uint64_t *colptr, uint64_t *rowind,
+                          double *values);
+int spal_csc_download_f32(spal_csc_t a, uint64_t *colptr, uint64_t *rowind,
+                          float *values);
+/* Keys: "kernel" 1 = atomic scatter (LDS-privatised where the row window of a
+ * 1024-column block fits LDS, global atomics otherwise), 2 = transposed: the
+ * matrix is converted to CSR on the device once and the CSR kernels run
+ * (deterministic; bit-identical to the reference's k-ascending order), 0 = auto
+ * (= 2).  "lds" 0/1, "lanes_per_col" tune kernel 1. */
 int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value);
 int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len);
+
+/* ---- CSR <-> CSC on the device ------------------------------------------------
+ * Replace `impl From<&CscMatrix<T>> for CsrMatrix<T>` (src/csr/conv/csc.rs:4-52)
+ * and `impl From<&CsrMatrix<T>> for CscMatrix<T>` (src/csc/conv/csr.rs:4-52),
+ * i.e. the counting sort of CsrMatrix::transpose (src/csr.rs:358-406): a stable
+ * sort of the entries by their minor index.  Entries are only moved, so the
+ * result equals the reference's exactly.  The input handle is unchanged; the
+ * output is a new, independent handle. */
+int spal_csc_to_csr(spal_csc_t a, spal_csr_t *out);
+int spal_csr_to_csc(spal_csr_t a, spal_csc_t *out);
 
 /* ---- COO -> CSR assembly on the device -------------------------------------
  * Replaces `impl From<&CooMatrix<T>> for CsrMatrix<T>`

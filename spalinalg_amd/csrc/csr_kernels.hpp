@@ -443,6 +443,112 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
                                                        0u, last_nz);
 }
 
+// ---- persistent form of the stream kernel --------------------------------------
+// Same tiles, same arithmetic, same results as csr_spmv_stream; what changes is
+// who walks them.  A fixed grid (two workgroups per CU) is launched; workgroups
+// that share an XCD split that XCD's contiguous run of super-tiles into
+// contiguous chunks and loop over them.  The wave's load pipeline never drains
+// at a super-tile boundary: while the last tile of super-tile s is summed, the
+// first tile of s+1 is already in flight, and it stays in flight across the two
+// barriers that retire the old x window and publish the new one.  This removes
+// the per-workgroup cold start (boundary load -> tile loads -> window) and the
+// drain that the one-super-tile-per-workgroup form pays every 1024 rows.
+template <typename T, int L, int U, bool USE_DPP, int TPW>
+__global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
+    const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
+    const uint16_t *__restrict__ col16, const T *__restrict__ vals, const T *__restrict__ x,
+    T *__restrict__ y, const uint4 *__restrict__ desc, uint32_t nrows, uint32_t nnz,
+    uint32_t nblocks, uint32_t per_xcd, uint32_t chunk) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
+    T *prod_all = reinterpret_cast<T *>(spal_smem);
+    T *xw = prod_all + kStreamWaves * kStreamTileNnz;
+    constexpr uint32_t kRows = stream_rows(TPW);
+
+    // this workgroup's super-tiles: [s_begin, s_end) inside its XCD's run
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t run_end = min((xcd + 1) * per_xcd, nblocks);
+    const uint32_t s_begin = xcd * per_xcd + slot * chunk;
+    if (s_begin >= run_end) return;
+    const uint32_t s_end = min(s_begin + chunk, run_end);
+
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = threadIdx.x / kWave;
+    T *prod = prod_all + wave * kStreamTileNnz;
+    const uint32_t last_nz = nnz - 1;
+
+    // tile boundaries (entry offsets) of this wave's TPW tiles in super-tile s
+    auto bounds_lane = [&](uint32_t s) {
+        const uint32_t row0 = s * kRows, row1 = min(row0 + kRows, nrows);
+        const uint32_t wrow = row0 + wave * (TPW * kStreamTileRows);
+        return rowptr[min(wrow + min(lane, (uint32_t)TPW) * kStreamTileRows, row1)];
+    };
+
+    StreamTile<T> cur, nxt;
+    bool cur_valid = false;          // cur holds the first tile of super-tile s (prefetched)
+    uint32_t tbl = bounds_lane(s_begin);
+
+    for (uint32_t s = s_begin; s < s_end; ++s) {
+        const uint32_t row0 = s * kRows, row1 = min(row0 + kRows, nrows);
+        const uint4 d = desc[s];  // block-uniform
+        // the next super-tile's boundaries: asked for now, needed at this one's last tile
+        const bool next_stream = (s + 1 < s_end) && desc[s + 1].z == kModeStream;
+        const uint32_t tbl_next = (s + 1 < s_end) ? bounds_lane(s + 1) : 0u;
+
+        if (d.z == kModeStream) {
+            uint32_t tb[TPW + 1];
+#pragma unroll
+            for (int k = 0; k <= TPW; ++k) tb[k] = __builtin_amdgcn_readlane(tbl, k);
+            const uint32_t wrow = row0 + wave * (TPW * kStreamTileRows);
+            const bool has0 = wrow < row1;  // wave-uniform
+            if (has0 && !cur_valid) stream_load<T>(cur, rowptr, col16, vals, wrow, row1, tb[0], tb[1], lane);
+            __syncthreads();  // every wave is done with the previous window
+            stage_window<T, kStreamBlock>(xw, x, d.x, d.y);
+            __syncthreads();
+            const uint32_t wmax = d.y - 1;
+            bool fetched_next = false;
+            if (has0) {
+#pragma unroll
+                for (int k = 0; k < TPW; ++k) {
+                    const uint32_t r0 = wrow + k * kStreamTileRows;
+                    if (r0 >= row1) break;  // wave-uniform
+                    const uint32_t rn = r0 + kStreamTileRows;
+                    const bool more = (k + 1 < TPW) && rn < row1;
+                    if (more) {
+                        stream_load<T>(nxt, rowptr, col16, vals, rn, row1, tb[k + 1],
+                                       tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
+                    } else if (next_stream) {
+                        // last tile of this super-tile: start on the next one's first tile
+                        const uint32_t nrow0 = (s + 1) * kRows, nrow1 = min(nrow0 + kRows, nrows);
+                        const uint32_t nwrow = nrow0 + wave * (TPW * kStreamTileRows);
+                        if (nwrow < nrow1) {
+                            const uint32_t b0 = __builtin_amdgcn_readlane(tbl_next, 0);
+                            const uint32_t b1 = __builtin_amdgcn_readlane(tbl_next, 1);
+                            stream_load<T>(nxt, rowptr, col16, vals, nwrow, nrow1, b0, b1, lane);
+                            fetched_next = true;
+                        }
+                    }
+                    stream_compute<T>(cur, xw, wmax, prod, y, r0, row1, lane);
+                    if (more || fetched_next) cur = nxt;
+                }
+            }
+            cur_valid = fetched_next;
+        } else {
+            cur_valid = false;
+            __syncthreads();
+            if (d.z == kModeVectorLds) {
+                stage_window<T, kStreamBlock>(xw, x, d.x, d.y);
+                __syncthreads();
+                vector_rows<T, L, U, true, USE_DPP, kStreamBlock>(rowptr, colind, vals, x, xw, y, row0,
+                                                                  row1, d.x, last_nz);
+            } else {
+                vector_rows<T, L, U, false, USE_DPP, kStreamBlock>(rowptr, colind, vals, x, nullptr, y,
+                                                                   row0, row1, 0u, last_nz);
+            }
+        }
+        tbl = tbl_next;
+    }
+}
+
 // y[i] = 0 for an all-empty matrix slice (nnz == 0): nothing to stream.
 template <typename T>
 __global__ void fill_zero(T *y, uint64_t n) {

@@ -657,6 +657,87 @@ static int coo_assemble_t(spal_coo *c, hipStream_t st, spal_csr **out) {
     return SPAL_OK;
 }
 
+// --------------------------------------------------------------------------
+// compressed-by-major -> compressed-by-minor (CSR <-> CSC, transpose)
+// Device twin of the counting sort of src/csr.rs:358-406 /
+// src/csr/conv/csc.rs:4-52 / src/csc/conv/csr.rs:4-52: a stable sort of the
+// entries by their minor index keeps the major indices ascending inside every
+// minor slice, so the result is exactly the reference's (same order, same
+// values -- entries are only moved).
+// --------------------------------------------------------------------------
+// major index of every entry (one thread per major slice; slices are short)
+__global__ __launch_bounds__(256) void expand_major(const uint32_t *__restrict__ ptr, uint32_t nmajor,
+                                                    uint32_t *__restrict__ major) {
+    const uint64_t m = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= nmajor) return;
+    for (uint32_t p = ptr[m]; p < ptr[m + 1]; ++p) major[p] = (uint32_t)m;
+}
+
+template <typename T>
+static int transpose_t(int device, uint64_t nmajor, uint64_t nminor, uint64_t nnz,
+                       const uint32_t *d_ptr, const uint32_t *d_ind, const T *d_val, hipStream_t st,
+                       uint32_t **out_ptr, uint32_t **out_ind, T **out_val, uint64_t *out_cap) {
+    (void)device;
+    const uint64_t cap = nnz + 256;  // the stream kernel's over-read margin
+    DevBuf optr, oind, oval;
+    SPAL_HIP_TRY(optr.alloc((nminor + 1) * 4));
+    SPAL_HIP_TRY(oind.alloc(cap * 4));
+    SPAL_HIP_TRY(oval.alloc(cap * sizeof(T)));
+    SPAL_HIP_TRY(hipMemsetAsync((char *)oind.p + nnz * 4, 0, 256 * 4, st));
+    SPAL_HIP_TRY(hipMemsetAsync((char *)oval.p + nnz * sizeof(T), 0, 256 * sizeof(T), st));
+    if (nnz == 0) {
+        SPAL_HIP_TRY(hipMemsetAsync(optr.p, 0, (nminor + 1) * 4, st));
+    } else {
+        const CooWorkspace ws = coo_workspace_layout(nnz, nminor, sizeof(T));
+        DevBuf work, major;
+        SPAL_HIP_TRY(work.alloc(ws.bytes));
+        SPAL_HIP_TRY(major.alloc(nnz * 4));
+        char *wb = (char *)work.p;
+        SortBuffers<T> sb;
+        for (int i = 0; i < 2; ++i) {
+            sb.key[i] = (uint32_t *)(wb + ws.off_key[i]);
+            sb.aux[i] = (uint32_t *)(wb + ws.off_aux[i]);
+            sb.val[i] = (T *)(wb + ws.off_val[i]);
+        }
+        sb.counts = (uint32_t *)(wb + ws.off_counts);
+        sb.sums = (uint32_t *)(wb + ws.off_sums);
+        hipLaunchKernelGGL(expand_major, dim3((uint32_t)((nmajor + 255) / 256)), dim3(256), 0, st, d_ptr,
+                           (uint32_t)nmajor, major.as<uint32_t>());
+        int cur = 0;
+        SPAL_HIP_TRY(radix_sort_bits<T>(sb, nnz, 0, bits_for(nminor), cur, st, d_ind,
+                                        major.as<uint32_t>(), d_val));
+        hipLaunchKernelGGL(rows_lower_bound, dim3((uint32_t)((nminor + 1 + 255) / 256)), dim3(256), 0, st,
+                           sb.key[cur], (uint32_t)nnz, (uint32_t)nminor, optr.as<uint32_t>());
+        SPAL_HIP_TRY(hipMemcpyAsync(oind.p, sb.aux[cur], nnz * 4, hipMemcpyDeviceToDevice, st));
+        SPAL_HIP_TRY(hipMemcpyAsync(oval.p, sb.val[cur], nnz * sizeof(T), hipMemcpyDeviceToDevice, st));
+        SPAL_HIP_TRY(hipGetLastError());
+        SPAL_HIP_TRY(hipStreamSynchronize(st));  // `work` is freed on return
+    }
+    SPAL_HIP_TRY(hipStreamSynchronize(st));
+    *out_ptr = (uint32_t *)optr.release();
+    *out_ind = (uint32_t *)oind.release();
+    *out_val = (T *)oval.release();
+    *out_cap = cap;
+    return SPAL_OK;
+}
+
+int transpose_device(int device, int elem_size, uint64_t nmajor, uint64_t nminor, uint64_t nnz,
+                     const uint32_t *d_ptr, const uint32_t *d_ind, const void *d_val, hipStream_t st,
+                     uint32_t **out_ptr, uint32_t **out_ind, void **out_val, uint64_t *out_cap) {
+    if (elem_size == 8) {
+        double *v = nullptr;
+        SPAL_TRY(transpose_t<double>(device, nmajor, nminor, nnz, d_ptr, d_ind, (const double *)d_val, st,
+                                     out_ptr, out_ind, &v, out_cap));
+        *out_val = v;
+    } else {
+        float *v = nullptr;
+        SPAL_TRY(transpose_t<float>(device, nmajor, nminor, nnz, d_ptr, d_ind, (const float *)d_val, st,
+                                    out_ptr, out_ind, &v, out_cap));
+        *out_val = v;
+    }
+    return SPAL_OK;
+}
+
 static void coo_free(spal_coo *c) {
     if (!c) return;
     (void)hipFree(c->d_work);

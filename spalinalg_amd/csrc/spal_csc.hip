@@ -177,7 +177,13 @@ static hipError_t csc_launch_t(const spal_csc *a, const void *x, void *y, hipStr
     }
 }
 
+static int csc_ensure_csr(spal_csc *a);
+
 static int csc_launch(spal_csc *a, const void *x, void *y, hipStream_t st) {
+    if (a->kernel == 2) {  // the same matrix as CSR (built once), stream / vector CSR kernel
+        SPAL_TRY(csc_ensure_csr(a));
+        return csr_launch(a->as_csr, x, y, st);
+    }
     hipError_t e = a->elem_size == 8 ? csc_launch_t<double>(a, x, y, st)
                                      : csc_launch_t<float>(a, x, y, st);
     if (e != hipSuccess) return fail(SPAL_ERR_HIP, "csc spmv launch failed: %s", hipGetErrorString(e));
@@ -232,8 +238,52 @@ static int csc_plan_build(spal_csc *a) {
     return SPAL_OK;
 }
 
+// CSC -> CSR on the device (stable sort of the entries by row), kept on the handle.
+static int csc_ensure_csr(spal_csc *a) {
+    if (a->as_csr) return SPAL_OK;
+    uint32_t *rp = nullptr, *ci = nullptr;
+    void *va = nullptr;
+    uint64_t cap = 0;
+    SPAL_TRY(transpose_device(a->device, a->elem_size, a->ncols, a->nrows, a->nnz, a->d_colptr,
+                              a->d_rowind, a->d_values, a->stream, &rp, &ci, &va, &cap));
+    int st = csr_adopt_device(a->device, a->elem_size, a->nrows, a->ncols, a->nnz, cap, rp, ci, va,
+                              &a->as_csr);
+    if (st != SPAL_OK) { (void)hipFree(rp); (void)hipFree(ci); (void)hipFree(va); }
+    return st;
+}
+
+int csc_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, uint64_t nnz,
+                     uint32_t *d_colptr, uint32_t *d_rowind, void *d_values, spal_csc **out) {
+    spal_csc *a = new spal_csc;
+    a->device = device;
+    a->elem_size = elem_size;
+    a->nrows = nrows; a->ncols = ncols; a->nnz = nnz;
+    a->d_colptr = d_colptr; a->d_rowind = d_rowind; a->d_values = d_values;
+    a->lanes_per_col = 16;
+    {
+        int L = 2;
+        const double mean = ncols ? (double)nnz / (double)ncols : 0.0;
+        while (L < 64 && (double)L < mean) L <<= 1;
+        a->lanes_per_col = L;
+    }
+    auto bail = [&](int st) {
+        a->d_colptr = nullptr; a->d_rowind = nullptr; a->d_values = nullptr;  // stay with the caller
+        (void)hipFree(a->d_meta); (void)hipFree(a->d_desc);
+        if (a->stream) (void)hipStreamDestroy(a->stream);
+        delete a;
+        return st;
+    };
+    hipError_t e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return bail(fail(SPAL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)));
+    int st = csc_plan_build(a);
+    if (st != SPAL_OK) return bail(st);
+    *out = a;
+    return SPAL_OK;
+}
+
 static void csc_free(spal_csc *a) {
     if (!a) return;
+    if (a->as_csr) (void)spal_csr_destroy(a->as_csr);
     (void)hipFree(a->d_colptr);
     (void)hipFree(a->d_rowind);
     (void)hipFree(a->d_values);
@@ -273,7 +323,6 @@ static int csc_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t
     a->device = device;
     a->elem_size = (int)sizeof(T);
     a->nrows = nrows; a->ncols = ncols; a->nnz = nnz;
-    a->kernel = 1;
     a->lanes_per_col = pick_lanes_csc(ncols ? (double)nnz / (double)ncols : 0.0);
     const uint64_t cap = nnz + kStreamPad;  // whole-step reads of the LDS-mode stream
     hipError_t e = hipMalloc(&a->d_colptr, (ncols + 1) * sizeof(uint32_t));
@@ -333,6 +382,25 @@ static int csc_spmv_dev(spal_csc_t a, const T *x_dev, T *y_dev, void *stream) {
     return csc_launch(a, x_dev, y_dev, (hipStream_t)stream);
 }
 
+template <typename T>
+static int csc_download(spal_csc_t a, uint64_t *colptr, uint64_t *rowind, T *values) {
+    if (!a || !colptr) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csc_download: null argument");
+    if (a->elem_size != (int)sizeof(T))
+        return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csc_download: handle holds %s values",
+                    a->elem_size == 8 ? "f64" : "f32");
+    if (a->nnz && (!rowind || !values)) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csc_download: null array");
+    DeviceGuard guard(a->device);
+    if (guard.status != SPAL_OK) return guard.status;
+    std::vector<uint32_t> cp(a->ncols + 1), ri(a->nnz);
+    SPAL_HIP_TRY(hipMemcpy(cp.data(), a->d_colptr, cp.size() * 4, hipMemcpyDeviceToHost));
+    if (a->nnz) {
+        SPAL_HIP_TRY(hipMemcpy(ri.data(), a->d_rowind, ri.size() * 4, hipMemcpyDeviceToHost));
+        SPAL_HIP_TRY(hipMemcpy(values, a->d_values, a->nnz * sizeof(T), hipMemcpyDeviceToHost));
+    }
+    for (uint64_t i = 0; i <= a->ncols; ++i) colptr[i] = cp[i];
+    for (uint64_t i = 0; i < a->nnz; ++i) rowind[i] = ri[i];
+    return SPAL_OK;
+}
 }  // namespace spal
 
 using namespace spal;
@@ -377,6 +445,45 @@ int spal_csc_spmv_dev_f64(spal_csc_t a, const double *x_dev, double *y_dev, void
 int spal_csc_spmv_dev_f32(spal_csc_t a, const float *x_dev, float *y_dev, void *stream) {
     return csc_spmv_dev<float>(a, x_dev, y_dev, stream);
 }
+int spal_csc_to_csr(spal_csc_t a, spal_csr_t *out) {
+    if (!a || !out) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csc_to_csr: null argument");
+    *out = nullptr;
+    DeviceGuard guard(a->device);
+    if (guard.status != SPAL_OK) return guard.status;
+    std::lock_guard<std::mutex> lock(a->mu);
+    uint32_t *rp = nullptr, *ci = nullptr;
+    void *va = nullptr;
+    uint64_t cap = 0;
+    SPAL_TRY(transpose_device(a->device, a->elem_size, a->ncols, a->nrows, a->nnz, a->d_colptr,
+                              a->d_rowind, a->d_values, a->stream, &rp, &ci, &va, &cap));
+    int st = csr_adopt_device(a->device, a->elem_size, a->nrows, a->ncols, a->nnz, cap, rp, ci, va, out);
+    if (st != SPAL_OK) { (void)hipFree(rp); (void)hipFree(ci); (void)hipFree(va); }
+    return st;
+}
+
+int spal_csr_to_csc(spal_csr_t a, spal_csc_t *out) {
+    if (!a || !out) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_to_csc: null argument");
+    *out = nullptr;
+    DeviceGuard guard(a->device);
+    if (guard.status != SPAL_OK) return guard.status;
+    std::lock_guard<std::mutex> lock(a->mu);
+    uint32_t *cp = nullptr, *ri = nullptr;
+    void *va = nullptr;
+    uint64_t cap = 0;
+    SPAL_TRY(transpose_device(a->device, a->elem_size, a->nrows, a->ncols, a->nnz, a->d_rowptr,
+                              a->d_colind, a->d_values, a->stream, &cp, &ri, &va, &cap));
+    int st = csc_adopt_device(a->device, a->elem_size, a->nrows, a->ncols, a->nnz, cp, ri, va, out);
+    if (st != SPAL_OK) { (void)hipFree(cp); (void)hipFree(ri); (void)hipFree(va); }
+    return st;
+}
+
+int spal_csc_download_f64(spal_csc_t a, uint64_t *colptr, uint64_t *rowind, double *values) {
+    return csc_download<double>(a, colptr, rowind, values);
+}
+int spal_csc_download_f32(spal_csc_t a, uint64_t *colptr, uint64_t *rowind, float *values) {
+    return csc_download<float>(a, colptr, rowind, values);
+}
+
 int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value) {
     if (!a || !key) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csc_set_option: null argument");
     DeviceGuard guard(a->device);
@@ -390,6 +497,14 @@ int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value) {
         if (value < 2 || value > 64 || (value & (value - 1)))
             return fail(SPAL_ERR_INVALID_ARGUMENT, "lanes_per_col must be one of 2,4,8,16,32,64");
         a->lanes_per_col = (int)value;
+        return SPAL_OK;
+    }
+    if (!strcmp(key, "kernel")) {
+        // 1 = atomic scatter (the path BASELINE config 4 names), 2 = transposed
+        // (device CSC->CSR once, then the CSR kernels), 0 = auto = 2
+        if (value < 0 || value > 2) return fail(SPAL_ERR_INVALID_ARGUMENT, "kernel must be 0, 1 or 2");
+        a->kernel = value == 1 ? 1 : 2;
+        if (a->kernel == 2) return csc_ensure_csr(a);
         return SPAL_OK;
     }
     if (!strcmp(key, "lds")) {
@@ -407,7 +522,8 @@ int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len) {
              "\"lds_window_bytes\": %llu, \"lds_col_fraction\": %.4f}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz,
-             a->lds_entries ? "lds_privatised_scatter" : "atomic_scatter", kCscCols, a->nblocks,
+             a->kernel == 2 ? "transposed_csr" : a->lds_entries ? "lds_privatised_scatter" : "atomic_scatter",
+             kCscCols, a->nblocks,
              a->lanes_per_col, (unsigned long long)a->lds_entries * (unsigned long long)a->elem_size,
              a->lds_col_fraction);
     return SPAL_OK;

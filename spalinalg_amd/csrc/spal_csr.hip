@@ -164,8 +164,28 @@ static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, h
     return hipGetLastError();
 }
 
+// persistent form: 2 workgroups per CU, contiguous chunks of each XCD's run
+template <typename T, int L>
+static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    const CsrPlan &p = a->plan;
+    const uint32_t per_xcd = (p.nblocks + 7) / 8;
+    const uint32_t slots = (uint32_t)std::max(1, p.persistent_blocks / 8);   // workgroups per XCD
+    const uint32_t chunk = (per_xcd + slots - 1) / slots;
+    const uint32_t used = (per_xcd + chunk - 1) / chunk;                      // non-empty slots
+    const size_t lds = ((size_t)kStreamWaves * kStreamTileNnz + p.lds_entries) * sizeof(T);
+    auto kern = csr_spmv_stream_persistent<T, L, 2, true, 4>;
+    static std::atomic<uint64_t> configured{0};
+    hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(used * 8), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
+                       a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc,
+                       (uint32_t)a->nrows, (uint32_t)a->nnz, p.nblocks, per_xcd, chunk);
+    return hipGetLastError();
+}
+
 template <typename T, int L>
 static hipError_t launch_stream(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    if (a->plan.persistent && a->plan.tiles_per_wave == 4) return launch_stream_persistent<T, L>(a, x, y, st);
     return a->plan.tiles_per_wave == 8 ? launch_stream_tpw<T, L, 8>(a, x, y, st)
                                        : launch_stream_tpw<T, L, 4>(a, x, y, st);
 }
@@ -654,6 +674,13 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         else if (value != 1 && value != 2 && value != 4)
             return fail(SPAL_ERR_INVALID_ARGUMENT, "unroll must be 1, 2 or 4");
         else { p.unroll = (int)value; p.user_unroll = true; }
+    } else if (!strcmp(key, "persistent")) {
+        if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "persistent must be 0 or 1");
+        p.persistent = (int)value;
+    } else if (!strcmp(key, "persistent_blocks")) {
+        if (value < 8 || value > 4096 || (value % 8))
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "persistent_blocks must be a multiple of 8 in [8, 4096]");
+        p.persistent_blocks = (int)value;
     } else if (!strcmp(key, "tiles_per_wave")) {
         if (value != 4 && value != 8) return fail(SPAL_ERR_INVALID_ARGUMENT, "tiles_per_wave must be 4 or 8");
         p.tiles_per_wave = (int)value;
@@ -677,13 +704,14 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "{\"format\": \"csr\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"nnz\": %llu, "
              "\"index_bits\": %d, \"kernel\": \"%s\", \"lanes_per_row\": %d, \"unroll\": %d, "
              "\"rows_per_block\": %d, \"blocks\": %u, \"threads_per_block\": %d, \"lds_x\": %d, "
-             "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f}",
+             "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f, "
+             "\"persistent\": %d}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, p.kernel == 2 ? 16 : 32,
              p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
              p.rows_per_block, p.nblocks, p.threads, p.lds_x,
              (unsigned long long)p.lds_entries * (unsigned long long)a->elem_size, p.lds_row_fraction,
-             p.stream_row_fraction);
+             p.stream_row_fraction, (p.kernel == 2 && p.persistent && p.tiles_per_wave == 4) ? 1 : 0);
     return SPAL_OK;
 }
 

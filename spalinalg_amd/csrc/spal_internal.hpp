@@ -73,6 +73,8 @@ struct CsrPlan {
     int unroll = 1;          // row groups in flight per wave iteration
     int threads = 512;       // workgroup size: 512 or 1024
     int tiles_per_wave = 4;  // stream kernel: 64-row tiles per wave (4 or 8)
+    int persistent = 0;      // stream kernel: fixed grid walking chunks of super-tiles
+    int persistent_blocks = 512;  // its grid (2 workgroups per CU on 256 CUs)
     int rows_per_block = 0;  // R
     int lds_x = 0;           // stage the block's x window in LDS
     uint32_t lds_entries = 0;  // LDS window capacity (elements) when lds_x
@@ -83,6 +85,16 @@ struct CsrPlan {
          user_unroll = false, user_threads = false;
 };
 
+// implemented in spal_coo.hip: stable sort of the entries by their minor index
+// (compressed-by-major -> compressed-by-minor); outputs are hipMalloc'ed with
+// *out_cap entries (nnz + over-read margin) and owned by the caller
+int transpose_device(int device, int elem_size, uint64_t nmajor, uint64_t nminor, uint64_t nnz,
+                     const uint32_t *d_ptr, const uint32_t *d_ind, const void *d_val,
+                     hipStream_t st, uint32_t **out_ptr, uint32_t **out_ind, void **out_val,
+                     uint64_t *out_cap);
+// implemented in spal_csc.hip: handle around device arrays it takes ownership of
+int csc_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, uint64_t nnz,
+                     uint32_t *d_colptr, uint32_t *d_rowind, void *d_values, spal_csc **out);
 }  // namespace spal
 
 // The opaque handle types of spal.h.
@@ -116,7 +128,8 @@ struct spal_csc {
     uint32_t lds_entries = 0;      // largest LDS y window (elements); 0 = global scatter only
     double lds_col_fraction = 0.0;
     int use_lds = 1;
-    int kernel = 0;
+    int kernel = 2;                // 1 = atomic scatter (LDS-privatised / global), 2 = transposed (CSR kernels; default)
+    spal_csr *as_csr = nullptr;    // kernel 2: the same matrix as CSR, built on the device on first use
     int lanes_per_col = 0;
     std::mutex mu;
     void *d_x = nullptr, *d_y = nullptr;

@@ -142,9 +142,29 @@ class DeviceCsr(_DeviceMatrix):
         check(self._fn(f"download_{_sfx(self.dtype)}")(self._h, _p(rp), _p(ci), _p(va)))
         return rp, ci, va
 
+    def to_csc(self) -> "DeviceCsc":
+        """device CSR -> CSC (stable sort by column; src/csc/conv/csr.rs:4-52)"""
+        out = vp()
+        check(_ffi.lib().spal_csr_to_csc(self._h, C.byref(out)))
+        return DeviceCsc(out, self.dtype, self.device)
+
 
 class DeviceCsc(_DeviceMatrix):
     _kind = "csc"
+
+    def download(self):
+        _, ncols, nnz = self.shape()
+        cp = np.empty(ncols + 1, dtype=np.uint64)
+        ri = np.empty(nnz, dtype=np.uint64)
+        va = np.empty(nnz, dtype=self.dtype)
+        check(self._fn(f"download_{_sfx(self.dtype)}")(self._h, _p(cp), _p(ri), _p(va)))
+        return cp, ri, va
+
+    def to_csr(self) -> DeviceCsr:
+        """device CSC -> CSR (stable sort by row; src/csr/conv/csc.rs:4-52)"""
+        out = vp()
+        check(_ffi.lib().spal_csc_to_csr(self._h, C.byref(out)))
+        return DeviceCsr(out, self.dtype, self.device)
 
 
 class DeviceCoo:
@@ -292,8 +312,17 @@ class CsrMatrix(_Compressed):
         return out
 
     @classmethod
-    def from_(cls, coo, device: int = 0):
-        return cls.from_coo(coo, device)
+    def from_csc(cls, csc: "CscMatrix", device: int = 0) -> "CsrMatrix":
+        """`CsrMatrix::from(&csc)` (src/csr/conv/csc.rs:4-52) on the device."""
+        dev = csc.device(device).to_csr()
+        rp, ci, va = dev.download()
+        out = cls._trusted(csc.nrows(), csc.ncols(), rp, ci, va)
+        out._dev[device] = dev
+        return out
+
+    @classmethod
+    def from_(cls, other, device: int = 0):
+        return cls.from_csc(other, device) if isinstance(other, CscMatrix) else cls.from_coo(other, device)
 
 
 class CscMatrix(_Compressed):
@@ -310,6 +339,19 @@ class CscMatrix(_Compressed):
 
     def rowind(self) -> np.ndarray:
         return self._ind
+
+    @classmethod
+    def from_csr(cls, csr: "CsrMatrix", device: int = 0) -> "CscMatrix":
+        """`CscMatrix::from(&csr)` (src/csc/conv/csr.rs:4-52) on the device."""
+        dev = csr.device(device).to_csc()
+        cp, ri, va = dev.download()
+        out = cls._trusted(csr.nrows(), csr.ncols(), cp, ri, va)
+        out._dev[device] = dev
+        return out
+
+    @classmethod
+    def from_(cls, csr, device: int = 0):
+        return cls.from_csr(csr, device)
 
 
 # --------------------------------------------------------------------------

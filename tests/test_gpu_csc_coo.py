@@ -8,6 +8,68 @@ from tests.util import assert_spmv_close, random_csr
 pytestmark = pytest.mark.gpu
 
 
+# ---- CSR <-> CSC on the device ---------------------------------
+def test_conversion_kats_g3_g4_g6(kats):
+    g = kats["G3_csc_to_csr"]
+    csc = sp.CscMatrix(g["nrows"], g["ncols"], g["colptr"], g["rowind"], np.array(g["csc_values"]))
+    csr = sp.CsrMatrix.from_csc(csc)
+    assert (csr.rowptr().tolist(), csr.colind().tolist(), csr.values().tolist()) == (
+        g["rowptr"], g["colind"], g["csr_values"])
+    g = kats["G4_csr_to_csc"]
+    csr = sp.CsrMatrix(g["nrows"], g["ncols"], g["rowptr"], g["colind"], np.array(g["csr_values"]))
+    csc = sp.CscMatrix.from_csr(csr)
+    assert (csc.colptr().tolist(), csc.rowind().tolist(), csc.values().tolist()) == (
+        g["colptr"], g["rowind"], g["csc_values"])
+    # transpose doc-tests: the CSC arrays of M are the CSR arrays of M^T
+    g = kats["G6_transpose"]["csr"]
+    m = sp.CsrMatrix(g["n"], g["n"], g["rowptr"], g["colind"], np.array(g["values"]))
+    t = sp.CscMatrix.from_csr(m)
+    assert (t.colptr().tolist(), t.rowind().tolist(), t.values().tolist()) == (
+        g["t_rowptr"], g["t_colind"], g["t_values"])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_conversions_random_exact(oracle, dtype):
+    """entries are only moved: indices AND values equal the oracle's bit for bit"""
+    rng = np.random.default_rng(31)
+    for nr, nc in [(1, 1), (1, 300), (300, 1), (257, 300), (40_000, 30_000), (3000, 200_000)]:
+        rp, ci, va = random_csr(rng, nr, nc, density=min(0.3, 6.0 / nc), dtype=dtype)
+        cp, ri, cv = oracle.transpose(nr, nc, rp, ci, va)
+        csr = sp.CsrMatrix(nr, nc, rp, ci, va)
+        csc = sp.CscMatrix.from_csr(csr)
+        assert np.array_equal(csc.colptr(), cp) and np.array_equal(csc.rowind(), ri)
+        assert np.array_equal(csc.values(), cv)
+        back = sp.CsrMatrix.from_csc(csc)
+        assert np.array_equal(back.rowptr(), rp) and np.array_equal(back.colind(), ci)
+        assert np.array_equal(back.values(), va)
+        # the converted matrices are valid in the reference's sense
+        sp.CscMatrix(nr, nc, csc.colptr(), csc.rowind(), csc.values())
+    # one row holding 100k entries (longer than any LDS tile)
+    nr, nc = 3, 200_000
+    rp = np.array([0, 0, 100_000, 100_000], dtype=np.uint64)
+    ci = np.sort(rng.choice(nc, 100_000, replace=False)).astype(np.uint64)
+    va = rng.uniform(-1, 1, 100_000).astype(dtype)
+    cp, ri, cv = oracle.transpose(nr, nc, rp, ci, va)
+    csc = sp.CscMatrix.from_csr(sp.CsrMatrix(nr, nc, rp, ci, va))
+    assert np.array_equal(csc.colptr(), cp) and np.array_equal(csc.rowind(), ri) and np.array_equal(csc.values(), cv)
+
+
+def test_csc_transposed_kernel_is_bit_identical(oracle):
+    """kernel 2 (the default): CSC -> CSR once on the device, then the stream
+    kernel: y equals the reference's k-ascending sums bit for bit."""
+    n = 200_000
+    rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, 3)
+    cp, ri, cv = oracle.transpose(n, n, rp, ci, va)
+    x = sp.synth.vector(n)
+    dev = sp.CscMatrix(n, n, cp, ri, cv).device()
+    assert dev.describe()["kernel"] == "transposed_csr"
+    y = dev.spmv(x)
+    assert np.array_equal(y, oracle.csc_spmv(n, cp, ri, cv, x))
+    dev.set_option("kernel", 1)
+    assert dev.describe()["kernel"] == "lds_privatised_scatter"
+    np.testing.assert_allclose(dev.spmv(x), y, rtol=1e-10, atol=1e-13)
+
+
 # ---- CSC ---------------------------------------------------------------------
 def test_csc_kat_g5(kats):
     g = kats["G5_csc_mul"]
@@ -25,10 +87,11 @@ def test_csc_random(oracle, dtype):
         cp, ri, cv = oracle.transpose(nr, nc, rp, ci, va)
         x = rng.uniform(-1, 1, nc).astype(dtype)
         m = sp.CscMatrix(nr, nc, cp, ri, cv)
-        y = m * x
         y_ref = oracle.csc_spmv(nr, cp, ri, cv, x)
         bound = oracle.csr_abs_bound(rp, ci, va.astype(np.float64), x.astype(np.float64))
-        assert_spmv_close(y, y_ref, bound, 1e-10 if dtype == np.float64 else 1e-4)
+        for kernel in (2, 1):
+            m.device().set_option("kernel", kernel)
+            assert_spmv_close(m * x, y_ref, bound, 1e-10 if dtype == np.float64 else 1e-4)
 
 
 def test_csc_lds_and_global_paths(oracle):
@@ -53,6 +116,8 @@ def test_csc_lds_and_global_paths(oracle):
     y_ref = oracle.csc_spmv(n, cp, ri, cv, x)
     bound = oracle.csr_abs_bound(rp2, ci2, va2, np.nan_to_num(x, posinf=0.0))
     dev = m.device()
+    assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10)        # default: transposed
+    dev.set_option("kernel", 1)
     d = dev.describe()
     assert d["kernel"] == "lds_privatised_scatter" and 0.8 < d["lds_col_fraction"] < 1.0
     assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10)
@@ -72,11 +137,14 @@ def test_csc_config4(oracle):
     cp, ri, cv = oracle.transpose(n, n, rp, ci, va)
     x = sp.synth.vector(n)
     m = sp.CscMatrix(n, n, cp, ri, cv)
+    m.device().set_option("kernel", 1)          # the atomic scatter path config 4 names
     y = m * x
     y_ref = oracle.csc_spmv(n, cp, ri, cv, x)
     assert_spmv_close(y, y_ref, oracle.csr_abs_bound(rp, ci, va, x), 1e-10)
     assert m.device().describe()["lds_col_fraction"] > 0.99
-    y32 = sp.CscMatrix(n, n, cp, ri, cv.astype(np.float32)) * x.astype(np.float32)
+    m32 = sp.CscMatrix(n, n, cp, ri, cv.astype(np.float32))
+    m32.device().set_option("kernel", 1)
+    y32 = m32 * x.astype(np.float32)
     assert_spmv_close(y32, y_ref, oracle.csr_abs_bound(rp, ci, va, x), 1e-4)
     with pytest.raises(sp.Panic):
         m * np.ones(n - 1)

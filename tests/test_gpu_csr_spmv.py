@@ -75,6 +75,11 @@ def test_stream_kernel_is_bit_identical_to_the_reference_order(oracle):
         assert d["kernel"] == "stream" and d["stream_row_fraction"] == 1.0 and d["index_bits"] == 16
         y = dev.spmv(x)
         assert np.array_equal(y, oracle.csr_spmv(rp, ci, va, x))
+        for persistent, blocks in ((1, 512), (1, 8), (1, 1024), (0, 512)):
+            dev.set_option("persistent", persistent)
+            dev.set_option("persistent_blocks", blocks)
+            assert dev.describe()["persistent"] == persistent
+            assert np.array_equal(dev.spmv(x), y)
         # ragged rows (0..24 entries), odd tile starts, a short last super-tile
         nr, nc = 70_001, 3000
         rp, ci, va = random_csr(rng, nr, nc, row_len=lambda r: r.integers(0, 25), dtype=dtype)
@@ -87,6 +92,10 @@ def test_stream_kernel_is_bit_identical_to_the_reference_order(oracle):
         y_ref = oracle.csr_spmv(rp, ci, va, x)
         assert np.array_equal(y, y_ref)
         assert np.array_equal(np.signbit(y), np.signbit(y_ref))     # -0.0 from a lone -v * 0.0 included
+        dev.set_option("persistent", 1)
+        for blocks in (512, 16, 40):
+            dev.set_option("persistent_blocks", blocks)
+            assert np.array_equal(dev.spmv(x), y_ref)
 
 
 def test_stream_kernel_mixed_supertiles(oracle):
@@ -107,6 +116,8 @@ def test_stream_kernel_mixed_supertiles(oracle):
     dev = check(oracle, rp, ci, va, x, n, kernel=2)
     d = dev.describe()
     assert d["kernel"] == "stream" and 0.5 < d["stream_row_fraction"] < 1.0
+    check(oracle, rp, ci, va, x, n, kernel=2, persistent=1)
+    check(oracle, rp, ci, va, x, n, kernel=2, persistent=1, persistent_blocks=8)
     check(oracle, rp, ci, va, x, n, kernel=1)
 
 
@@ -129,6 +140,7 @@ def test_every_lane_width_and_unroll(oracle, lanes, unroll):
             check(oracle, rp, ci, va, x, nc, kernel=1, lanes_per_row=lanes, unroll=unroll, threads=threads, lds_x=lds)
     if unroll == 1:
         check(oracle, rp, ci, va, x, nc, kernel=2, lanes_per_row=lanes)
+        check(oracle, rp, ci, va, x, nc, kernel=2, lanes_per_row=lanes, persistent=1)
 
 
 @pytest.mark.parametrize("rows_per_block", [64, 512, 2048, 4096, 16384])
