@@ -184,6 +184,9 @@ int spal_coo_destroy(spal_coo_t c);
  * new CSR handle.  Synchronises the stream once (the output size is data
  * dependent). */
 int spal_coo_assemble_csr(spal_coo_t c, void *stream, spal_csr_t *out);
+/* Same assembly compressed by columns: replaces
+ * `impl From<&CooMatrix<T>> for CscMatrix<T>` (src/csc/conv/coo.rs:4-115). */
+int spal_coo_assemble_csc(spal_coo_t c, void *stream, spal_csc_t *out);
 /* One-call convenience: upload + assemble + free the COO copy. */
 int spal_coo_to_csr_f64(int device, uint64_t nrows, uint64_t ncols, uint64_t len,
                         const uint64_t *rows, const uint64_t *cols,
@@ -191,6 +194,13 @@ int spal_coo_to_csr_f64(int device, uint64_t nrows, uint64_t ncols, uint64_t len
 int spal_coo_to_csr_f32(int device, uint64_t nrows, uint64_t ncols, uint64_t len,
                         const uint64_t *rows, const uint64_t *cols,
                         const float *vals, spal_csr_t *out);
+
+int spal_coo_to_csc_f64(int device, uint64_t nrows, uint64_t ncols, uint64_t len,
+                        const uint64_t *rows, const uint64_t *cols,
+                        const double *vals, spal_csc_t *out);
+int spal_coo_to_csc_f32(int device, uint64_t nrows, uint64_t ncols, uint64_t len,
+                        const uint64_t *rows, const uint64_t *cols,
+                        const float *vals, spal_csc_t *out);
 
 /* ---- device memory helpers for callers without a HIP binding of their own
  * (the Rust shim, ctypes tests, the C++ tools). ---------------------------- */

@@ -63,6 +63,8 @@ template <> struct Abi<double> {
     static constexpr auto csc_create = spal_csc_create_f64;
     static constexpr auto csc_spmv = spal_csc_spmv_f64;
     static constexpr auto coo_to_csr = spal_coo_to_csr_f64;
+    static constexpr auto coo_to_csc = spal_coo_to_csc_f64;
+    static constexpr auto csc_download = spal_csc_download_f64;
 };
 template <> struct Abi<float> {
     static constexpr auto csr_create = spal_csr_create_f32;
@@ -71,12 +73,15 @@ template <> struct Abi<float> {
     static constexpr auto csc_create = spal_csc_create_f32;
     static constexpr auto csc_spmv = spal_csc_spmv_f32;
     static constexpr auto coo_to_csr = spal_coo_to_csr_f32;
+    static constexpr auto coo_to_csc = spal_coo_to_csc_f32;
+    static constexpr auto csc_download = spal_csc_download_f32;
 };
 struct CsrDeleter { void operator()(spal_csr *h) const { spal_csr_destroy(h); } };
 struct CscDeleter { void operator()(spal_csc *h) const { spal_csc_destroy(h); } };
 }  // namespace detail
 
 template <typename T> class CooMatrix;
+template <typename T> class CscMatrix;
 
 // ---------------------------------------------------------------------------
 // CsrMatrix<T>                                     reference src/csr.rs:66-72
@@ -127,13 +132,29 @@ class CsrMatrix {
 
     // CsrMatrix::from(&coo): assembled on the device, bit-identical to the reference.
     static CsrMatrix from(const CooMatrix<T> &coo, int device = 0);
+    // CsrMatrix::from(&csc)  (src/csr/conv/csc.rs:4-52): device stable sort by row.
+    static CsrMatrix from(const CscMatrix<T> &csc, int device = 0);
 
   private:
+    friend class CscMatrix<T>;
     struct Trusted {};
     CsrMatrix(Trusted, usize nrows, usize ncols, std::vector<usize> rp, std::vector<usize> ci,
               std::vector<T> va)
         : nrows_(nrows), ncols_(ncols), rowptr_(std::move(rp)), colind_(std::move(ci)),
           values_(std::move(va)) {}
+    static CsrMatrix adopt(spal_csr_t h) {   // downloads h into a host matrix that also owns h
+        std::unique_ptr<spal_csr, detail::CsrDeleter> guard(h);
+        uint64_t nr = 0, nc = 0, nz = 0;
+        int es = 0;
+        detail::check(spal_csr_shape(h, &nr, &nc, &nz, &es));
+        std::vector<usize> rp(nr + 1), ci(nz);
+        std::vector<T> va(nz);
+        detail::check(detail::Abi<T>::csr_download(h, rp.data(), ci.data(), va.data()));
+        // struct-literal construction like the reference (src/csr/conv/coo.rs:108-114)
+        CsrMatrix out(Trusted{}, nr, nc, std::move(rp), std::move(ci), std::move(va));
+        out.dev_ = std::move(guard);
+        return out;
+    }
     usize nrows_, ncols_;
     std::vector<usize> rowptr_, colind_;
     std::vector<T> values_;
@@ -171,7 +192,7 @@ class CscMatrix {
         }
         return dev_.get();
     }
-    // y = A * x by atomic scatter; panics when x.len() != ncols (src/csc/ops/mul.rs:9).
+    // y = A * x; panics when x.len() != ncols (src/csc/ops/mul.rs:9).
     std::vector<T> operator*(const std::vector<T> &x) const {
         if (x.size() != ncols_)
             throw Panic(SPAL_ERR_INVALID_ARGUMENT, "assertion failed: `(left == right)` ncols vs x.len()");
@@ -179,8 +200,34 @@ class CscMatrix {
         detail::check(detail::Abi<T>::csc_spmv(device_handle(), x.data(), x.size(), y.data(), y.size()));
         return y;
     }
+    // CscMatrix::from(&csr)  (src/csc/conv/csr.rs:4-52) and CscMatrix::from(&coo)
+    // (src/csc/conv/coo.rs:3-116), both on the device.
+    static CscMatrix from(const CsrMatrix<T> &csr, int device = 0) {
+        spal_csc_t h = nullptr;
+        detail::check(spal_csr_to_csc(csr.device_handle(device), &h));
+        return adopt(h);
+    }
+    static CscMatrix from(const CooMatrix<T> &coo, int device = 0);
 
   private:
+    friend class CsrMatrix<T>;
+    struct Trusted {};
+    CscMatrix(Trusted, usize nrows, usize ncols, std::vector<usize> cp, std::vector<usize> ri,
+              std::vector<T> va)
+        : nrows_(nrows), ncols_(ncols), colptr_(std::move(cp)), rowind_(std::move(ri)),
+          values_(std::move(va)) {}
+    static CscMatrix adopt(spal_csc_t h) {
+        std::unique_ptr<spal_csc, detail::CscDeleter> guard(h);
+        uint64_t nr = 0, nc = 0, nz = 0;
+        int es = 0;
+        detail::check(spal_csc_shape(h, &nr, &nc, &nz, &es));
+        std::vector<usize> cp(nc + 1), ri(nz);
+        std::vector<T> va(nz);
+        detail::check(detail::Abi<T>::csc_download(h, cp.data(), ri.data(), va.data()));
+        CscMatrix out(Trusted{}, nr, nc, std::move(cp), std::move(ri), std::move(va));
+        out.dev_ = std::move(guard);
+        return out;
+    }
     usize nrows_, ncols_;
     std::vector<usize> colptr_, rowind_;
     std::vector<T> values_;
@@ -246,17 +293,22 @@ CsrMatrix<T> CsrMatrix<T>::from(const CooMatrix<T> &coo, int device) {
     spal_csr_t h = nullptr;
     detail::check(detail::Abi<T>::coo_to_csr(device, coo.nrows(), coo.ncols(), coo.length(),
                                              coo.rows().data(), coo.cols().data(), coo.vals().data(), &h));
-    std::unique_ptr<spal_csr, detail::CsrDeleter> guard(h);
-    uint64_t nr = 0, nc = 0, nz = 0;
-    int es = 0;
-    detail::check(spal_csr_shape(h, &nr, &nc, &nz, &es));
-    std::vector<usize> rp(nr + 1), ci(nz);
-    std::vector<T> va(nz);
-    detail::check(detail::Abi<T>::csr_download(h, rp.data(), ci.data(), va.data()));
-    // struct-literal construction like the reference (src/csr/conv/coo.rs:108-114)
-    CsrMatrix out(Trusted{}, nr, nc, std::move(rp), std::move(ci), std::move(va));
-    out.dev_ = std::move(guard);
-    return out;
+    return adopt(h);
+}
+
+template <typename T>
+CsrMatrix<T> CsrMatrix<T>::from(const CscMatrix<T> &csc, int device) {
+    spal_csr_t h = nullptr;
+    detail::check(spal_csc_to_csr(csc.device_handle(device), &h));
+    return adopt(h);
+}
+
+template <typename T>
+CscMatrix<T> CscMatrix<T>::from(const CooMatrix<T> &coo, int device) {
+    spal_csc_t h = nullptr;
+    detail::check(detail::Abi<T>::coo_to_csc(device, coo.nrows(), coo.ncols(), coo.length(),
+                                             coo.rows().data(), coo.cols().data(), coo.vals().data(), &h));
+    return adopt(h);
 }
 
 }  // namespace spalinalg

@@ -530,11 +530,24 @@ static CooWorkspace coo_workspace_layout(uint64_t len, uint64_t nrows, size_t el
     return w;
 }
 
+// The assembly on (major, minor): for CSR major = rows, for CSC major = columns
+// (`From<&CooMatrix> for CscMatrix`, src/csc/conv/coo.rs:4-115, is the same code
+// with the two exchanged).  Produces the compressed arrays; the caller wraps
+// them in a handle.
+struct Assembled {
+    uint32_t *ptr = nullptr, *ind = nullptr;
+    void *val = nullptr;
+    uint64_t nnz = 0, cap = 0;
+};
+
 template <typename T>
-static int coo_assemble_t(spal_coo *c, hipStream_t st, spal_csr **out) {
+static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &res) {
     const uint64_t len = c->len;
-    const uint32_t nrows = (uint32_t)c->nrows;
-    const uint32_t cbits = bits_for(c->ncols), rbits = bits_for(c->nrows);
+    const uint64_t n_major = by_cols ? c->ncols : c->nrows, n_minor = by_cols ? c->nrows : c->ncols;
+    const uint32_t *d_major = by_cols ? c->d_cols : c->d_rows;
+    const uint32_t *d_minor = by_cols ? c->d_rows : c->d_cols;
+    const uint32_t nrows = (uint32_t)n_major;  // "rows" below = the major index
+    const uint32_t cbits = bits_for(n_minor), rbits = bits_for(n_major);
     DevBuf rowptr;
     SPAL_HIP_TRY(rowptr.alloc(((size_t)nrows + 1) * 4));
     if (len == 0) {  // no entries at all: an empty CSR matrix
@@ -543,11 +556,8 @@ static int coo_assemble_t(spal_coo *c, hipStream_t st, spal_csr **out) {
         SPAL_HIP_TRY(oval.alloc(sizeof(T)));
         SPAL_HIP_TRY(hipMemsetAsync(rowptr.p, 0, ((size_t)nrows + 1) * 4, st));
         SPAL_HIP_TRY(hipStreamSynchronize(st));
-        spal_csr *a = nullptr;
-        SPAL_TRY(csr_adopt_device(c->device, (int)sizeof(T), c->nrows, c->ncols, 0, 0,
-                                  rowptr.as<uint32_t>(), ocol.as<uint32_t>(), oval.p, &a));
-        rowptr.release(); ocol.release(); oval.release();
-        *out = a;
+        res.ptr = (uint32_t *)rowptr.release(); res.ind = (uint32_t *)ocol.release();
+        res.val = oval.release(); res.nnz = 0; res.cap = 0;
         return SPAL_OK;
     }
 
@@ -573,7 +583,7 @@ static int coo_assemble_t(spal_coo *c, hipStream_t st, spal_csr **out) {
     // ---- 1. stable sort by row, (col, value) carried along; the first pass
     // reads the uploaded triplets directly (they stay untouched)
     int cur = 0;
-    SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, 0, rbits, cur, st, c->d_rows, c->d_cols,
+    SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, 0, rbits, cur, st, d_major, d_minor,
                                     (const T *)c->d_vals));
     // ---- 2. row offsets, tile check
     const uint32_t g_rows = (uint32_t)(((uint64_t)nrows + 1 + 255) / 256);
@@ -608,18 +618,15 @@ static int coo_assemble_t(spal_coo *c, hipStream_t st, spal_csr **out) {
                            ocol.as<uint32_t>(), oval.as<T>());
         SPAL_HIP_TRY(hipGetLastError());
         SPAL_HIP_TRY(hipStreamSynchronize(st));
-        spal_csr *a = nullptr;
-        SPAL_TRY(csr_adopt_device(c->device, (int)sizeof(T), c->nrows, c->ncols, nnz, cap,
-                                  rowptr.as<uint32_t>(), ocol.as<uint32_t>(), oval.p, &a));
-        rowptr.release(); ocol.release(); oval.release();
-        *out = a;
+        res.ptr = (uint32_t *)rowptr.release(); res.ind = (uint32_t *)ocol.release();
+        res.val = oval.release(); res.nnz = nnz; res.cap = cap;
         return SPAL_OK;
     }
 
     // ---- general route: sort by column bits, then by row bits (LSD), with the
     // column as key first (key <-> aux swapped for the column passes)
     cur = 0;
-    SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, 0, cbits, cur, st, c->d_cols, c->d_rows,
+    SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, 0, cbits, cur, st, d_minor, d_major,
                                     (const T *)c->d_vals));
     std::swap(sb.key[0], sb.aux[0]);  // now key = row, aux = col
     std::swap(sb.key[1], sb.aux[1]);
@@ -648,13 +655,15 @@ static int coo_assemble_t(spal_coo *c, hipStream_t st, spal_csr **out) {
                            nrows, rowptr.as<uint32_t>());
         SPAL_HIP_TRY(hipGetLastError());
         SPAL_HIP_TRY(hipStreamSynchronize(st));
-        spal_csr *a = nullptr;
-        SPAL_TRY(csr_adopt_device(c->device, (int)sizeof(T), c->nrows, c->ncols, nnz, cap,
-                                  rowptr.as<uint32_t>(), ocol.as<uint32_t>(), oval.p, &a));
-        rowptr.release(); ocol.release(); oval.release();
-        *out = a;
+        res.ptr = (uint32_t *)rowptr.release(); res.ind = (uint32_t *)ocol.release();
+        res.val = oval.release(); res.nnz = nnz; res.cap = cap;
     }
     return SPAL_OK;
+}
+
+static int coo_assemble(spal_coo *c, bool by_cols, hipStream_t st, Assembled &res) {
+    return c->elem_size == 8 ? coo_assemble_t<double>(c, by_cols, st, res)
+                             : coo_assemble_t<float>(c, by_cols, st, res);
 }
 
 // --------------------------------------------------------------------------
@@ -833,8 +842,39 @@ int spal_coo_assemble_csr(spal_coo_t c, void *stream, spal_csr_t *out) {
     *out = nullptr;
     DeviceGuard guard(c->device);
     if (guard.status != SPAL_OK) return guard.status;
-    return c->elem_size == 8 ? coo_assemble_t<double>(c, (hipStream_t)stream, out)
-                             : coo_assemble_t<float>(c, (hipStream_t)stream, out);
+    Assembled r;
+    SPAL_TRY(coo_assemble(c, false, (hipStream_t)stream, r));
+    int st = csr_adopt_device(c->device, c->elem_size, c->nrows, c->ncols, r.nnz, r.cap, r.ptr, r.ind,
+                              r.val, out);
+    if (st != SPAL_OK) { (void)hipFree(r.ptr); (void)hipFree(r.ind); (void)hipFree(r.val); }
+    return st;
+}
+int spal_coo_assemble_csc(spal_coo_t c, void *stream, spal_csc_t *out) {
+    if (!c || !out) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_coo_assemble_csc: null argument");
+    *out = nullptr;
+    DeviceGuard guard(c->device);
+    if (guard.status != SPAL_OK) return guard.status;
+    Assembled r;
+    SPAL_TRY(coo_assemble(c, true, (hipStream_t)stream, r));
+    if (r.cap < r.nnz + 256) {  // csc handles expect the over-read margin too
+        uint32_t *ind = nullptr;
+        void *val = nullptr;
+        hipError_t e = hipMalloc(&ind, (r.nnz + 256) * 4);
+        if (e == hipSuccess) e = hipMalloc(&val, (r.nnz + 256) * (size_t)c->elem_size);
+        if (e == hipSuccess) e = hipMemset(ind, 0, (r.nnz + 256) * 4);
+        if (e == hipSuccess) e = hipMemset(val, 0, (r.nnz + 256) * (size_t)c->elem_size);
+        if (e == hipSuccess && r.nnz) e = hipMemcpy(ind, r.ind, r.nnz * 4, hipMemcpyDeviceToDevice);
+        if (e == hipSuccess && r.nnz) e = hipMemcpy(val, r.val, r.nnz * (size_t)c->elem_size, hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(ind); (void)hipFree(val); (void)hipFree(r.ptr); (void)hipFree(r.ind); (void)hipFree(r.val);
+            return fail(SPAL_ERR_HIP, "spal_coo_assemble_csc: %s", hipGetErrorString(e));
+        }
+        (void)hipFree(r.ind); (void)hipFree(r.val);
+        r.ind = ind; r.val = val;
+    }
+    int st = csc_adopt_device(c->device, c->elem_size, c->nrows, c->ncols, r.nnz, r.ptr, r.ind, r.val, out);
+    if (st != SPAL_OK) { (void)hipFree(r.ptr); (void)hipFree(r.ind); (void)hipFree(r.val); }
+    return st;
 }
 int spal_coo_to_csr_f64(int device, uint64_t nrows, uint64_t ncols, uint64_t len, const uint64_t *rows,
                         const uint64_t *cols, const double *vals, spal_csr_t *out) {
@@ -843,6 +883,26 @@ int spal_coo_to_csr_f64(int device, uint64_t nrows, uint64_t ncols, uint64_t len
 int spal_coo_to_csr_f32(int device, uint64_t nrows, uint64_t ncols, uint64_t len, const uint64_t *rows,
                         const uint64_t *cols, const float *vals, spal_csr_t *out) {
     return coo_to_csr<float>(device, nrows, ncols, len, rows, cols, vals, out);
+}
+int spal_coo_to_csc_f64(int device, uint64_t nrows, uint64_t ncols, uint64_t len, const uint64_t *rows,
+                        const uint64_t *cols, const double *vals, spal_csc_t *out) {
+    if (!out) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_coo_to_csc: out is NULL");
+    *out = nullptr;
+    spal_coo_t c = nullptr;
+    SPAL_TRY(coo_upload<double>(device, nrows, ncols, len, rows, cols, vals, &c));
+    int st = spal_coo_assemble_csc(c, nullptr, out);
+    spal_coo_destroy(c);
+    return st;
+}
+int spal_coo_to_csc_f32(int device, uint64_t nrows, uint64_t ncols, uint64_t len, const uint64_t *rows,
+                        const uint64_t *cols, const float *vals, spal_csc_t *out) {
+    if (!out) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_coo_to_csc: out is NULL");
+    *out = nullptr;
+    spal_coo_t c = nullptr;
+    SPAL_TRY(coo_upload<float>(device, nrows, ncols, len, rows, cols, vals, &c));
+    int st = spal_coo_assemble_csc(c, nullptr, out);
+    spal_coo_destroy(c);
+    return st;
 }
 
 }  // extern "C"

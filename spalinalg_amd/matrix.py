@@ -181,6 +181,12 @@ class DeviceCoo:
         check(_ffi.lib().spal_coo_assemble_csr(self._h, _stream_ptr(stream), C.byref(out)))
         return DeviceCsr(out, self.dtype, self.device)
 
+    def assemble_csc(self, stream=None) -> DeviceCsc:
+        """COO -> CSC on the device (src/csc/conv/coo.rs:4-115)."""
+        out = vp()
+        check(_ffi.lib().spal_coo_assemble_csc(self._h, _stream_ptr(stream), C.byref(out)))
+        return DeviceCsc(out, self.dtype, self.device)
+
     def close(self):
         if self._h is not None:
             _ffi.lib().spal_coo_destroy(self._h)
@@ -339,6 +345,17 @@ class CscMatrix(_Compressed):
 
     def rowind(self) -> np.ndarray:
         return self._ind
+
+    @classmethod
+    def from_coo(cls, coo: "CooMatrix", device: int = 0) -> "CscMatrix":
+        """`CscMatrix::from(&coo)` (src/csc/conv/coo.rs:3-116) on the device."""
+        d = coo.upload(device)
+        dev = d.assemble_csc()
+        d.close()
+        cp, ri, va = dev.download()
+        out = cls._trusted(coo.nrows(), coo.ncols(), cp, ri, va)
+        out._dev[device] = dev
+        return out
 
     @classmethod
     def from_csr(cls, csr: "CsrMatrix", device: int = 0) -> "CscMatrix":

@@ -63,6 +63,16 @@ static void gpu_tests() {
     CHECK(csr.colind() == (std::vector<usize>{0, 1, 2, 2}));
     CHECK(csr.values() == (std::vector<double>{3.0, 3.0, 4.0, 5.0}));
     CHECK((csr * std::vector<double>{1.0, 1.0, 1.0}) == (std::vector<double>{10.0, 5.0}));
+    // src/csc/conv/coo.rs:128-145 (same pushes, compressed by column)
+    auto csc = CscMatrix<double>::from(coo);
+    CHECK(csc.colptr() == (std::vector<usize>{0, 1, 2, 4}));
+    CHECK(csc.rowind() == (std::vector<usize>{0, 0, 0, 1}));
+    CHECK(csc.values() == (std::vector<double>{3.0, 3.0, 4.0, 5.0}));
+    // src/csr/conv/csc.rs:65-78 and src/csc/conv/csr.rs:65-78
+    auto csr2 = CsrMatrix<double>::from(csc);
+    CHECK(csr2.rowptr() == csr.rowptr() && csr2.colind() == csr.colind() && csr2.values() == csr.values());
+    auto csc2 = CscMatrix<double>::from(csr);
+    CHECK(csc2.colptr() == csc.colptr() && csc2.rowind() == csc.rowind() && csc2.values() == csc.values());
     // src/csc/ops/mul.rs:67-95: every rhs column is an x, every result column its y
     CscMatrix<double> lhs(5, 3, {0, 3, 4, 6}, {0, 1, 4, 3, 1, 2}, {1.0, -5.0, 4.0, 3.0, 7.0, 2.0});
     CHECK((lhs * std::vector<double>{1.0, -5.0, 7.0}) == (std::vector<double>{1.0, 44.0, 14.0, -15.0, 4.0}));

@@ -163,6 +163,26 @@ def assemble_and_compare(oracle, nrows, ncols, r, c, v):
     return csr
 
 
+def test_coo_to_csc_kat_g2_and_random(kats, oracle):
+    """`CscMatrix::from(&coo)` (src/csc/conv/coo.rs): G2 and random inputs, bit-exact."""
+    g = kats["G2_coo_to_csc"]
+    coo = sp.CooMatrix.with_triplets(g["nrows"], g["ncols"], g["rows"], g["cols"], np.array(g["vals"]))
+    csc = sp.CscMatrix.from_coo(coo)
+    assert (csc.colptr().tolist(), csc.rowind().tolist(), csc.values().tolist()) == (
+        g["colptr"], g["rowind"], g["values"])
+    rng = np.random.default_rng(41)
+    for nr, nc, n in [(1, 1, 9), (90, 100, 5000), (3, 70_000, 100_000), (5000, 4000, 250_000)]:
+        r = rng.integers(0, nr, n).astype(np.uint64)
+        c = rng.integers(0, nc, n).astype(np.uint64)
+        v = rng.integers(-2, 3, n).astype(np.float64) * rng.uniform(0.5, 1.5)
+        csc = sp.CscMatrix.from_coo(sp.CooMatrix.with_triplets(nr, nc, r, c, v))
+        p, i, w = oracle.coo_to_csc(nr, nc, r, c, v)
+        assert np.array_equal(csc.colptr(), p) and np.array_equal(csc.rowind(), i)
+        assert np.array_equal(csc.values().view(np.uint64), w.view(np.uint64))
+        x = rng.uniform(-1, 1, nc)
+        np.testing.assert_allclose(csc * x, oracle.csc_spmv(nr, p, i, w, x), rtol=1e-10, atol=1e-12)
+
+
 def test_coo_kat_g1(kats, oracle):
     g = kats["G1_coo_to_csr"]
     coo = sp.CooMatrix(g["nrows"], g["ncols"])
