@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (tuning)")
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "halo"],
+                    help="N > 1 only: per-step exchange of y. allgather (default, what BASELINE's north_star "
+                         "describes: every rank ends with the whole y) or halo (SURVEY 8f-4: each rank receives "
+                         "only the entries its rows reference; banded shards: +-W/2 from the neighbours)")
     return ap.parse_args()
 
 
@@ -251,6 +255,10 @@ def main():
     plan = dev.describe()
 
     op = RowPartitionedSpmv.from_shard(dev, bounds, rank, world, device)
+    if world > 1 and args.exchange == "halo":
+        if nrows != ncols:
+            sys.exit("--exchange halo needs a square matrix (y feeds back as x)")
+        op.plan_halo(int(ci.min()), int(ci.max()) + 1)
 
     # ---- x: generated on rank 0, broadcast once over RCCL
     if rank == 0:
@@ -269,6 +277,8 @@ def main():
     def step():
         if world == 1:
             dev.spmv_torch(x, out=y)       # y is the rank's (= the whole) slice
+        elif args.exchange == "halo":
+            op.spmv_halo(x, y)
         else:
             op.spmv(x, y)
 
@@ -368,7 +378,9 @@ def main():
                         + (f" W={window}" if args.dist == "banded" else "")
                         + f" (BASELINE configs[{2 if args.config == 3 else 1}]), "
                         + ("single GPU" if world == 1 else
-                           f"rows partitioned over {world} GPUs, x bcast once, y all-gather per step (RCCL)"),
+                           f"rows partitioned over {world} GPUs, x bcast once, "
+                           + ("y all-gather per step (RCCL)" if args.exchange == "allgather" else
+                              f"halo exchange per step (RCCL send/recv, {getattr(op, 'halo_bytes', 0)} B received per rank)")),
             "nrows": nrows, "ncols": ncols, "nnz": nnz, "algorithmic_index_bits": 32,
             "partition": "none" if world == 1 else f"rows/{world}",
             "plan": plan,

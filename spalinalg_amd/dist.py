@@ -83,6 +83,58 @@ class RowPartitionedSpmv:
         self.local_spmv(x, self.y_local)
         return self.y_local[: self.r1 - self.r0]
 
+    # ---- halo exchange -------------------------------------
+    # For a square matrix used iteratively (y is the next x) a rank does not need
+    # the whole vector, only the columns its rows reference: [need_lo, need_hi).
+    # For banded matrices that is its own slice plus a halo of W/2 entries on
+    # either side, so the per-step exchange shrinks from an all-gather of the
+    # whole vector to two small neighbour messages.
+    def plan_halo(self, need_lo: int, need_hi: int):
+        """need_lo/need_hi: smallest / one past the largest column referenced by
+        this rank's rows.  Collective: every rank learns every rank's needs."""
+        torch, dist = self.torch, self.torch.distributed
+        dev = self.y_local.device
+        mine = torch.tensor([need_lo, need_hi], dtype=torch.int64, device=dev)
+        allneeds = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        if self.world > 1:
+            dist.all_gather(allneeds, mine, group=self.group)
+        else:
+            allneeds = [mine]
+        needs = [(int(t[0]), int(t[1])) for t in allneeds]
+        own = [(int(self.bounds[g]), int(self.bounds[g + 1])) for g in range(self.world)]
+
+        def cut(a, b):  # intersection of two half-open ranges
+            lo, hi = max(a[0], b[0]), min(a[1], b[1])
+            return (lo, hi) if lo < hi else None
+
+        # what I receive from g: my need inside g's slice; what I send to g: g's need inside mine
+        self.halo_recv = [(g, *c) for g in range(self.world) if g != self.rank
+                          for c in [cut(needs[self.rank], own[g])] if c]
+        self.halo_send = [(g, *c) for g in range(self.world) if g != self.rank
+                          for c in [cut(needs[g], own[self.rank])] if c]
+        self.halo_bytes = sum(hi - lo for _, lo, hi in self.halo_recv) * self.y_local.element_size()
+        return self
+
+    def spmv_halo(self, x, y_vec):
+        """y_vec[own rows] = A_local * x, then the entries of y_vec that this
+        rank's rows reference as columns ([need_lo, need_hi)) are completed from
+        their owners.  x and y_vec are full-length buffers; only the own slice
+        and the halo regions hold meaningful data."""
+        dist = self.torch.distributed
+        own = y_vec[self.r0:self.r1]
+        self.local_spmv(x, self.y_local)
+        own.copy_(self.y_local[: self.r1 - self.r0])
+        if self.world == 1 or not (self.halo_recv or self.halo_send):
+            return y_vec
+        ops = []
+        for g, lo, hi in self.halo_send:
+            ops.append(dist.P2POp(dist.isend, y_vec[lo:hi], g, group=self.group))
+        for g, lo, hi in self.halo_recv:
+            ops.append(dist.P2POp(dist.irecv, y_vec[lo:hi], g, group=self.group))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        return y_vec
+
     def spmv(self, x, y_full):
         """y_full (nrows, on every rank) = A * x."""
         dist = self.torch.distributed

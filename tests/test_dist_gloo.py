@@ -67,3 +67,66 @@ def test_row_partitioned_spmv_gloo(world, equal):
     assert all(o[1] for o in out), "every rank must end with the complete, identical y"
     assert all(o[2] == equal for o in out)
     assert all(o[3] == out[0][3] for o in out)
+
+
+def _halo_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import oracle
+    import spalinalg_amd as sp
+    from spalinalg_amd.dist import RowPartitionedSpmv, partition_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, w = 6000, 512
+        rp, ci, va = sp.synth.banded_csr(n, n, 14, w, 77)
+        bounds = partition_rows(rp, world)
+        a = sp.CsrMatrix(n, n, rp, ci, va)
+        r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+        shard = a.row_slice(r0, r1)
+
+        def local(x_full, out_local):          # oracle stands in for the HIP kernel (test only)
+            y = oracle.csr_spmv(shard.rowptr(), shard.colind(), shard.values(), x_full.numpy())
+            out_local[: y.size].copy_(torch.from_numpy(y))
+
+        op = RowPartitionedSpmv(local, bounds, rank, world, torch.float64, "cpu")
+        need_lo, need_hi = int(shard.colind().min()), int(shard.colind().max()) + 1
+        op.plan_halo(need_lo, need_hi)
+        x0 = sp.synth.vector(n)
+        # two products in a row, y feeding back as x: only own slice + halo is ever exchanged
+        x = torch.from_numpy(x0.copy())
+        y = torch.full((n,), float("nan"), dtype=torch.float64)
+        op.spmv_halo(x, y)
+        z = torch.full((n,), float("nan"), dtype=torch.float64)
+        op.spmv_halo(y, z)
+        x1 = oracle.csr_spmv(rp, ci, va, x0)
+        x2 = oracle.csr_spmv(rp, ci, va, x1)
+        ok1 = bool(np.array_equal(y.numpy()[need_lo:need_hi], x1[need_lo:need_hi]))
+        ok2 = bool(np.array_equal(z.numpy()[r0:r1], x2[r0:r1]))
+        untouched = bool(np.isnan(y.numpy()[:need_lo]).all() and np.isnan(y.numpy()[need_hi:]).all())
+        q.put((rank, ok1, ok2, untouched, op.halo_bytes, (r1 - r0) * 8))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_halo_exchange_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok1, ok2, untouched, halo_bytes, own_bytes in out:
+        assert ok1, "own slice + halo of the first product must be complete and exact"
+        assert ok2, "the second product (fed by the halo-exchanged y) must be exact on the own rows"
+        assert untouched, "nothing outside [need_lo, need_hi) is transferred"
+        assert halo_bytes <= 2 * 256 * 8 + 64          # +-W/2 entries per side
+        assert halo_bytes < own_bytes / 2
