@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (tuning)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo only to rehearse the N > 1 path on a 1-GPU box")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "halo"],
                     help="N > 1 only: per-step exchange of y. allgather (default, what BASELINE's north_star "
                          "describes: every rank ends with the whole y) or halo (SURVEY 8f-4: each rank receives "
@@ -224,11 +228,16 @@ def main():
 
     if not torch.cuda.is_available() or sp.device_count() < 1:
         sys.exit("bench.py needs a GPU: libspal_hip has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cfg = sp.synth.CONFIGS[args.config]
     nrows, ncols, per_row = cfg["nrows"], cfg["ncols"], cfg["per_row"]
@@ -273,6 +282,8 @@ def main():
     torch.cuda.synchronize()
     x_bcast_ms = (time.perf_counter() - tb) * 1e3 if world > 1 else 0.0
     y = torch.empty(nrows, dtype=t_dt, device=device)
+    # setup: let the library pick between its kernel variants on this device (results are identical)
+    plan = dev.autotune(x, op.y_local[: r1 - r0], iters=30)
 
     def step():
         if world == 1:

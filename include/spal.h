@@ -118,6 +118,14 @@ int spal_csr_download_f32(spal_csr_t a, uint64_t *rowptr, uint64_t *colind,
  * "rows_per_block", "lanes_per_row", "lds_x" (-1 auto/0/1), "unroll", "threads".  Unknown key or
  * a value the kernels are not instantiated for: SPAL_ERR_INVALID_ARGUMENT. */
 int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value);
+/* Setup-time autotune: runs the planned kernel's variants (today: the stream
+ * kernel with one workgroup per super-tile vs. its persistent form) `iters`
+ * times each on the caller's device vectors, keeps the fastest.  All variants
+ * produce identical y.  Synchronises `stream`. */
+int spal_csr_autotune_f64(spal_csr_t a, const double *x_dev, double *y_dev,
+                          void *stream, int iters);
+int spal_csr_autotune_f32(spal_csr_t a, const float *x_dev, float *y_dev,
+                          void *stream, int iters);
 /* Writes a one-line JSON description of the active plan into buf. */
 int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len);
 

@@ -578,6 +578,54 @@ static int csr_download(spal_csr_t a, uint64_t *rowptr, uint64_t *colind, T *val
     return SPAL_OK;
 }
 
+// Times the applicable variants of the planned kernel on the caller's vectors
+// and keeps the fastest (all variants compute identical results).  Setup-time
+// work: it synchronises `stream`.
+template <typename T>
+static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, int iters) {
+    if (!a) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_autotune: handle is NULL");
+    if (a->elem_size != (int)sizeof(T))
+        return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_autotune: handle holds %s values",
+                    a->elem_size == 8 ? "f64" : "f32");
+    if (!x_dev || !y_dev) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_autotune: null vector");
+    if (iters < 1) iters = 1;
+    DeviceGuard guard(a->device);
+    if (guard.status != SPAL_OK) return guard.status;
+    std::lock_guard<std::mutex> lock(a->mu);
+    CsrPlan &p = a->plan;
+    a->tuned_us[0] = a->tuned_us[1] = 0.f;
+    if (a->nnz == 0 || p.kernel != 2 || p.tiles_per_wave != 4) return SPAL_OK;  // nothing to choose from
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    SPAL_HIP_TRY(hipEventCreate(&e0));
+    SPAL_HIP_TRY(hipEventCreate(&e1));
+    int best = p.persistent;
+    float best_ms = 1e30f;
+    int rc = SPAL_OK;
+    for (int round = 0; round < 2 && rc == SPAL_OK; ++round) {      // round 0 also settles the clocks
+        for (int cand = 0; cand < 2 && rc == SPAL_OK; ++cand) {
+            p.persistent = cand;
+            for (int i = 0; i < 3 && rc == SPAL_OK; ++i) rc = csr_launch(a, x_dev, y_dev, st);
+            if (rc != SPAL_OK) break;
+            hipError_t e = hipEventRecord(e0, st);
+            for (int i = 0; i < iters && rc == SPAL_OK; ++i) rc = csr_launch(a, x_dev, y_dev, st);
+            if (e == hipSuccess) e = hipEventRecord(e1, st);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e != hipSuccess) { rc = fail(SPAL_ERR_HIP, "spal_csr_autotune: %s", hipGetErrorString(e)); break; }
+            if (round == 1) {
+                a->tuned_us[cand] = ms * 1e3f / (float)iters;
+                if (ms < best_ms) { best_ms = ms; best = cand; }
+            }
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    p.persistent = best;
+    return rc;
+}
+
 }  // namespace spal
 
 using namespace spal;
@@ -697,6 +745,13 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
     return st;
 }
 
+int spal_csr_autotune_f64(spal_csr_t a, const double *x_dev, double *y_dev, void *stream, int iters) {
+    return csr_autotune<double>(a, x_dev, y_dev, stream, iters);
+}
+int spal_csr_autotune_f32(spal_csr_t a, const float *x_dev, float *y_dev, void *stream, int iters) {
+    return csr_autotune<float>(a, x_dev, y_dev, stream, iters);
+}
+
 int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
     if (!a || !buf || !buf_len) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_describe: null argument");
     const CsrPlan &p = a->plan;
@@ -705,13 +760,14 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "\"index_bits\": %d, \"kernel\": \"%s\", \"lanes_per_row\": %d, \"unroll\": %d, "
              "\"rows_per_block\": %d, \"blocks\": %u, \"threads_per_block\": %d, \"lds_x\": %d, "
              "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f, "
-             "\"persistent\": %d}",
+             "\"persistent\": %d, \"autotune_us\": [%.1f, %.1f]}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, p.kernel == 2 ? 16 : 32,
              p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
              p.rows_per_block, p.nblocks, p.threads, p.lds_x,
              (unsigned long long)p.lds_entries * (unsigned long long)a->elem_size, p.lds_row_fraction,
-             p.stream_row_fraction, (p.kernel == 2 && p.persistent && p.tiles_per_wave == 4) ? 1 : 0);
+             p.stream_row_fraction, (p.kernel == 2 && p.persistent && p.tiles_per_wave == 4) ? 1 : 0,
+             (double)a->tuned_us[0], (double)a->tuned_us[1]);
     return SPAL_OK;
 }
 

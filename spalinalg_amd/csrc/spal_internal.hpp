@@ -108,6 +108,7 @@ struct spal_csr {
     uint16_t *d_col16 = nullptr;   // nnz (+pad): window-relative columns of streamable super-tiles
     uint4 *d_desc = nullptr;       // per row block {window base column, window length or 0, mode, 0}
     uint64_t cap_entries = 0;      // allocated entries of d_colind / d_values (>= nnz + pad)
+    float tuned_us[2] = {0.f, 0.f};  // autotune: microseconds per launch, plain / persistent stream kernel
     spal::CsrPlan plan;
     // host-convenience staging (spal_csr_spmv_*): guarded by mu
     std::mutex mu;

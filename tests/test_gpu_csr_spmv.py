@@ -204,6 +204,23 @@ def test_dimension_mismatch_panics():
         a.device().spmv(np.ones(4))
 
 
+def test_autotune_keeps_results(oracle):
+    torch = pytest.importorskip("torch")
+    n = 400_000
+    rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, 9)
+    x = sp.synth.vector(n)
+    dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.empty_like(xd)
+    d = dev.autotune(xd, yd, iters=5)
+    assert d["autotune_us"][0] > 0 and d["autotune_us"][1] > 0 and d["persistent"] in (0, 1)
+    assert np.array_equal(dev.spmv_torch(xd).cpu().numpy(), oracle.csr_spmv(rp, ci, va, x))
+    # a matrix the vector kernel handles: nothing to tune, still fine
+    rp, ci, va = sp.synth.banded_csr(n, n, 14, n, 9)
+    dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    assert dev.autotune(xd, yd, iters=2)["autotune_us"] == [0.0, 0.0]
+
+
 def test_device_path_with_torch_stream(oracle):
     """the timed entry point: device pointers + torch's current stream."""
     torch = pytest.importorskip("torch")
