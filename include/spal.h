@@ -119,8 +119,9 @@ int spal_csr_download_f32(spal_csr_t a, uint64_t *rowptr, uint64_t *colind,
  * a value the kernels are not instantiated for: SPAL_ERR_INVALID_ARGUMENT. */
 int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value);
 /* Setup-time autotune: runs the planned kernel's variants (today: the stream
- * kernel with one workgroup per super-tile vs. its persistent form) `iters`
- * times each on the caller's device vectors, keeps the fastest.  All variants
+ * kernel with one workgroup per super-tile vs. its persistent form, each with
+ * plain or non-temporal y stores) `iters` times each on the caller's device
+ * vectors, keeps the fastest.  All variants
  * produce identical y.  Synchronises `stream`. */
 int spal_csr_autotune_f64(spal_csr_t a, const double *x_dev, double *y_dev,
                           void *stream, int iters);

@@ -339,7 +339,7 @@ __device__ __forceinline__ void stream_load(StreamTile<T> &t, const uint32_t *__
 template <typename T>
 __device__ __forceinline__ void stream_compute(const StreamTile<T> &t, const T *xw, uint32_t wmax,
                                                T *prod, T *__restrict__ y, uint32_t row0,
-                                               uint32_t row1, uint32_t lane) {
+                                               uint32_t row1, uint32_t lane, bool nt_store = false) {
     using pair_t = typename Pair<T>::type;
     pair_t *prod2 = reinterpret_cast<pair_t *>(prod);
 #pragma unroll
@@ -378,7 +378,10 @@ __device__ __forceinline__ void stream_compute(const StreamTile<T> &t, const T *
         for (; k < len; ++k) acc = acc + prod[off + k];
     }
     __builtin_amdgcn_wave_barrier();  // the next tile's products overwrite this strip
-    if (row0 + lane < min(row0 + kStreamTileRows, row1)) y[row0 + lane] = acc;
+    if (row0 + lane < min(row0 + kStreamTileRows, row1)) {
+        if (nt_store) __builtin_nontemporal_store(acc, &y[row0 + lane]);  // y is written once, never re-read here
+        else y[row0 + lane] = acc;
+    }
 }
 
 // desc[b] = {window base column, window length, mode, 0}
@@ -387,8 +390,9 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
     const uint16_t *__restrict__ col16, const T *__restrict__ vals, const T *__restrict__ x,
     T *__restrict__ y, const uint4 *__restrict__ desc, uint32_t nrows, uint32_t nnz,
-    uint32_t nblocks, uint32_t per_xcd) {
+    uint32_t nblocks, uint32_t per_xcd, uint32_t flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
+    const bool nt_store = flags & 1u;
     // [ products: 4 waves x kStreamTileNnz ][ x window ]
     T *prod_all = reinterpret_cast<T *>(spal_smem);
     T *xw = prod_all + kStreamWaves * kStreamTileNnz;
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
             const uint32_t rn = r0 + kStreamTileRows;
             const bool more = (k + 1 < TPW) && rn < row1;
             if (more) stream_load<T>(nxt, rowptr, col16, vals, rn, row1, tb[k + 1], tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
-            stream_compute<T>(cur, xw, wmax, prod, y, r0, row1, lane);
+            stream_compute<T>(cur, xw, wmax, prod, y, r0, row1, lane, nt_store);
             if (more) cur = nxt;
         }
         return;
@@ -458,8 +462,9 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
     const uint16_t *__restrict__ col16, const T *__restrict__ vals, const T *__restrict__ x,
     T *__restrict__ y, const uint4 *__restrict__ desc, uint32_t nrows, uint32_t nnz,
-    uint32_t nblocks, uint32_t per_xcd, uint32_t chunk) {
+    uint32_t nblocks, uint32_t per_xcd, uint32_t chunk, uint32_t flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
+    const bool nt_store = flags & 1u;
     T *prod_all = reinterpret_cast<T *>(spal_smem);
     T *xw = prod_all + kStreamWaves * kStreamTileNnz;
     constexpr uint32_t kRows = stream_rows(TPW);
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
                             fetched_next = true;
                         }
                     }
-                    stream_compute<T>(cur, xw, wmax, prod, y, r0, row1, lane);
+                    stream_compute<T>(cur, xw, wmax, prod, y, r0, row1, lane, nt_store);
                     if (more || fetched_next) cur = nxt;
                 }
             }

@@ -160,7 +160,8 @@ static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, h
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
                        a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc,
-                       (uint32_t)a->nrows, (uint32_t)a->nnz, p.nblocks, per_xcd);
+                       (uint32_t)a->nrows, (uint32_t)a->nnz, p.nblocks, per_xcd,
+                       (uint32_t)(p.nt_store ? 1 : 0));
     return hipGetLastError();
 }
 
@@ -179,7 +180,8 @@ static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, voi
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(used * 8), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
                        a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc,
-                       (uint32_t)a->nrows, (uint32_t)a->nnz, p.nblocks, per_xcd, chunk);
+                       (uint32_t)a->nrows, (uint32_t)a->nnz, p.nblocks, per_xcd, chunk,
+                       (uint32_t)(p.nt_store ? 1 : 0));
     return hipGetLastError();
 }
 
@@ -593,18 +595,20 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
     if (guard.status != SPAL_OK) return guard.status;
     std::lock_guard<std::mutex> lock(a->mu);
     CsrPlan &p = a->plan;
-    a->tuned_us[0] = a->tuned_us[1] = 0.f;
+    for (float &t : a->tuned_us) t = 0.f;
     if (a->nnz == 0 || p.kernel != 2 || p.tiles_per_wave != 4) return SPAL_OK;  // nothing to choose from
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
     SPAL_HIP_TRY(hipEventCreate(&e0));
     SPAL_HIP_TRY(hipEventCreate(&e1));
-    int best = p.persistent;
+    int best = (p.persistent ? 1 : 0) | (p.nt_store ? 2 : 0);
     float best_ms = 1e30f;
     int rc = SPAL_OK;
+    // candidate c: bit 0 = persistent form, bit 1 = non-temporal y stores
     for (int round = 0; round < 2 && rc == SPAL_OK; ++round) {      // round 0 also settles the clocks
-        for (int cand = 0; cand < 2 && rc == SPAL_OK; ++cand) {
-            p.persistent = cand;
+        for (int cand = 0; cand < 4 && rc == SPAL_OK; ++cand) {
+            p.persistent = cand & 1;
+            p.nt_store = (cand >> 1) & 1;
             for (int i = 0; i < 3 && rc == SPAL_OK; ++i) rc = csr_launch(a, x_dev, y_dev, st);
             if (rc != SPAL_OK) break;
             hipError_t e = hipEventRecord(e0, st);
@@ -622,7 +626,8 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    p.persistent = best;
+    p.persistent = best & 1;
+    p.nt_store = (best >> 1) & 1;
     return rc;
 }
 
@@ -722,6 +727,9 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         else if (value != 1 && value != 2 && value != 4)
             return fail(SPAL_ERR_INVALID_ARGUMENT, "unroll must be 1, 2 or 4");
         else { p.unroll = (int)value; p.user_unroll = true; }
+    } else if (!strcmp(key, "nt_store")) {
+        if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "nt_store must be 0 or 1");
+        p.nt_store = (int)value;
     } else if (!strcmp(key, "persistent")) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "persistent must be 0 or 1");
         p.persistent = (int)value;
@@ -760,14 +768,15 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "\"index_bits\": %d, \"kernel\": \"%s\", \"lanes_per_row\": %d, \"unroll\": %d, "
              "\"rows_per_block\": %d, \"blocks\": %u, \"threads_per_block\": %d, \"lds_x\": %d, "
              "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f, "
-             "\"persistent\": %d, \"autotune_us\": [%.1f, %.1f]}",
+             "\"persistent\": %d, \"nt_store\": %d, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f]}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, p.kernel == 2 ? 16 : 32,
              p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
              p.rows_per_block, p.nblocks, p.threads, p.lds_x,
              (unsigned long long)p.lds_entries * (unsigned long long)a->elem_size, p.lds_row_fraction,
              p.stream_row_fraction, (p.kernel == 2 && p.persistent && p.tiles_per_wave == 4) ? 1 : 0,
-             (double)a->tuned_us[0], (double)a->tuned_us[1]);
+             (p.kernel == 2 && p.nt_store) ? 1 : 0, (double)a->tuned_us[0], (double)a->tuned_us[1],
+             (double)a->tuned_us[2], (double)a->tuned_us[3]);
     return SPAL_OK;
 }
 

@@ -74,6 +74,7 @@ struct CsrPlan {
     int threads = 512;       // workgroup size: 512 or 1024
     int tiles_per_wave = 4;  // stream kernel: 64-row tiles per wave (4 or 8)
     int persistent = 0;      // stream kernel: fixed grid walking chunks of super-tiles
+    int nt_store = 0;        // stream kernel: non-temporal stores of y
     int persistent_blocks = 512;  // its grid (2 workgroups per CU on 256 CUs)
     int rows_per_block = 0;  // R
     int lds_x = 0;           // stage the block's x window in LDS
@@ -108,7 +109,8 @@ struct spal_csr {
     uint16_t *d_col16 = nullptr;   // nnz (+pad): window-relative columns of streamable super-tiles
     uint4 *d_desc = nullptr;       // per row block {window base column, window length or 0, mode, 0}
     uint64_t cap_entries = 0;      // allocated entries of d_colind / d_values (>= nnz + pad)
-    float tuned_us[2] = {0.f, 0.f};  // autotune: microseconds per launch, plain / persistent stream kernel
+    // autotune: microseconds per launch of {plain, persistent} x {plain, non-temporal y stores}
+    float tuned_us[4] = {0.f, 0.f, 0.f, 0.f};
     spal::CsrPlan plan;
     // host-convenience staging (spal_csr_spmv_*): guarded by mu
     std::mutex mu;

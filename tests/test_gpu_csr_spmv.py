@@ -77,6 +77,7 @@ def test_stream_kernel_is_bit_identical_to_the_reference_order(oracle):
         assert np.array_equal(y, oracle.csr_spmv(rp, ci, va, x))
         for persistent, blocks in ((1, 512), (1, 8), (1, 1024), (0, 512)):
             dev.set_option("persistent", persistent)
+            dev.set_option("nt_store", blocks == 8)
             dev.set_option("persistent_blocks", blocks)
             assert dev.describe()["persistent"] == persistent
             assert np.array_equal(dev.spmv(x), y)
@@ -213,12 +214,12 @@ def test_autotune_keeps_results(oracle):
     xd = torch.from_numpy(x).cuda()
     yd = torch.empty_like(xd)
     d = dev.autotune(xd, yd, iters=5)
-    assert d["autotune_us"][0] > 0 and d["autotune_us"][1] > 0 and d["persistent"] in (0, 1)
+    assert all(t > 0 for t in d["autotune_us"]) and d["persistent"] in (0, 1) and d["nt_store"] in (0, 1)
     assert np.array_equal(dev.spmv_torch(xd).cpu().numpy(), oracle.csr_spmv(rp, ci, va, x))
     # a matrix the vector kernel handles: nothing to tune, still fine
     rp, ci, va = sp.synth.banded_csr(n, n, 14, n, 9)
     dev = sp.CsrMatrix(n, n, rp, ci, va).device()
-    assert dev.autotune(xd, yd, iters=2)["autotune_us"] == [0.0, 0.0]
+    assert dev.autotune(xd, yd, iters=2)["autotune_us"] == [0.0] * 4
 
 
 def test_device_path_with_torch_stream(oracle):
