@@ -289,9 +289,11 @@ __global__ __launch_bounds__(BLOCK, 8) void csr_spmv_vector(
 // done by vector_rows() in the same launch (block-uniform branch).
 constexpr int kStreamBlock = 256;
 constexpr int kStreamWaves = kStreamBlock / kWave;                          // 4
-constexpr int kStreamTileRows = 64;
-// rows of a super-tile when every wave owns TPW tiles (TPW = 4: 1024, 8: 2048)
-constexpr int stream_rows(int tpw) { return kStreamWaves * tpw * kStreamTileRows; }
+// A tile holds RPT rows (64, 32 or 16: one lane per row, the other lanes idle
+// in the reduction) and at most kStreamTileNnz entries; narrower tiles let
+// matrices with up to ~64 entries per row stream as well.
+// rows of a super-tile when every wave owns TPW tiles of RPT rows (4 x 64: 1024)
+constexpr int stream_rows(int tpw, int rpt = 64) { return kStreamWaves * tpw * rpt; }
 constexpr int kStreamSteps = 8;                                             // 128 entries per step
 constexpr int kStreamTileNnz = kStreamSteps * 128;                          // 1024 incl. alignment slack
 constexpr int kStreamPad = 256;  // device arrays are over-allocated by this many entries
@@ -311,13 +313,13 @@ struct StreamTile {
 };
 
 // b, e: the tile's entry range [rowptr[row0], rowptr[last row + 1]), wave-uniform
-template <typename T>
+template <typename T, int RPT>
 __device__ __forceinline__ void stream_load(StreamTile<T> &t, const uint32_t *__restrict__ rowptr,
                                             const uint16_t *__restrict__ col16,
                                             const T *__restrict__ vals, uint32_t row0,
                                             uint32_t row1, uint32_t b, uint32_t e, uint32_t lane) {
     using pair_t = typename Pair<T>::type;
-    const uint32_t rlast = min(row0 + kStreamTileRows, row1);
+    const uint32_t rlast = min(row0 + (uint32_t)RPT, row1);
     t.start = b & ~1u;
     t.steps = (e - t.start + 127u) >> 7;
     const uint32_t e0 = t.start + lane * 2;
@@ -336,7 +338,7 @@ __device__ __forceinline__ void stream_load(StreamTile<T> &t, const uint32_t *__
     t.rp1 = rowptr[min(row0 + lane + 1, rlast)];
 }
 
-template <typename T>
+template <typename T, int RPT>
 __device__ __forceinline__ void stream_compute(const StreamTile<T> &t, const T *xw, uint32_t wmax,
                                                T *prod, T *__restrict__ y, uint32_t row0,
                                                uint32_t row1, uint32_t lane, bool nt_store = false) {
@@ -378,14 +380,14 @@ __device__ __forceinline__ void stream_compute(const StreamTile<T> &t, const T *
         for (; k < len; ++k) acc = acc + prod[off + k];
     }
     __builtin_amdgcn_wave_barrier();  // the next tile's products overwrite this strip
-    if (row0 + lane < min(row0 + kStreamTileRows, row1)) {
+    if (row0 + lane < min(row0 + (uint32_t)RPT, row1)) {
         if (nt_store) __builtin_nontemporal_store(acc, &y[row0 + lane]);  // y is written once, never re-read here
         else y[row0 + lane] = acc;
     }
 }
 
 // desc[b] = {window base column, window length, mode, 0}
-template <typename T, int L, int U, bool USE_DPP, int TPW>
+template <typename T, int L, int U, bool USE_DPP, int TPW, int RPT>
 __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
     const uint16_t *__restrict__ col16, const T *__restrict__ vals, const T *__restrict__ x,
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
 
     const uint32_t b = xcd_contiguous_block(blockIdx.x, per_xcd);
     if (b >= nblocks) return;
-    constexpr uint32_t kRows = stream_rows(TPW);
+    constexpr uint32_t kRows = stream_rows(TPW, RPT);
     const uint32_t row0 = b * kRows;
     const uint32_t row1 = min(row0 + kRows, nrows);
     const uint4 d = desc[b];  // block-uniform
@@ -409,28 +411,28 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
         const uint32_t wave = threadIdx.x / kWave;
         T *prod = prod_all + wave * kStreamTileNnz;
         // this wave's tiles: rows row0 + (wave*4 + k) * 64
-        const uint32_t wrow = row0 + wave * (TPW * kStreamTileRows);
+        const uint32_t wrow = row0 + wave * (TPW * (uint32_t)RPT);
         // entry offsets of this wave's tile boundaries, fetched once (lane k holds
         // boundary k) so that no tile's loads wait on a row-pointer round trip
-        const uint32_t tb_lane = rowptr[min(wrow + min(lane, (uint32_t)TPW) * kStreamTileRows, row1)];
+        const uint32_t tb_lane = rowptr[min(wrow + min(lane, (uint32_t)TPW) * (uint32_t)RPT, row1)];
         uint32_t tb[TPW + 1];
 #pragma unroll
         for (int k = 0; k <= TPW; ++k) tb[k] = __builtin_amdgcn_readlane(tb_lane, k);
         StreamTile<T> cur, nxt;
         const bool has0 = wrow < row1;  // wave-uniform
-        if (has0) stream_load<T>(cur, rowptr, col16, vals, wrow, row1, tb[0], tb[1], lane);  // overlaps the staging
+        if (has0) stream_load<T, RPT>(cur, rowptr, col16, vals, wrow, row1, tb[0], tb[1], lane);  // overlaps the staging
         stage_window<T, kStreamBlock>(xw, x, d.x, d.y);
         __syncthreads();
         if (!has0) return;
         const uint32_t wmax = d.y - 1;
 #pragma unroll
         for (int k = 0; k < TPW; ++k) {
-            const uint32_t r0 = wrow + k * kStreamTileRows;
+            const uint32_t r0 = wrow + k * (uint32_t)RPT;
             if (r0 >= row1) break;  // wave-uniform
-            const uint32_t rn = r0 + kStreamTileRows;
+            const uint32_t rn = r0 + (uint32_t)RPT;
             const bool more = (k + 1 < TPW) && rn < row1;
-            if (more) stream_load<T>(nxt, rowptr, col16, vals, rn, row1, tb[k + 1], tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
-            stream_compute<T>(cur, xw, wmax, prod, y, r0, row1, lane, nt_store);
+            if (more) stream_load<T, RPT>(nxt, rowptr, col16, vals, rn, row1, tb[k + 1], tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
+            stream_compute<T, RPT>(cur, xw, wmax, prod, y, r0, row1, lane, nt_store);
             if (more) cur = nxt;
         }
         return;
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
 // barriers that retire the old x window and publish the new one.  This removes
 // the per-workgroup cold start (boundary load -> tile loads -> window) and the
 // drain that the one-super-tile-per-workgroup form pays every 1024 rows.
-template <typename T, int L, int U, bool USE_DPP, int TPW>
+template <typename T, int L, int U, bool USE_DPP, int TPW, int RPT>
 __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
     const uint16_t *__restrict__ col16, const T *__restrict__ vals, const T *__restrict__ x,
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
     const bool nt_store = flags & 1u;
     T *prod_all = reinterpret_cast<T *>(spal_smem);
     T *xw = prod_all + kStreamWaves * kStreamTileNnz;
-    constexpr uint32_t kRows = stream_rows(TPW);
+    constexpr uint32_t kRows = stream_rows(TPW, RPT);
 
     // this workgroup's super-tiles: [s_begin, s_end) inside its XCD's run
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
@@ -484,8 +486,8 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
     // tile boundaries (entry offsets) of this wave's TPW tiles in super-tile s
     auto bounds_lane = [&](uint32_t s) {
         const uint32_t row0 = s * kRows, row1 = min(row0 + kRows, nrows);
-        const uint32_t wrow = row0 + wave * (TPW * kStreamTileRows);
-        return rowptr[min(wrow + min(lane, (uint32_t)TPW) * kStreamTileRows, row1)];
+        const uint32_t wrow = row0 + wave * (TPW * (uint32_t)RPT);
+        return rowptr[min(wrow + min(lane, (uint32_t)TPW) * (uint32_t)RPT, row1)];
     };
 
     StreamTile<T> cur, nxt;
@@ -503,9 +505,9 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
             uint32_t tb[TPW + 1];
 #pragma unroll
             for (int k = 0; k <= TPW; ++k) tb[k] = __builtin_amdgcn_readlane(tbl, k);
-            const uint32_t wrow = row0 + wave * (TPW * kStreamTileRows);
+            const uint32_t wrow = row0 + wave * (TPW * (uint32_t)RPT);
             const bool has0 = wrow < row1;  // wave-uniform
-            if (has0 && !cur_valid) stream_load<T>(cur, rowptr, col16, vals, wrow, row1, tb[0], tb[1], lane);
+            if (has0 && !cur_valid) stream_load<T, RPT>(cur, rowptr, col16, vals, wrow, row1, tb[0], tb[1], lane);
             __syncthreads();  // every wave is done with the previous window
             stage_window<T, kStreamBlock>(xw, x, d.x, d.y);
             __syncthreads();
@@ -514,25 +516,25 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
             if (has0) {
 #pragma unroll
                 for (int k = 0; k < TPW; ++k) {
-                    const uint32_t r0 = wrow + k * kStreamTileRows;
+                    const uint32_t r0 = wrow + k * (uint32_t)RPT;
                     if (r0 >= row1) break;  // wave-uniform
-                    const uint32_t rn = r0 + kStreamTileRows;
+                    const uint32_t rn = r0 + (uint32_t)RPT;
                     const bool more = (k + 1 < TPW) && rn < row1;
                     if (more) {
-                        stream_load<T>(nxt, rowptr, col16, vals, rn, row1, tb[k + 1],
+                        stream_load<T, RPT>(nxt, rowptr, col16, vals, rn, row1, tb[k + 1],
                                        tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
                     } else if (next_stream) {
                         // last tile of this super-tile: start on the next one's first tile
                         const uint32_t nrow0 = (s + 1) * kRows, nrow1 = min(nrow0 + kRows, nrows);
-                        const uint32_t nwrow = nrow0 + wave * (TPW * kStreamTileRows);
+                        const uint32_t nwrow = nrow0 + wave * (TPW * (uint32_t)RPT);
                         if (nwrow < nrow1) {
                             const uint32_t b0 = __builtin_amdgcn_readlane(tbl_next, 0);
                             const uint32_t b1 = __builtin_amdgcn_readlane(tbl_next, 1);
-                            stream_load<T>(nxt, rowptr, col16, vals, nwrow, nrow1, b0, b1, lane);
+                            stream_load<T, RPT>(nxt, rowptr, col16, vals, nwrow, nrow1, b0, b1, lane);
                             fetched_next = true;
                         }
                     }
-                    stream_compute<T>(cur, xw, wmax, prod, y, r0, row1, lane, nt_store);
+                    stream_compute<T, RPT>(cur, xw, wmax, prod, y, r0, row1, lane, nt_store);
                     if (more || fetched_next) cur = nxt;
                 }
             }

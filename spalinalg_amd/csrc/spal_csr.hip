@@ -68,13 +68,14 @@ static constexpr uint32_t kStreamWindowBytes = 48 * 1024;
 // One thread per super-tile: every 64-row tile must fit the product strip.
 __global__ __launch_bounds__(256) void csr_stream_check(const uint32_t *__restrict__ rowptr,
                                                         uint32_t nrows, uint32_t nblocks,
-                                                        uint32_t R, uint32_t *__restrict__ ok) {
+                                                        uint32_t R, uint32_t rpt,
+                                                        uint32_t *__restrict__ ok) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nblocks) return;
     const uint32_t row0 = b * R, row1 = min(row0 + R, nrows);
     uint32_t good = 1;
-    for (uint32_t r0 = row0; r0 < row1; r0 += kStreamTileRows) {
-        const uint32_t rl = min(r0 + (uint32_t)kStreamTileRows, row1);
+    for (uint32_t r0 = row0; r0 < row1; r0 += rpt) {
+        const uint32_t rl = min(r0 + rpt, row1);
         const uint32_t n = rowptr[rl] - (rowptr[r0] & ~1u);
         if (n > (uint32_t)kStreamTileNnz) good = 0;
     }
@@ -149,12 +150,13 @@ static hipError_t launch_vec_unroll(const spal_csr *a, const void *x, void *y, h
 }
 
 // stream kernel; its vector fallback for non-streamable super-tiles uses U = 2
-template <typename T, int L, int TPW>
+template <typename T, int TPW, int RPT>
 static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    constexpr int L = 16;  // lanes per row of the in-kernel vector fallback (any value is correct)
     const CsrPlan &p = a->plan;
     const uint32_t per_xcd = (p.nblocks + 7) / 8;
     const size_t lds = ((size_t)kStreamWaves * kStreamTileNnz + p.lds_entries) * sizeof(T);
-    auto kern = csr_spmv_stream<T, L, 2, true, TPW>;
+    auto kern = csr_spmv_stream<T, L, 2, true, TPW, RPT>;
     static std::atomic<uint64_t> configured{0};
     hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
     if (e != hipSuccess) return e;
@@ -166,15 +168,16 @@ static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, h
 }
 
 // persistent form: 2 workgroups per CU, contiguous chunks of each XCD's run
-template <typename T, int L>
+template <typename T, int RPT>
 static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    constexpr int L = 16;
     const CsrPlan &p = a->plan;
     const uint32_t per_xcd = (p.nblocks + 7) / 8;
     const uint32_t slots = (uint32_t)std::max(1, p.persistent_blocks / 8);   // workgroups per XCD
     const uint32_t chunk = (per_xcd + slots - 1) / slots;
     const uint32_t used = (per_xcd + chunk - 1) / chunk;                      // non-empty slots
     const size_t lds = ((size_t)kStreamWaves * kStreamTileNnz + p.lds_entries) * sizeof(T);
-    auto kern = csr_spmv_stream_persistent<T, L, 2, true, 4>;
+    auto kern = csr_spmv_stream_persistent<T, L, 2, true, 4, RPT>;
     static std::atomic<uint64_t> configured{0};
     hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
     if (e != hipSuccess) return e;
@@ -185,19 +188,24 @@ static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, voi
     return hipGetLastError();
 }
 
-template <typename T, int L>
+template <typename T>
 static hipError_t launch_stream(const spal_csr *a, const void *x, void *y, hipStream_t st) {
-    if (a->plan.persistent && a->plan.tiles_per_wave == 4) return launch_stream_persistent<T, L>(a, x, y, st);
-    return a->plan.tiles_per_wave == 8 ? launch_stream_tpw<T, L, 8>(a, x, y, st)
-                                       : launch_stream_tpw<T, L, 4>(a, x, y, st);
+    const CsrPlan &p = a->plan;
+    if (p.tiles_per_wave == 8) return launch_stream_tpw<T, 8, 64>(a, x, y, st);  // (64-row tiles only)
+    switch (p.rows_per_tile) {
+        case 64: return p.persistent ? launch_stream_persistent<T, 64>(a, x, y, st) : launch_stream_tpw<T, 4, 64>(a, x, y, st);
+        case 32: return p.persistent ? launch_stream_persistent<T, 32>(a, x, y, st) : launch_stream_tpw<T, 4, 32>(a, x, y, st);
+        case 16: return p.persistent ? launch_stream_persistent<T, 16>(a, x, y, st) : launch_stream_tpw<T, 4, 16>(a, x, y, st);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 template <typename T>
 static hipError_t launch_lanes(const spal_csr *a, const void *x, void *y, hipStream_t st) {
-    const bool stream = a->plan.kernel == 2;
+    if (a->plan.kernel == 2) return launch_stream<T>(a, x, y, st);
     switch (a->plan.lanes_per_row) {
 #define SPAL_LANES_CASE(LL) \
-    case LL: return stream ? launch_stream<T, LL>(a, x, y, st) : launch_vec_unroll<T, LL>(a, x, y, st);
+    case LL: return launch_vec_unroll<T, LL>(a, x, y, st);
         SPAL_LANES_CASE(2) SPAL_LANES_CASE(4) SPAL_LANES_CASE(8) SPAL_LANES_CASE(16)
         SPAL_LANES_CASE(32) SPAL_LANES_CASE(64)
 #undef SPAL_LANES_CASE
@@ -242,14 +250,15 @@ static int block_windows(spal_csr *a, uint32_t R, std::vector<uint2> &win) {
 
 // Stream plan: super-tiles of R rows; returns the fraction of rows
 // that can be streamed and fills `desc`.
-static int stream_plan(spal_csr *a, uint32_t R, std::vector<uint4> &desc, uint32_t &cap, double &frac) {
+static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4> &desc, uint32_t &cap,
+                       double &frac) {
     const uint32_t nb = (uint32_t)((a->nrows + R - 1) / R);
     std::vector<uint2> win;
     SPAL_TRY(block_windows(a, R, win));
     uint32_t *d_ok = nullptr;
     SPAL_HIP_TRY(hipMalloc(&d_ok, (size_t)nb * 4));
     hipLaunchKernelGGL(csr_stream_check, dim3((nb + 255) / 256), dim3(256), 0, a->stream, a->d_rowptr,
-                       (uint32_t)a->nrows, nb, R, d_ok);
+                       (uint32_t)a->nrows, nb, R, rpt, d_ok);
     std::vector<uint32_t> ok(nb);
     hipError_t e = hipMemcpyAsync(ok.data(), d_ok, (size_t)nb * 4, hipMemcpyDeviceToHost, a->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
@@ -305,29 +314,44 @@ int csr_plan_build(spal_csr *a) {
     }
     const uint32_t valign = 16u / (uint32_t)a->elem_size;
 
-    // ---- stream kernel: short rows whose windows fit (auto: at least half the rows)
-    if (p.user_kernel == 0 || p.user_kernel == 2) {
-        std::vector<uint4> desc;
-        uint32_t cap = 0;
-        double frac = 0.0;
+    // ---- stream kernel: rows short enough that 64 / 32 / 16 of them fit a tile and
+    // whose windows fit LDS (auto: at least half the rows).  Widest tile first.
+    if ((p.user_kernel == 0 && mean <= 64.0) || p.user_kernel == 2) {
         if (p.tiles_per_wave != 4 && p.tiles_per_wave != 8) p.tiles_per_wave = 4;
-        const uint32_t R = (uint32_t)stream_rows(p.tiles_per_wave);
-        SPAL_TRY(stream_plan(a, R, desc, cap, frac));
-        if (p.user_kernel == 2 || frac >= 0.5) {
+        const int rpt_all[] = {64, 32, 16};
+        std::vector<int> rpts;
+        if (p.user_rows_per_tile) rpts.push_back(p.rows_per_tile);
+        else if (p.tiles_per_wave == 8) rpts.push_back(64);
+        else rpts.assign(rpt_all, rpt_all + 3);
+        std::vector<uint4> desc, best_desc;
+        uint32_t cap = 0, best_cap = 0;
+        double frac = 0.0, best_frac = -1.0;
+        int best_rpt = rpts[0];
+        for (int rpt : rpts) {
+            const uint32_t R = (uint32_t)stream_rows(p.tiles_per_wave, rpt);
+            SPAL_TRY(stream_plan(a, R, (uint32_t)rpt, desc, cap, frac));
+            if (frac > best_frac + 0.05) {  // a narrower tile must buy real coverage
+                best_frac = frac; best_rpt = rpt; best_cap = cap; best_desc.swap(desc);
+            }
+            if (best_frac >= 0.95) break;
+        }
+        if (p.user_kernel == 2 || best_frac >= 0.5) {
+            const uint32_t R = (uint32_t)stream_rows(p.tiles_per_wave, best_rpt);
             p.kernel = 2;
+            p.rows_per_tile = best_rpt;
             p.rows_per_block = (int)R;
             p.threads = kStreamBlock;
-            p.nblocks = (uint32_t)desc.size();
-            p.lds_x = cap > 0;
-            p.lds_entries = (std::max(cap, valign) + valign - 1) & ~(valign - 1);
-            p.stream_row_fraction = frac;
+            p.nblocks = (uint32_t)best_desc.size();
+            p.lds_x = best_cap > 0;
+            p.lds_entries = (std::max(best_cap, valign) + valign - 1) & ~(valign - 1);
+            p.stream_row_fraction = best_frac;
             uint64_t lds_rows = 0;
             for (uint32_t b = 0; b < p.nblocks; ++b)
-                if (desc[b].z != kModeVectorGlobal)
+                if (best_desc[b].z != kModeVectorGlobal)
                     lds_rows += std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
             p.lds_row_fraction = (double)lds_rows / (double)a->nrows;
             SPAL_HIP_TRY(hipMalloc(&a->d_desc, (size_t)p.nblocks * sizeof(uint4)));
-            SPAL_HIP_TRY(hipMemcpyAsync(a->d_desc, desc.data(), (size_t)p.nblocks * sizeof(uint4),
+            SPAL_HIP_TRY(hipMemcpyAsync(a->d_desc, best_desc.data(), (size_t)p.nblocks * sizeof(uint4),
                                         hipMemcpyHostToDevice, a->stream));
             if (!a->d_col16) {
                 SPAL_HIP_TRY(hipMalloc(&a->d_col16, (size_t)a->cap_entries * sizeof(uint16_t)));
@@ -707,6 +731,7 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         p.user_kernel = (int)value;
         if (value == 0) {
             p.user_rows_per_block = p.user_lanes = p.user_lds = p.user_unroll = p.user_threads = false;
+            p.user_rows_per_tile = false;
         }
     } else if (!strcmp(key, "rows_per_block")) {
         if (value == 0) p.user_rows_per_block = false;
@@ -737,6 +762,11 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         if (value < 8 || value > 4096 || (value % 8))
             return fail(SPAL_ERR_INVALID_ARGUMENT, "persistent_blocks must be a multiple of 8 in [8, 4096]");
         p.persistent_blocks = (int)value;
+    } else if (!strcmp(key, "rows_per_tile")) {
+        if (value == 0) p.user_rows_per_tile = false;
+        else if (value != 64 && value != 32 && value != 16)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "rows_per_tile must be 0 (auto), 64, 32 or 16");
+        else { p.rows_per_tile = (int)value; p.user_rows_per_tile = true; }
     } else if (!strcmp(key, "tiles_per_wave")) {
         if (value != 4 && value != 8) return fail(SPAL_ERR_INVALID_ARGUMENT, "tiles_per_wave must be 4 or 8");
         p.tiles_per_wave = (int)value;
@@ -766,13 +796,13 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
     snprintf(buf, buf_len,
              "{\"format\": \"csr\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"nnz\": %llu, "
              "\"index_bits\": %d, \"kernel\": \"%s\", \"lanes_per_row\": %d, \"unroll\": %d, "
-             "\"rows_per_block\": %d, \"blocks\": %u, \"threads_per_block\": %d, \"lds_x\": %d, "
+             "\"rows_per_block\": %d, \"rows_per_tile\": %d, \"blocks\": %u, \"threads_per_block\": %d, \"lds_x\": %d, "
              "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f, "
              "\"persistent\": %d, \"nt_store\": %d, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f]}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, p.kernel == 2 ? 16 : 32,
              p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
-             p.rows_per_block, p.nblocks, p.threads, p.lds_x,
+             p.rows_per_block, p.kernel == 2 ? p.rows_per_tile : 0, p.nblocks, p.threads, p.lds_x,
              (unsigned long long)p.lds_entries * (unsigned long long)a->elem_size, p.lds_row_fraction,
              p.stream_row_fraction, (p.kernel == 2 && p.persistent && p.tiles_per_wave == 4) ? 1 : 0,
              (p.kernel == 2 && p.nt_store) ? 1 : 0, (double)a->tuned_us[0], (double)a->tuned_us[1],

@@ -72,7 +72,8 @@ struct CsrPlan {
     int lanes_per_row = 0;   // L in {2,4,8,16,32,64}
     int unroll = 1;          // row groups in flight per wave iteration
     int threads = 512;       // workgroup size: 512 or 1024
-    int tiles_per_wave = 4;  // stream kernel: 64-row tiles per wave (4 or 8)
+    int tiles_per_wave = 4;  // stream kernel: tiles per wave (4 or 8)
+    int rows_per_tile = 64;  // stream kernel: rows of a wave-tile (64, 32 or 16)
     int persistent = 0;      // stream kernel: fixed grid walking chunks of super-tiles
     int nt_store = 0;        // stream kernel: non-temporal stores of y
     int persistent_blocks = 512;  // its grid (2 workgroups per CU on 256 CUs)
@@ -83,7 +84,7 @@ struct CsrPlan {
     double lds_row_fraction = 0.0;  // rows whose block window fits
     double stream_row_fraction = 0.0;  // rows handled by the stream path (kernel 2)
     bool user_rows_per_block = false, user_lanes = false, user_lds = false,
-         user_unroll = false, user_threads = false;
+         user_unroll = false, user_threads = false, user_rows_per_tile = false;
 };
 
 // implemented in spal_coo.hip: stable sort of the entries by their minor index

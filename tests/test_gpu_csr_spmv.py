@@ -99,6 +99,51 @@ def test_stream_kernel_is_bit_identical_to_the_reference_order(oracle):
             assert np.array_equal(dev.spmv(x), y_ref)
 
 
+@pytest.mark.parametrize("maxlen,rpt", [(25, 64), (41, 32), (90, 16)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_stream_kernel_narrow_tiles_bit_identical(oracle, maxlen, rpt, dtype):
+    """rows of up to ~64 entries stream too, in tiles of 32 or 16 rows; still
+    bit-identical to the sequential reference order, in every kernel form."""
+    rng = np.random.default_rng(maxlen)
+    nr, nc = 50_003, 4000
+    rp, ci, va = random_csr(rng, nr, nc, row_len=lambda r: r.integers(0, maxlen), dtype=dtype, empty_rows=0.02)
+    x = rng.uniform(-1, 1, nc).astype(dtype)
+    dev = sp.CsrMatrix(nr, nc, rp, ci, va).device()
+    d = dev.describe()
+    assert d["kernel"] == "stream" and d["rows_per_tile"] == rpt and d["stream_row_fraction"] > 0.95, d
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    tol = 1e-10 if dtype == np.float64 else 1e-4
+
+    def same(y, frac):
+        # rows of streamable super-tiles are bit-identical; the few super-tiles that fell
+        # back to the vector path (a tile over 1024 entries) agree to rounding
+        np.testing.assert_allclose(y, y_ref, rtol=tol, atol=tol)
+        assert int((y != y_ref).sum()) <= int(round((1.0 - frac) * nr))
+        if frac == 1.0:
+            assert np.array_equal(y, y_ref)
+
+    same(dev.spmv(x), d["stream_row_fraction"])
+    for persistent, nt in ((1, 0), (1, 1), (0, 1)):
+        dev.set_option("persistent", persistent)
+        dev.set_option("nt_store", nt)
+        same(dev.spmv(x), d["stream_row_fraction"])
+    # forcing a narrower tile than needed is still exact
+    if rpt > 16:
+        dev.set_option("rows_per_tile", rpt // 2)
+        d2 = dev.describe()
+        assert d2["rows_per_tile"] == rpt // 2
+        same(dev.spmv(x), d2["stream_row_fraction"])
+
+
+def test_long_rows_go_to_the_vector_kernel(oracle):
+    rng = np.random.default_rng(140)
+    nr, nc = 20_000, 5000
+    rp, ci, va = random_csr(rng, nr, nc, row_len=lambda r: r.integers(40, 140), empty_rows=0.0)
+    x = rng.uniform(-1, 1, nc)
+    dev = check(oracle, rp, ci, va, x, nc)
+    assert dev.describe()["kernel"] == "vector"
+
+
 def test_stream_kernel_mixed_supertiles(oracle):
     """a few heavy rows make single super-tiles fall back to the vector path
     inside the same launch; one wide row forces the global-gather mode."""
