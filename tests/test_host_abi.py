@@ -156,3 +156,29 @@ def test_partition_rows_balances_entries():
     lib.spal_partition_rows(rp.ctypes.data_as(_ffi.u64p), C.c_uint64(10), C.c_uint32(4),
                             b.ctypes.data_as(_ffi.u64p))
     assert b.tolist() == [0, 2, 5, 7, 10]
+
+
+def test_shapes_beyond_32_bit_indices_are_refused():
+    """device indices are 32-bit: larger shapes fail loudly with
+    SPAL_ERR_UNSUPPORTED before any device is touched."""
+    a = sp.CsrMatrix(1, 2 ** 33, [0, 1], [2 ** 33 - 1], np.array([1.0]))
+    with pytest.raises(sp.SpalError) as e:
+        a.device()
+    assert e.value.status == _ffi.SPAL_ERR_UNSUPPORTED
+    c = sp.CscMatrix(2 ** 33, 1, [0, 1], [2 ** 33 - 1], np.array([1.0]))
+    with pytest.raises(sp.SpalError) as e:
+        c.device()
+    assert e.value.status == _ffi.SPAL_ERR_UNSUPPORTED
+    coo = sp.CooMatrix.with_triplets(2 ** 33, 2, [2 ** 33 - 1], [1], np.array([1.0]))
+    with pytest.raises(sp.SpalError) as e:
+        coo.upload()
+    assert e.value.status == _ffi.SPAL_ERR_UNSUPPORTED
+
+
+def test_option_validation():
+    """unknown keys / values the kernels are not instantiated for are rejected
+    (checked before any device work for a handle-less call)."""
+    lib = _ffi.lib()
+    assert lib.spal_csr_set_option(None, b"kernel", C.c_int64(1)) == _ffi.SPAL_ERR_INVALID_ARGUMENT
+    assert lib.spal_csc_set_option(None, b"kernel", C.c_int64(1)) == _ffi.SPAL_ERR_INVALID_ARGUMENT
+    assert lib.spal_csr_destroy(None) == 0 and lib.spal_csc_destroy(None) == 0 and lib.spal_coo_destroy(None) == 0

@@ -17,13 +17,15 @@ import spalinalg_amd as sp  # noqa: E402
 
 
 def main():
-    variants = [a for a in sys.argv[1:] if "=" in a]
+    variants = [a for a in sys.argv[1:] if "=" in a and not a.startswith("@")]
     flags = [a for a in sys.argv[1:] if "=" not in a]
-    n = 10_000_000
-    window = None if "uniform" in flags else 4096
+    shape = dict(kv[1:].split("=") for kv in sys.argv[1:] if kv.startswith("@"))   # @per_row=27 @window=8192 @rows=5000000
+    n = int(shape.get("rows", 10_000_000))
+    per_row = int(shape.get("per_row", 14))
+    window = None if "uniform" in flags else int(shape.get("window", 4096))
     dtype = np.float32 if "f32" in flags else np.float64
     rounds, iters = 7, 25
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, window or n, sp.synth.matrix_seed(3), dtype=dtype)
+    rp, ci, va = sp.synth.banded_csr(n, n, per_row, window or n, sp.synth.matrix_seed(3), dtype=dtype)
     devs = []
     for v in variants:  # one handle per variant: no re-planning inside the timed rounds
         d = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
@@ -34,7 +36,7 @@ def main():
     x = torch.from_numpy(sp.synth.vector(n, dtype=dtype)).cuda()
     y = torch.empty_like(x)
     yref = devs[0].spmv_torch(x).clone()
-    B = sp.synth.spmv_bytes(n * 14, n, n, n, np.dtype(dtype).itemsize)
+    B = sp.synth.spmv_bytes(n * per_row, n, n, n, np.dtype(dtype).itemsize)
     times = [[] for _ in variants]
     for r in range(rounds):
         for i, d in enumerate(devs):
@@ -50,8 +52,10 @@ def main():
             times[i].append(e0.elapsed_time(e1) / iters * 1e3)
     for v, t, d in zip(variants, times, devs):
         ok = bool(torch.equal(d.spmv_torch(x), yref))
+        pl = d.describe()
+        v = f"{v} [{pl['kernel']} rpt={pl.get('rows_per_tile')} stream={pl['stream_row_fraction']}]"
         med, mn = statistics.median(t), min(t)
-        print(f"{v:48s} median {med:7.1f} us  min {mn:7.1f} us  {B/med/1e3:7.1f} GB/s ({100*B/med/1e3/8000:5.2f} %)  "
+        print(f"{v:72s} median {med:7.1f} us  min {mn:7.1f} us  {B/med/1e3:7.1f} GB/s ({100*B/med/1e3/8000:5.2f} %)  "
               f"bit-equal-to-first={ok}  rounds={[round(q) for q in t]}", flush=True)
 
 
