@@ -45,6 +45,8 @@ typedef enum spal_status {
 typedef struct spal_csr *spal_csr_t; /* mirrors CsrMatrix<T>, src/csr.rs:66-72 */
 typedef struct spal_csc *spal_csc_t; /* mirrors CscMatrix<T>, src/csc.rs:66-72 */
 typedef struct spal_coo *spal_coo_t; /* mirrors CooMatrix<T>, src/coo.rs:53-57 (SoA on device) */
+typedef struct spal_mg *spal_mg_t;          /* the GPUs of one node + their RCCL communicators */
+typedef struct spal_mg_csr *spal_mg_csr_t;  /* a CsrMatrix partitioned by rows over them */
 
 /* ---- library ---------------------------------------------------------- */
 const char *spal_last_error(void);   /* thread-local, never NULL */
@@ -210,6 +212,44 @@ int spal_coo_to_csc_f64(int device, uint64_t nrows, uint64_t ncols, uint64_t len
 int spal_coo_to_csc_f32(int device, uint64_t nrows, uint64_t ncols, uint64_t len,
                         const uint64_t *rows, const uint64_t *cols,
                         const float *vals, spal_csc_t *out);
+
+/* ---- row-partitioned y = A * x over the GPUs of one node, from one process ---
+ * (SURVEY.md section 8e).  Rows are cut into contiguous ranges with balanced
+ * stored entries; every GPU holds its range and a full x.  Exchange steps:
+ * ncclBroadcast of x from GPU 0, local kernels, ncclAllGather of the y slices
+ * (RCCL over xGMI, loaded lazily; ngpus == 1 needs no RCCL).  The product of a
+ * range is the same kernel as the single-GPU path, so results are identical.
+ * devices == NULL means GPUs 0 .. ngpus-1. */
+int spal_mg_create(int ngpus, const int *devices, spal_mg_t *out);
+int spal_mg_destroy(spal_mg_t ctx);
+int spal_mg_device_count(spal_mg_t ctx, int *ngpus);
+int spal_mg_csr_create_f64(spal_mg_t ctx, uint64_t nrows, uint64_t ncols,
+                           const uint64_t *rowptr, uint64_t rowptr_len,
+                           const uint64_t *colind, uint64_t colind_len,
+                           const double *values, uint64_t values_len,
+                           spal_mg_csr_t *out);
+int spal_mg_csr_create_f32(spal_mg_t ctx, uint64_t nrows, uint64_t ncols,
+                           const uint64_t *rowptr, uint64_t rowptr_len,
+                           const uint64_t *colind, uint64_t colind_len,
+                           const float *values, uint64_t values_len,
+                           spal_mg_csr_t *out);
+int spal_mg_csr_destroy(spal_mg_csr_t a);
+/* the row boundaries in use: ngpus + 1 entries */
+int spal_mg_csr_partition(spal_mg_csr_t a, uint64_t *bounds);
+/* host vectors: H2D x to GPU 0, broadcast, multiply, all-gather, D2H y */
+int spal_mg_csr_spmv_f64(spal_mg_csr_t a, const double *x, uint64_t x_len,
+                         double *y, uint64_t y_len);
+int spal_mg_csr_spmv_f32(spal_mg_csr_t a, const float *x, uint64_t x_len,
+                         float *y, uint64_t y_len);
+/* resident (timed) path: write x into GPU 0's buffer (x_root), broadcast it
+ * once, then any number of spmv_resident (kernels + all-gather, asynchronous
+ * on the context's streams); synchronize; GPU 0's gathered y is at y_root as
+ * ngpus slices of slice_stride elements (slice g holds rows bounds[g] ..). */
+int spal_mg_csr_x_root(spal_mg_csr_t a, void **x_dev);
+int spal_mg_csr_broadcast_x(spal_mg_csr_t a);
+int spal_mg_csr_spmv_resident(spal_mg_csr_t a);
+int spal_mg_csr_y_root(spal_mg_csr_t a, void **y_dev, uint64_t *slice_stride);
+int spal_mg_csr_synchronize(spal_mg_csr_t a);
 
 /* ---- device memory helpers for callers without a HIP binding of their own
  * (the Rust shim, ctypes tests, the C++ tools). ---------------------------- */

@@ -208,6 +208,53 @@ class DeviceCoo:
             pass
 
 
+class MultiGpuCsr:
+    """A CsrMatrix partitioned by rows over `ngpus` GPUs of this node, driven
+    from this one process (C ABI spal_mg_*: RCCL broadcast of x, local kernels,
+    all-gather of y)."""
+
+    def __init__(self, csr: "CsrMatrix", ngpus: int, devices=None):
+        self.dtype = csr.dtype
+        self._ctx, self._h = vp(), vp()
+        dev = (C.c_int * ngpus)(*devices) if devices is not None else None
+        check(_ffi.lib().spal_mg_create(C.c_int(ngpus), dev, C.byref(self._ctx)))
+        try:
+            check(getattr(_ffi.lib(), f"spal_mg_csr_create_{_sfx(self.dtype)}")(
+                self._ctx, u64(csr.nrows()), u64(csr.ncols()), _p(csr.rowptr()), u64(csr.rowptr().size),
+                _p(csr.colind()), u64(csr.colind().size), _p(csr.values()), u64(csr.values().size),
+                C.byref(self._h)))
+        except Exception:
+            _ffi.lib().spal_mg_destroy(self._ctx)
+            self._ctx = None
+            raise
+        self.nrows, self.ncols, self.ngpus = csr.nrows(), csr.ncols(), ngpus
+
+    def partition(self) -> np.ndarray:
+        b = np.empty(self.ngpus + 1, dtype=np.uint64)
+        check(_ffi.lib().spal_mg_csr_partition(self._h, _p(b)))
+        return b
+
+    def spmv(self, x) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        y = np.empty(self.nrows, dtype=self.dtype)
+        check(getattr(_ffi.lib(), f"spal_mg_csr_spmv_{_sfx(self.dtype)}")(self._h, _p(x), u64(x.size), _p(y), u64(y.size)))
+        return y
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _ffi.lib().spal_mg_csr_destroy(self._h)
+            self._h = None
+        if getattr(self, "_ctx", None):
+            _ffi.lib().spal_mg_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # --------------------------------------------------------------------------
 # CsrMatrix / CscMatrix
 # --------------------------------------------------------------------------

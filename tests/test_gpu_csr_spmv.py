@@ -308,3 +308,23 @@ def test_full_size_config3_properties():
     for r in (0, 1, 4_999_999, 9_999_999):
         lo, hi = int(rp[r]), int(rp[r + 1])
         assert abs(float(ax[r]) - float(np.dot(va[lo:hi], xs[ci[lo:hi].astype(np.int64)]))) < 1e-13
+
+
+def test_single_process_multi_gpu_context(oracle):
+    """the spal_mg_* exports (one process driving the node's GPUs): on a 1-GPU
+    box only ngpus = 1 can run, which still exercises partition, shard upload,
+    the resident buffers and the gather layout; more GPUs than visible is refused."""
+    n = 150_000
+    rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, 17)
+    x = sp.synth.vector(n)
+    a = sp.CsrMatrix(n, n, rp, ci, va)
+    mg = sp.MultiGpuCsr(a, 1)
+    assert mg.partition().tolist() == [0, n]
+    y = mg.spmv(x)
+    assert np.array_equal(y, oracle.csr_spmv(rp, ci, va, x))       # same kernel, same bits
+    with pytest.raises(sp.Panic):
+        mg.spmv(x[:-1])
+    mg.close()
+    if sp.device_count() == 1:
+        with pytest.raises(sp.Panic):
+            sp.MultiGpuCsr(a, 2)
