@@ -233,7 +233,12 @@ int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream) 
 }
 
 // per-row-block column windows for block size R -> host vector {cmin, cmax + 1}
-static int block_windows(spal_csr *a, uint32_t R, std::vector<uint2> &win) {
+// ({0xffffffff, 0} for a block without entries).  The device pass runs once per
+// matrix at 256-row granularity; every candidate R that is a multiple of 256 is
+// derived from it on the host.
+static constexpr uint32_t kWinBase = 256;
+
+static int block_windows_device(spal_csr *a, uint32_t R, std::vector<uint2> &win) {
     const uint32_t nb = (uint32_t)((a->nrows + R - 1) / R);
     uint2 *d_win = nullptr;
     SPAL_HIP_TRY(hipMalloc(&d_win, (size_t)nb * sizeof(uint2)));
@@ -245,6 +250,24 @@ static int block_windows(spal_csr *a, uint32_t R, std::vector<uint2> &win) {
     if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
     (void)hipFree(d_win);
     SPAL_HIP_TRY(e);
+    return SPAL_OK;
+}
+
+static int block_windows(spal_csr *a, uint32_t R, std::vector<uint2> &win) {
+    if (R % kWinBase) return block_windows_device(a, R, win);
+    if (a->win_base.empty()) SPAL_TRY(block_windows_device(a, kWinBase, a->win_base));
+    const uint32_t k = R / kWinBase;
+    const uint32_t nb = (uint32_t)((a->nrows + R - 1) / R);
+    win.resize(nb);
+    for (uint32_t b = 0; b < nb; ++b) {
+        uint2 w = make_uint2(0xffffffffu, 0u);
+        const size_t j1 = std::min<size_t>((size_t)(b + 1) * k, a->win_base.size());
+        for (size_t j = (size_t)b * k; j < j1; ++j) {
+            w.x = std::min(w.x, a->win_base[j].x);
+            w.y = std::max(w.y, a->win_base[j].y);
+        }
+        win[b] = w;
+    }
     return SPAL_OK;
 }
 

@@ -113,6 +113,7 @@ struct spal_csr {
     // autotune: microseconds per launch of {plain, persistent} x {plain, non-temporal y stores}
     float tuned_us[4] = {0.f, 0.f, 0.f, 0.f};
     spal::CsrPlan plan;
+    std::vector<uint2> win_base;   // host copy of the per-256-row column windows (planner cache)
     // host-convenience staging (spal_csr_spmv_*): guarded by mu
     std::mutex mu;
     void *d_x = nullptr, *d_y = nullptr;

@@ -129,12 +129,20 @@ def test_no_cpu_fallback():
 
 def test_product_does_not_import_the_oracle():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for dirpath, _, files in os.walk(os.path.join(root, "spalinalg_amd")):
-        for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
-                text = open(os.path.join(dirpath, f)).read()
-                assert "import oracle" not in text and "from oracle" not in text, f
-                assert "liboracle" not in text and "spal_oracle" not in text, f
+    for top in ("spalinalg_amd", "include", "tools", "rust_shim"):
+        for dirpath, _, files in os.walk(os.path.join(root, top)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", ".rs", ".sh")):
+                    text = open(os.path.join(dirpath, f)).read()
+                    assert "import oracle" not in text and "from oracle" not in text, f
+                    assert "liboracle" not in text and "spal_oracle" not in text, f
+    # bench.py may touch the oracle only inside its cpu_baseline legs
+    bench = open(os.path.join(root, "bench.py")).read().split("\n")
+    for i, line in enumerate(bench):
+        if "import oracle" in line:
+            assert "CPU baseline leg only" in line, (i, line)
+            window = "\n".join(bench[max(0, i - 4):i + 1])
+            assert "no_cpu_baseline" in window, (i, "oracle import outside a cpu_baseline leg")
 
 
 def test_partition_rows_balances_entries():

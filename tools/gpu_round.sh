@@ -25,6 +25,10 @@ for s in "$@"; do
     other)  step 900 lab_other.log python tools/lab_other.py $OTHER_ARGS ;;
     profother) export TMPDIR=/tmp
             step 600 prof_other.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_other -o other -- python3 tools/lab_other.py $OTHER_ARGS ;;
+    prof45) export TMPDIR=/tmp
+            step 400 prof4.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof4 -o c4 -- python3 bench.py --config 4 --steps 100 --warmup 10 --no-cpu-baseline
+            step 600 prof5.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof5 -o c5 -- python3 bench.py --config 5 --steps 10 --warmup 2 --no-cpu-baseline
+            ;;
     pmc)    export TMPDIR=/tmp
             step 400 pmc1.log rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d gpurun_out/pmc1 -o p -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline
             step 400 pmc2.log rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU --output-format csv -d gpurun_out/pmc2 -o p -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline

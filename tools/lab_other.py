@@ -50,14 +50,17 @@ def main():
         csr_case("cfg3 banded f64 vector kernel", 10_000_000, 4096, np.float64, opts=[("kernel", 1)])
         csr_case("cfg2 banded f64 (fits MALL)", 1_000_000, 4096, np.float64, iters=100)
     if "csc" in which:
-        import oracle  # lab only: builds the CSC input by the oracle's counting sort
+        import scipy.sparse as sps
         n = 1_000_000
         rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, sp.synth.matrix_seed(2))
-        cp, ri, cv = oracle.transpose(n, n, rp, ci, va)
+        csc = sps.csr_matrix((va, ci.astype(np.int64), rp.astype(np.int64)), shape=(n, n)).tocsc()
+        csc.sort_indices()
+        cp, ri, cv = csc.indptr.astype(np.uint64), csc.indices.astype(np.uint64), csc.data
         dev = sp.CscMatrix._trusted(n, n, cp, ri, cv).device()
         x = torch.from_numpy(sp.synth.vector(n)).cuda()
         y = torch.empty_like(x)
         B = sp.synth.spmv_bytes(n * 14, n, n, n, 8)
+        dev.set_option("kernel", 1)
         for lds in (1, 0):
             dev.set_option("lds", lds)
             t = timeit(lambda: dev.spmv_torch(x, out=y), 50)
