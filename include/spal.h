@@ -166,6 +166,11 @@ int spal_csc_download_f32(spal_csc_t a, uint64_t *colptr, uint64_t *rowind,
  * (deterministic; bit-identical to the reference's k-ascending order), 0 = auto
  * (= 2).  "lds" 0/1, "lanes_per_col" tune kernel 1. */
 int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value);
+/* as spal_csr_autotune_* for the transposed route (kernel 2); no-op for kernel 1 */
+int spal_csc_autotune_f64(spal_csc_t a, const double *x_dev, double *y_dev,
+                          void *stream, int iters);
+int spal_csc_autotune_f32(spal_csc_t a, const float *x_dev, float *y_dev,
+                          void *stream, int iters);
 int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len);
 
 /* ---- CSR <-> CSC on the device ------------------------------------------------

@@ -276,7 +276,11 @@ int csc_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, 
     hipError_t e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
     if (e != hipSuccess) return bail(fail(SPAL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)));
     int st = csc_plan_build(a);
-    if (st != SPAL_OK) return bail(st);
+    if (st == SPAL_OK && a->kernel == 2) st = csc_ensure_csr(a);  // setup work, not the first product's
+    if (st != SPAL_OK) {
+        if (a->as_csr) { (void)spal_csr_destroy(a->as_csr); a->as_csr = nullptr; }
+        return bail(st);
+    }
     *out = a;
     return SPAL_OK;
 }
@@ -339,6 +343,7 @@ static int csc_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t
                     "spal_csc_create: upload failed: %s", hipGetErrorString(e));
     }
     int st = csc_plan_build(a);
+    if (st == SPAL_OK && a->kernel == 2) st = csc_ensure_csr(a);  // setup work, not the first product's
     if (st != SPAL_OK) { csc_free(a); return st; }
     *out = a;
     return SPAL_OK;
@@ -482,6 +487,23 @@ int spal_csc_download_f64(spal_csc_t a, uint64_t *colptr, uint64_t *rowind, doub
 }
 int spal_csc_download_f32(spal_csc_t a, uint64_t *colptr, uint64_t *rowind, float *values) {
     return csc_download<float>(a, colptr, rowind, values);
+}
+
+int spal_csc_autotune_f64(spal_csc_t a, const double *x_dev, double *y_dev, void *stream, int iters) {
+    if (!a) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csc_autotune: handle is NULL");
+    if (a->kernel != 2) return SPAL_OK;  // the scatter kernel has a single form
+    DeviceGuard guard(a->device);
+    if (guard.status != SPAL_OK) return guard.status;
+    SPAL_TRY(csc_ensure_csr(a));
+    return spal_csr_autotune_f64(a->as_csr, x_dev, y_dev, stream, iters);
+}
+int spal_csc_autotune_f32(spal_csc_t a, const float *x_dev, float *y_dev, void *stream, int iters) {
+    if (!a) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csc_autotune: handle is NULL");
+    if (a->kernel != 2) return SPAL_OK;
+    DeviceGuard guard(a->device);
+    if (guard.status != SPAL_OK) return guard.status;
+    SPAL_TRY(csc_ensure_csr(a));
+    return spal_csr_autotune_f32(a->as_csr, x_dev, y_dev, stream, iters);
 }
 
 int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value) {

@@ -113,6 +113,15 @@ class _DeviceMatrix:
         """Device pointers; enqueued on `stream`, not synchronised."""
         check(self._fn(f"spmv_dev_{_sfx(self.dtype)}")(self._h, vp(x_ptr), vp(y_ptr), _stream_ptr(stream)))
 
+    def autotune(self, x, y, iters: int = 30) -> dict:
+        """Times the plan's kernel variants on torch device vectors x, y and keeps
+        the fastest (setup-time; synchronises the current stream)."""
+        import torch
+        st = torch.cuda.current_stream(x.device)
+        check(self._fn(f"autotune_{_sfx(self.dtype)}")(self._h, vp(x.data_ptr()), vp(y.data_ptr()),
+                                                       _stream_ptr(st), C.c_int(iters)))
+        return self.describe()
+
     def spmv_torch(self, x, out=None):
         """x, out: torch tensors on this handle's device; runs on torch's
         current stream (so torch.cuda.Event brackets it)."""
@@ -141,15 +150,6 @@ class DeviceCsr(_DeviceMatrix):
         va = np.empty(nnz, dtype=self.dtype)
         check(self._fn(f"download_{_sfx(self.dtype)}")(self._h, _p(rp), _p(ci), _p(va)))
         return rp, ci, va
-
-    def autotune(self, x, y, iters: int = 30) -> dict:
-        """Times the plan's kernel variants on torch device vectors x, y and keeps
-        the fastest (setup-time; synchronises the current stream)."""
-        import torch
-        st = torch.cuda.current_stream(x.device)
-        check(self._fn(f"autotune_{_sfx(self.dtype)}")(self._h, vp(x.data_ptr()), vp(y.data_ptr()),
-                                                       _stream_ptr(st), C.c_int(iters)))
-        return self.describe()
 
     def to_csc(self) -> "DeviceCsc":
         """device CSR -> CSC (stable sort by column; src/csc/conv/csr.rs:4-52)"""
