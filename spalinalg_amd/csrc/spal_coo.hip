@@ -22,8 +22,8 @@
 //      in order, drops zeros, compacts its row in place, counts what is left.
 //   4. scan of the per-row counts = rowptr; the tiles are compacted into the
 //      final colind / values.
-// If some 64-row tile holds more than 1024 entries (a very long row) the local
-// sort does not fit LDS: the assembly then runs the general route -- LSD passes
+// If some 64-row tile holds more than 1024 entries, or some row more than 128
+// (the local sort is quadratic in the row length), the assembly runs the general route -- LSD passes
 // over the column bits first, then the row bits -- and a lane-sequential run
 // summation, which is correct for any input, only slower.
 #include "spal_internal.hpp"
@@ -349,28 +349,68 @@ __global__ __launch_bounds__(256) void rows_lower_bound(const uint32_t *__restri
 
 constexpr int kTileRows = 64;
 constexpr int kTileCap = 1024;  // entries a 64-row tile may hold for the LDS local sort
+constexpr int kRowCap = 128;    // longest row the quadratic local sort takes
 
-// flag[0] = 1 if some 64-row tile holds more than kTileCap entries
+// flag[0] = 1 if some 64-row tile holds more than kTileCap entries or some row more than kRowCap
 __global__ __launch_bounds__(256) void tiles_check(const uint32_t *__restrict__ start, uint32_t nrows,
                                                    uint32_t *__restrict__ flag) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t r0 = t * kTileRows;
     if (r0 >= nrows) return;
     const uint32_t r1 = (uint32_t)min<uint64_t>(r0 + kTileRows, nrows);
-    if (start[r1] - start[r0] > (uint32_t)kTileCap) atomicOr(flag, 1u);
+    bool bad = start[r1] - start[r0] > (uint32_t)kTileCap;
+    for (uint32_t r = (uint32_t)r0; r < r1 && !bad; ++r) bad = start[r + 1] - start[r] > (uint32_t)kRowCap;
+    if (bad) atomicOr(flag, 1u);
 }
 
-// One wave per 64-row tile.  The tile's (col, val) are staged in LDS; lane l
-// owns row (first + l): stable insertion sort by column, runs of equal columns
-// summed left to right (coo.rs:42-46), zero sums dropped (coo.rs:64), survivors
-// packed at the front of the row's segment; kept[row] = how many.  The tile is
-// written back in place.
+// A wave copies the n <= kTileCap (col, val) pairs starting at entry e0 into its
+// LDS strips.  All of a lane's loads are issued before the first LDS write: one
+// memory round trip per tile instead of one per 64 entries.
+template <typename T>
+__device__ __forceinline__ void tile_load(uint32_t *c, T *v, const uint32_t *__restrict__ cols,
+                                          const T *__restrict__ vals, uint32_t e0, uint32_t n,
+                                          uint32_t lane) {
+    constexpr int K = kTileCap / 64;  // 16
+    uint32_t rc[K];
+    T rv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t i = lane + 64u * k;
+        const uint32_t ic = min(i, n - 1);  // n >= 1 here; clamped lanes re-read the last entry
+        rc[k] = cols[e0 + ic];
+        rv[k] = vals[e0 + ic];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t i = lane + 64u * k;
+        if (i < n) {
+            c[i] = rc[k];
+            v[i] = rv[k];
+        }
+    }
+}
+
+// One wave per 64-row tile; the tile's (col, val) are staged in LDS.
+//   1. ranking, entry-parallel: lane l takes entries l, l+64, ... of the tile and
+//      computes each one's stable rank inside its row -- the number of entries j
+//      of that row with col_j < col_i, or col_j == col_i and j < i.  The work
+//      (sum of n_r^2) is spread evenly over the 64 lanes and the LDS reads of
+//      the inner loop are independent (unrolled, pipelined); the inverse
+//      permutation is scattered to a small LDS array.
+//   2. consuming, row-parallel: lane l walks row (first + l) in sorted order:
+//      runs of equal columns are summed left to right = insertion order
+//      (coo.rs:42-46), zero sums dropped (coo.rs:64), survivors written to the
+//      front of the row's segment in global memory (in place: the whole tile
+//      already sits in LDS); kept[row] = how many.
 template <typename T>
 __global__ __launch_bounds__(256) void coo_tile_sort(const uint32_t *__restrict__ start,
+                                                     const uint32_t *__restrict__ sorted_row,
                                                      uint32_t *__restrict__ cols, T *__restrict__ vals,
                                                      uint32_t nrows, uint32_t *__restrict__ kept) {
     __shared__ uint32_t s_col[4][kTileCap];
     __shared__ T s_val[4][kTileCap];
+    __shared__ uint16_t s_inv[4][kTileCap];
+    __shared__ uint32_t s_rs[4][kTileRows + 1];
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t tile = (uint64_t)blockIdx.x * 4 + w;
     const uint64_t r0 = tile * kTileRows;
@@ -380,51 +420,72 @@ __global__ __launch_bounds__(256) void coo_tile_sort(const uint32_t *__restrict_
     const uint32_t n = e1 - e0;  // <= kTileCap (checked by tiles_check)
     uint32_t *c = s_col[w];
     T *v = s_val[w];
-    for (uint32_t i = lane; i < n; i += 64) {
-        c[i] = cols[e0 + i];
-        v[i] = vals[e0 + i];
+    uint16_t *inv = s_inv[w];
+    uint32_t *rs = s_rs[w];
+    if (n) tile_load<T>(c, v, cols, vals, e0, n, lane);
+    rs[lane] = start[min((uint32_t)r0 + lane, r1)] - e0;
+    if (lane == 0) rs[kTileRows] = start[r1] - e0;
+    __builtin_amdgcn_wave_barrier();
+    // 1. ranks (the row of every entry: one batch of loads)
+    uint32_t rowid[kTileCap / 64];
+#pragma unroll
+    for (int k = 0; k < kTileCap / 64; ++k) {
+        const uint32_t i = lane + 64u * k;
+        rowid[k] = (i < n) ? sorted_row[e0 + i] : (uint32_t)r0;
+    }
+#pragma unroll
+    for (int k = 0; k < kTileCap / 64; ++k) {
+        const uint32_t i = lane + 64u * k;
+        if (i >= n) break;
+        const uint32_t lr = rowid[k] - (uint32_t)r0;
+        const uint32_t a = rs[lr], b = rs[lr + 1];
+        const uint32_t ci = c[i];
+        uint32_t rank = 0, j = a;
+        for (; j + 4 <= b; j += 4) {
+            const uint32_t c0 = c[j], c1 = c[j + 1], c2 = c[j + 2], c3 = c[j + 3];
+            rank += (uint32_t)((c0 < ci) | ((c0 == ci) & (j < i)));
+            rank += (uint32_t)((c1 < ci) | ((c1 == ci) & (j + 1 < i)));
+            rank += (uint32_t)((c2 < ci) | ((c2 == ci) & (j + 2 < i)));
+            rank += (uint32_t)((c3 < ci) | ((c3 == ci) & (j + 3 < i)));
+        }
+        for (; j < b; ++j) {
+            const uint32_t cj = c[j];
+            rank += (uint32_t)((cj < ci) | ((cj == ci) & (j < i)));
+        }
+        inv[a + rank] = (uint16_t)i;
     }
     __builtin_amdgcn_wave_barrier();
+    // 2. runs
     const uint32_t r = (uint32_t)r0 + lane;
     if (r < r1) {
-        const uint32_t a = start[r] - e0, b = start[r + 1] - e0;
-        // stable insertion sort by column (rows are short)
-        for (uint32_t i = a + 1; i < b; ++i) {
-            const uint32_t ck = c[i];
-            const T vk = v[i];
-            uint32_t j = i;
-            while (j > a && c[j - 1] > ck) {
-                c[j] = c[j - 1];
-                v[j] = v[j - 1];
-                --j;
-            }
-            c[j] = ck;
-            v[j] = vk;
-        }
-        // runs of equal columns: left-to-right sums, drop zeros, pack
-        uint32_t out = a;
-        uint32_t i = a;
-        while (i < b) {
+        const uint32_t a = rs[lane], b = rs[lane + 1];
+        uint32_t out = e0 + a;  // global position of the next survivor
+        uint32_t q = a;
+        while (q < b) {
+            uint32_t i = inv[q];
             const uint32_t ck = c[i];
             T acc = v[i];
-            for (++i; i < b && c[i] == ck; ++i) acc = acc + v[i];
+            for (++q; q < b; ++q) {
+                i = inv[q];
+                if (c[i] != ck) break;
+                acc = acc + v[i];
+            }
             if (acc != T(0)) {
-                c[out] = ck;
-                v[out] = acc;
+                cols[out] = ck;
+                vals[out] = acc;
                 ++out;
             }
         }
-        kept[r] = out - a;
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = lane; i < n; i += 64) {
-        cols[e0 + i] = c[i];
-        vals[e0 + i] = v[i];
+        kept[r] = out - (e0 + a);
     }
 }
 
-// Packs the kept entries of every row at rowptr[row] (one wave per 64-row tile,
-// through LDS so that the writes are coalesced).
+// Packs the kept entries of every row at rowptr[row].  One wave per 64-row
+// tile, entry-parallel: the tile's output range [rowptr[first], rowptr[last+1])
+// is contiguous; lane l takes output positions l, l+64, ..., finds the row of
+// each by a binary search over the tile's 65 row offsets (LDS) and copies the
+// entry from its place in the row's segment.  All loads are independent and the
+// stores are coalesced.
 template <typename T>
 __global__ __launch_bounds__(256) void coo_tile_pack(const uint32_t *__restrict__ start,
                                                      const uint32_t *__restrict__ rowptr,
@@ -432,28 +493,48 @@ __global__ __launch_bounds__(256) void coo_tile_pack(const uint32_t *__restrict_
                                                      const T *__restrict__ vals, uint32_t nrows,
                                                      uint32_t *__restrict__ out_col,
                                                      T *__restrict__ out_val) {
-    __shared__ uint32_t s_col[4][kTileCap];
-    __shared__ T s_val[4][kTileCap];
+    __shared__ uint32_t s_rp[4][kTileRows + 1], s_st[4][kTileRows + 1];
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t tile = (uint64_t)blockIdx.x * 4 + w;
     const uint64_t r0 = tile * kTileRows;
     if (r0 >= nrows) return;
     const uint32_t r1 = (uint32_t)min<uint64_t>(r0 + kTileRows, nrows);
-    const uint32_t o0 = rowptr[r0], o1 = rowptr[r1];
-    uint32_t *c = s_col[w];
-    T *v = s_val[w];
-    const uint32_t r = (uint32_t)r0 + lane;
-    if (r < r1) {
-        const uint32_t src = start[r], dst = rowptr[r] - o0, k = rowptr[r + 1] - rowptr[r];
-        for (uint32_t i = 0; i < k; ++i) {
-            c[dst + i] = cols[src + i];
-            v[dst + i] = vals[src + i];
+    uint32_t *rp = s_rp[w], *st = s_st[w];
+    const uint32_t rl = min((uint32_t)r0 + lane, r1);
+    rp[lane] = rowptr[rl];
+    st[lane] = start[rl];
+    if (lane == 0) { rp[kTileRows] = rowptr[r1]; st[kTileRows] = start[r1]; }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t o0 = rp[0], o1 = rp[kTileRows];   // rows past r1 repeat rowptr[r1]
+    constexpr int K = kTileCap / 64;
+    uint32_t rc[K];
+    T rv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t o = o0 + lane + 64u * k;
+        rc[k] = 0;
+        rv[k] = T(0);
+        if (o < o1) {
+            // largest row index r (0..64) with rp[r] <= o; empty rows share an offset
+            // with their successor, the search lands on the last of them, whose
+            // successor offset is > o: the row that owns position o
+            uint32_t lo = 0, hi = kTileRows;  // invariant: rp[lo] <= o < rp[hi]
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (rp[mid] <= o) lo = mid; else hi = mid;
+            }
+            const uint32_t src = st[lo] + (o - rp[lo]);
+            rc[k] = cols[src];
+            rv[k] = vals[src];
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = lane; i < o1 - o0; i += 64) {
-        out_col[o0 + i] = c[i];
-        out_val[o0 + i] = v[i];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t o = o0 + lane + 64u * k;
+        if (o < o1) {
+            out_col[o] = rc[k];
+            out_val[o] = rv[k];
+        }
     }
 }
 
@@ -602,7 +683,8 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
     if (!too_long) {
         // ---- 3. per-row stable sort by column + run sums + zero drop, in LDS
         hipLaunchKernelGGL(coo_tile_sort<T>, dim3((ntiles + 3) / 4), dim3(256), 0, st,
-                           start.as<uint32_t>(), sb.aux[cur], sb.val[cur], nrows, kept.as<uint32_t>());
+                           start.as<uint32_t>(), sb.key[cur], sb.aux[cur], sb.val[cur], nrows,
+                           kept.as<uint32_t>());
         // ---- 4. rowptr = scan of the kept counts; pack
         SPAL_HIP_TRY(exclusive_scan_u32(kept.as<uint32_t>(), rowptr.as<uint32_t>(), nrows,
                                         sums.as<uint32_t>(), total.as<uint32_t>(), st, true));
