@@ -156,13 +156,18 @@ def bench_coo(args):
         d.assemble_csr().close()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    per_step = []
     for _ in range(steps):
+        ts = time.perf_counter()
         csr = d.assemble_csr()      # includes its one host sync and the CSR handle's planning
         nnz = csr.shape()[2]
         if _ + 1 < steps:
             csr.close()
+        per_step.append((time.perf_counter() - ts) * 1e3)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / steps
+    if os.environ.get("SPAL_BENCH_DEBUG"):
+        print("per-step ms:", [round(t, 2) for t in per_step], file=sys.stderr)
     # the assembled matrix multiplies (the config's second half)
     x = torch.from_numpy(sp.synth.vector(nr, dtype=np_dt)).cuda()
     y = torch.empty_like(x)

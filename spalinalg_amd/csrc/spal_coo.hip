@@ -324,8 +324,8 @@ static uint32_t bits_for(uint64_t n) {  // bits needed for values in [0, n)
 
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    ~DevBuf() { if (p) (void)dev_free(p); }
+    hipError_t alloc(size_t bytes) { return dev_alloc((void **)&p, bytes ? bytes : 1); }
     template <typename U> U *as() { return reinterpret_cast<U *>(p); }
     void *release() { void *q = p; p = nullptr; return q; }
 };
@@ -645,8 +645,8 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
     std::lock_guard<std::mutex> lock(c->mu);  // one assembly at a time per handle (shared workspace)
     const CooWorkspace ws = coo_workspace_layout(len, nrows, sizeof(T));
     if (!c->d_work || c->work_bytes < ws.bytes) {
-        if (c->d_work) { (void)hipFree(c->d_work); c->d_work = nullptr; }
-        SPAL_HIP_TRY(hipMalloc(&c->d_work, ws.bytes));
+        if (c->d_work) { (void)dev_free(c->d_work); c->d_work = nullptr; }
+        SPAL_HIP_TRY(dev_alloc((void **)&c->d_work, ws.bytes));
         c->work_bytes = ws.bytes;
     }
     char *wb = (char *)c->d_work;
@@ -831,10 +831,10 @@ int transpose_device(int device, int elem_size, uint64_t nmajor, uint64_t nminor
 
 static void coo_free(spal_coo *c) {
     if (!c) return;
-    (void)hipFree(c->d_work);
-    (void)hipFree(c->d_rows);
-    (void)hipFree(c->d_cols);
-    (void)hipFree(c->d_vals);
+    (void)dev_free(c->d_work);
+    (void)dev_free(c->d_rows);
+    (void)dev_free(c->d_cols);
+    (void)dev_free(c->d_vals);
     delete c;
 }
 
@@ -868,15 +868,15 @@ static int coo_upload(int device, uint64_t nrows, uint64_t ncols, uint64_t len, 
     spal_coo *c = new spal_coo;
     c->device = device; c->elem_size = (int)sizeof(T);
     c->nrows = nrows; c->ncols = ncols; c->len = len;
-    hipError_t e = hipMalloc(&c->d_rows, std::max<uint64_t>(len, 1) * 4);
-    if (e == hipSuccess) e = hipMalloc(&c->d_cols, std::max<uint64_t>(len, 1) * 4);
-    if (e == hipSuccess) e = hipMalloc(&c->d_vals, std::max<uint64_t>(len, 1) * sizeof(T));
+    hipError_t e = dev_alloc((void **)&c->d_rows, std::max<uint64_t>(len, 1) * 4);
+    if (e == hipSuccess) e = dev_alloc((void **)&c->d_cols, std::max<uint64_t>(len, 1) * 4);
+    if (e == hipSuccess) e = dev_alloc((void **)&c->d_vals, std::max<uint64_t>(len, 1) * sizeof(T));
     if (e == hipSuccess && len) e = hipMemcpy(c->d_rows, r32.data(), len * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess && len) e = hipMemcpy(c->d_cols, c32.data(), len * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess && len) e = hipMemcpy(c->d_vals, vals, len * sizeof(T), hipMemcpyHostToDevice);
     if (e == hipSuccess && len) {  // the assembly's workspace: setup, not the timed path
         c->work_bytes = coo_workspace_layout(len, nrows, sizeof(T)).bytes;
-        e = hipMalloc(&c->d_work, c->work_bytes);
+        e = dev_alloc((void **)&c->d_work, c->work_bytes);
     }
     if (e != hipSuccess) {
         coo_free(c);
@@ -928,7 +928,7 @@ int spal_coo_assemble_csr(spal_coo_t c, void *stream, spal_csr_t *out) {
     SPAL_TRY(coo_assemble(c, false, (hipStream_t)stream, r));
     int st = csr_adopt_device(c->device, c->elem_size, c->nrows, c->ncols, r.nnz, r.cap, r.ptr, r.ind,
                               r.val, out);
-    if (st != SPAL_OK) { (void)hipFree(r.ptr); (void)hipFree(r.ind); (void)hipFree(r.val); }
+    if (st != SPAL_OK) { (void)dev_free(r.ptr); (void)dev_free(r.ind); (void)dev_free(r.val); }
     return st;
 }
 int spal_coo_assemble_csc(spal_coo_t c, void *stream, spal_csc_t *out) {
@@ -941,21 +941,21 @@ int spal_coo_assemble_csc(spal_coo_t c, void *stream, spal_csc_t *out) {
     if (r.cap < r.nnz + 256) {  // csc handles expect the over-read margin too
         uint32_t *ind = nullptr;
         void *val = nullptr;
-        hipError_t e = hipMalloc(&ind, (r.nnz + 256) * 4);
-        if (e == hipSuccess) e = hipMalloc(&val, (r.nnz + 256) * (size_t)c->elem_size);
+        hipError_t e = dev_alloc((void **)&ind, (r.nnz + 256) * 4);
+        if (e == hipSuccess) e = dev_alloc((void **)&val, (r.nnz + 256) * (size_t)c->elem_size);
         if (e == hipSuccess) e = hipMemset(ind, 0, (r.nnz + 256) * 4);
         if (e == hipSuccess) e = hipMemset(val, 0, (r.nnz + 256) * (size_t)c->elem_size);
         if (e == hipSuccess && r.nnz) e = hipMemcpy(ind, r.ind, r.nnz * 4, hipMemcpyDeviceToDevice);
         if (e == hipSuccess && r.nnz) e = hipMemcpy(val, r.val, r.nnz * (size_t)c->elem_size, hipMemcpyDeviceToDevice);
         if (e != hipSuccess) {
-            (void)hipFree(ind); (void)hipFree(val); (void)hipFree(r.ptr); (void)hipFree(r.ind); (void)hipFree(r.val);
+            (void)dev_free(ind); (void)dev_free(val); (void)dev_free(r.ptr); (void)dev_free(r.ind); (void)dev_free(r.val);
             return fail(SPAL_ERR_HIP, "spal_coo_assemble_csc: %s", hipGetErrorString(e));
         }
-        (void)hipFree(r.ind); (void)hipFree(r.val);
+        (void)dev_free(r.ind); (void)dev_free(r.val);
         r.ind = ind; r.val = val;
     }
     int st = csc_adopt_device(c->device, c->elem_size, c->nrows, c->ncols, r.nnz, r.ptr, r.ind, r.val, out);
-    if (st != SPAL_OK) { (void)hipFree(r.ptr); (void)hipFree(r.ind); (void)hipFree(r.val); }
+    if (st != SPAL_OK) { (void)dev_free(r.ptr); (void)dev_free(r.ind); (void)dev_free(r.val); }
     return st;
 }
 int spal_coo_to_csr_f64(int device, uint64_t nrows, uint64_t ncols, uint64_t len, const uint64_t *rows,

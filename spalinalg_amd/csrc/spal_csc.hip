@@ -193,20 +193,20 @@ static int csc_launch(spal_csc *a, const void *x, void *y, hipStream_t st) {
 // Per-super-tile windows and modes; packed metadata for the LDS mode.
 static int csc_plan_build(spal_csc *a) {
     a->nblocks = (uint32_t)((a->ncols + kCscCols - 1) / kCscCols);
-    if (a->d_desc) { SPAL_HIP_TRY(hipFree(a->d_desc)); a->d_desc = nullptr; }
+    if (a->d_desc) { SPAL_HIP_TRY(dev_free(a->d_desc)); a->d_desc = nullptr; }
     a->lds_entries = 0;
     a->lds_col_fraction = 0.0;
     std::vector<uint4> desc(a->nblocks, make_uint4(0, 0, kCscModeGlobal, 0));
     if (a->nnz && a->use_lds) {
         uint2 *d_win = nullptr;
-        SPAL_HIP_TRY(hipMalloc(&d_win, (size_t)a->nblocks * sizeof(uint2)));
+        SPAL_HIP_TRY(dev_alloc((void **)&d_win, (size_t)a->nblocks * sizeof(uint2)));
         hipLaunchKernelGGL(csc_block_windows, dim3(a->nblocks), dim3(256), 0, a->stream, a->d_colptr,
                            a->d_rowind, (uint32_t)a->ncols, d_win);
         std::vector<uint2> win(a->nblocks);
         hipError_t e = hipMemcpyAsync(win.data(), d_win, (size_t)a->nblocks * sizeof(uint2),
                                       hipMemcpyDeviceToHost, a->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
-        (void)hipFree(d_win);
+        (void)dev_free(d_win);
         SPAL_HIP_TRY(e);
         const uint32_t budget = std::min<uint32_t>(kCscWindowBytes / (uint32_t)a->elem_size, 65536u);
         uint64_t cols_lds = 0;
@@ -222,12 +222,12 @@ static int csc_plan_build(spal_csc *a) {
         }
         a->lds_col_fraction = (double)cols_lds / (double)a->ncols;
     }
-    SPAL_HIP_TRY(hipMalloc(&a->d_desc, (size_t)a->nblocks * sizeof(uint4)));
+    SPAL_HIP_TRY(dev_alloc((void **)&a->d_desc, (size_t)a->nblocks * sizeof(uint4)));
     SPAL_HIP_TRY(hipMemcpyAsync(a->d_desc, desc.data(), (size_t)a->nblocks * sizeof(uint4),
                                 hipMemcpyHostToDevice, a->stream));
     if (a->lds_entries) {
         if (!a->d_meta) {
-            SPAL_HIP_TRY(hipMalloc(&a->d_meta, (size_t)(a->nnz + kStreamPad) * sizeof(uint32_t)));
+            SPAL_HIP_TRY(dev_alloc((void **)&a->d_meta, (size_t)(a->nnz + kStreamPad) * sizeof(uint32_t)));
             SPAL_HIP_TRY(hipMemsetAsync(a->d_meta, 0, (size_t)(a->nnz + kStreamPad) * sizeof(uint32_t), a->stream));
         }
         hipLaunchKernelGGL(csc_encode_meta, dim3(a->nblocks), dim3(256), 0, a->stream, a->d_colptr,
@@ -248,7 +248,7 @@ static int csc_ensure_csr(spal_csc *a) {
                               a->d_rowind, a->d_values, a->stream, &rp, &ci, &va, &cap));
     int st = csr_adopt_device(a->device, a->elem_size, a->nrows, a->ncols, a->nnz, cap, rp, ci, va,
                               &a->as_csr);
-    if (st != SPAL_OK) { (void)hipFree(rp); (void)hipFree(ci); (void)hipFree(va); }
+    if (st != SPAL_OK) { (void)dev_free(rp); (void)dev_free(ci); (void)dev_free(va); }
     return st;
 }
 
@@ -268,7 +268,7 @@ int csc_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, 
     }
     auto bail = [&](int st) {
         a->d_colptr = nullptr; a->d_rowind = nullptr; a->d_values = nullptr;  // stay with the caller
-        (void)hipFree(a->d_meta); (void)hipFree(a->d_desc);
+        (void)dev_free(a->d_meta); (void)dev_free(a->d_desc);
         if (a->stream) (void)hipStreamDestroy(a->stream);
         delete a;
         return st;
@@ -288,13 +288,13 @@ int csc_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, 
 static void csc_free(spal_csc *a) {
     if (!a) return;
     if (a->as_csr) (void)spal_csr_destroy(a->as_csr);
-    (void)hipFree(a->d_colptr);
-    (void)hipFree(a->d_rowind);
-    (void)hipFree(a->d_values);
-    (void)hipFree(a->d_meta);
-    (void)hipFree(a->d_desc);
-    (void)hipFree(a->d_x);
-    (void)hipFree(a->d_y);
+    (void)dev_free(a->d_colptr);
+    (void)dev_free(a->d_rowind);
+    (void)dev_free(a->d_values);
+    (void)dev_free(a->d_meta);
+    (void)dev_free(a->d_desc);
+    (void)dev_free(a->d_x);
+    (void)dev_free(a->d_y);
     if (a->stream) (void)hipStreamDestroy(a->stream);
     delete a;
 }
@@ -329,9 +329,9 @@ static int csc_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t
     a->nrows = nrows; a->ncols = ncols; a->nnz = nnz;
     a->lanes_per_col = pick_lanes_csc(ncols ? (double)nnz / (double)ncols : 0.0);
     const uint64_t cap = nnz + kStreamPad;  // whole-step reads of the LDS-mode stream
-    hipError_t e = hipMalloc(&a->d_colptr, (ncols + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&a->d_rowind, cap * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&a->d_values, cap * sizeof(T));
+    hipError_t e = dev_alloc((void **)&a->d_colptr, (ncols + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = dev_alloc((void **)&a->d_rowind, cap * sizeof(uint32_t));
+    if (e == hipSuccess) e = dev_alloc((void **)&a->d_values, cap * sizeof(T));
     if (e == hipSuccess) e = hipMemset((char *)a->d_values + nnz * sizeof(T), 0, kStreamPad * sizeof(T));
     if (e == hipSuccess) e = hipMemcpy(a->d_colptr, cp32.data(), (ncols + 1) * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && nnz) e = hipMemcpy(a->d_rowind, ri32.data(), nnz * sizeof(uint32_t), hipMemcpyHostToDevice);
@@ -366,8 +366,8 @@ static int csc_spmv_host(spal_csc_t a, const T *x, uint64_t x_len, T *y, uint64_
     DeviceGuard guard(a->device);
     if (guard.status != SPAL_OK) return guard.status;
     std::lock_guard<std::mutex> lock(a->mu);
-    if (!a->d_x) SPAL_HIP_TRY(hipMalloc(&a->d_x, a->ncols * sizeof(T)));
-    if (!a->d_y) SPAL_HIP_TRY(hipMalloc(&a->d_y, a->nrows * sizeof(T)));
+    if (!a->d_x) SPAL_HIP_TRY(dev_alloc((void **)&a->d_x, a->ncols * sizeof(T)));
+    if (!a->d_y) SPAL_HIP_TRY(dev_alloc((void **)&a->d_y, a->nrows * sizeof(T)));
     SPAL_HIP_TRY(hipMemcpyAsync(a->d_x, x, a->ncols * sizeof(T), hipMemcpyHostToDevice, a->stream));
     SPAL_TRY(csc_launch(a, a->d_x, a->d_y, a->stream));
     SPAL_HIP_TRY(hipMemcpyAsync(y, a->d_y, a->nrows * sizeof(T), hipMemcpyDeviceToHost, a->stream));
@@ -462,7 +462,7 @@ int spal_csc_to_csr(spal_csc_t a, spal_csr_t *out) {
     SPAL_TRY(transpose_device(a->device, a->elem_size, a->ncols, a->nrows, a->nnz, a->d_colptr,
                               a->d_rowind, a->d_values, a->stream, &rp, &ci, &va, &cap));
     int st = csr_adopt_device(a->device, a->elem_size, a->nrows, a->ncols, a->nnz, cap, rp, ci, va, out);
-    if (st != SPAL_OK) { (void)hipFree(rp); (void)hipFree(ci); (void)hipFree(va); }
+    if (st != SPAL_OK) { (void)dev_free(rp); (void)dev_free(ci); (void)dev_free(va); }
     return st;
 }
 
@@ -478,7 +478,7 @@ int spal_csr_to_csc(spal_csr_t a, spal_csc_t *out) {
     SPAL_TRY(transpose_device(a->device, a->elem_size, a->nrows, a->ncols, a->nnz, a->d_rowptr,
                               a->d_colind, a->d_values, a->stream, &cp, &ri, &va, &cap));
     int st = csc_adopt_device(a->device, a->elem_size, a->nrows, a->ncols, a->nnz, cp, ri, va, out);
-    if (st != SPAL_OK) { (void)hipFree(cp); (void)hipFree(ri); (void)hipFree(va); }
+    if (st != SPAL_OK) { (void)dev_free(cp); (void)dev_free(ri); (void)dev_free(va); }
     return st;
 }
 

@@ -27,6 +27,96 @@ DeviceGuard::~DeviceGuard() {
     if (prev >= 0) (void)hipSetDevice(prev);
 }
 
+// ---- caching allocator for large device blocks -----------------------------------
+namespace {
+struct DevCache {
+    std::mutex mu;
+    struct Block { void *p; size_t bytes; int device; };
+    std::vector<Block> free_blocks;
+    std::vector<Block> live;      // blocks handed out by dev_alloc (for their size at free time)
+    size_t cached_bytes = 0;
+    size_t limit = [] {
+        if (const char *e = getenv("SPAL_CACHE_BYTES")) return (size_t)strtoull(e, nullptr, 10);
+        return (size_t)8 << 30;
+    }();
+    ~DevCache() {}  // the process is going away; the driver reclaims device memory
+};
+DevCache &dev_cache() { static DevCache c; return c; }
+constexpr size_t kCacheMinBytes = 1u << 20;
+}  // namespace
+
+hipError_t dev_alloc(void **ptr, size_t bytes) {
+    *ptr = nullptr;
+    if (bytes == 0) bytes = 1;
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    DevCache &c = dev_cache();
+    if (bytes >= kCacheMinBytes) {
+        std::lock_guard<std::mutex> lock(c.mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < c.free_blocks.size(); ++i) {
+            const auto &b = c.free_blocks[i];
+            if (b.device == device && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 &&
+                (best == (size_t)-1 || b.bytes < c.free_blocks[best].bytes))
+                best = i;
+        }
+        if (best != (size_t)-1) {
+            DevCache::Block b = c.free_blocks[best];
+            c.free_blocks.erase(c.free_blocks.begin() + best);
+            c.cached_bytes -= b.bytes;
+            c.live.push_back(b);
+            *ptr = b.p;
+            return hipSuccess;
+        }
+    }
+    e = hipMalloc(ptr, bytes);
+    if (e == hipErrorOutOfMemory) {  // give the cache back and retry once
+        (void)hipGetLastError();
+        dev_cache_trim();
+        e = hipMalloc(ptr, bytes);
+    }
+    if (e == hipSuccess && bytes >= kCacheMinBytes) {
+        std::lock_guard<std::mutex> lock(c.mu);
+        c.live.push_back({*ptr, bytes, device});
+    }
+    return e;
+}
+
+hipError_t dev_free(void *ptr) {
+    if (!ptr) return hipSuccess;
+    DevCache &c = dev_cache();
+    DevCache::Block b{nullptr, 0, 0};
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        for (size_t i = 0; i < c.live.size(); ++i)
+            if (c.live[i].p == ptr) { b = c.live[i]; c.live.erase(c.live.begin() + i); break; }
+    }
+    if (!b.p) return hipFree(ptr);  // small block (or not ours): straight back
+    hipError_t e = hipDeviceSynchronize();  // what hipFree would have done: no user of the block is still running
+    std::lock_guard<std::mutex> lock(c.mu);
+    if (e == hipSuccess && c.cached_bytes + b.bytes <= c.limit) {
+        c.free_blocks.push_back(b);
+        c.cached_bytes += b.bytes;
+        return hipSuccess;
+    }
+    return hipFree(ptr);
+}
+
+void dev_cache_trim() {
+    DevCache &c = dev_cache();
+    std::vector<DevCache::Block> blocks;
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        blocks.swap(c.free_blocks);
+        c.cached_bytes = 0;
+    }
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (auto &b : blocks) { (void)hipSetDevice(b.device); (void)hipFree(b.p); }
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
+
 // ---- per-row-block column window ---------------------------------------------
 // Columns are strictly increasing inside a row (src/csr.rs:152-156), so a
 // row's first and last stored column bound it.  One workgroup per row block:
@@ -241,14 +331,14 @@ static constexpr uint32_t kWinBase = 256;
 static int block_windows_device(spal_csr *a, uint32_t R, std::vector<uint2> &win) {
     const uint32_t nb = (uint32_t)((a->nrows + R - 1) / R);
     uint2 *d_win = nullptr;
-    SPAL_HIP_TRY(hipMalloc(&d_win, (size_t)nb * sizeof(uint2)));
+    SPAL_HIP_TRY(dev_alloc((void **)&d_win, (size_t)nb * sizeof(uint2)));
     hipLaunchKernelGGL(csr_block_windows, dim3(nb), dim3(256), 0, a->stream, a->d_rowptr,
                        a->d_colind, (uint32_t)a->nrows, R, d_win);
     win.resize(nb);
     hipError_t e = hipMemcpyAsync(win.data(), d_win, (size_t)nb * sizeof(uint2),
                                   hipMemcpyDeviceToHost, a->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
-    (void)hipFree(d_win);
+    (void)dev_free(d_win);
     SPAL_HIP_TRY(e);
     return SPAL_OK;
 }
@@ -279,13 +369,13 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
     std::vector<uint2> win;
     SPAL_TRY(block_windows(a, R, win));
     uint32_t *d_ok = nullptr;
-    SPAL_HIP_TRY(hipMalloc(&d_ok, (size_t)nb * 4));
+    SPAL_HIP_TRY(dev_alloc((void **)&d_ok, (size_t)nb * 4));
     hipLaunchKernelGGL(csr_stream_check, dim3((nb + 255) / 256), dim3(256), 0, a->stream, a->d_rowptr,
                        (uint32_t)a->nrows, nb, R, rpt, d_ok);
     std::vector<uint32_t> ok(nb);
     hipError_t e = hipMemcpyAsync(ok.data(), d_ok, (size_t)nb * 4, hipMemcpyDeviceToHost, a->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
-    (void)hipFree(d_ok);
+    (void)dev_free(d_ok);
     SPAL_HIP_TRY(e);
     const uint32_t budget = kStreamWindowBytes / (uint32_t)a->elem_size;
     const uint32_t valign = 16u / (uint32_t)a->elem_size;
@@ -324,7 +414,7 @@ int csr_plan_build(spal_csr *a) {
     if (!p.user_unroll) p.unroll = 4;
     if (!p.user_threads) p.threads = 1024;
     if (a->d_desc) {
-        SPAL_HIP_TRY(hipFree(a->d_desc));
+        SPAL_HIP_TRY(dev_free(a->d_desc));
         a->d_desc = nullptr;
     }
     p.stream_row_fraction = 0.0;
@@ -373,11 +463,11 @@ int csr_plan_build(spal_csr *a) {
                 if (best_desc[b].z != kModeVectorGlobal)
                     lds_rows += std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
             p.lds_row_fraction = (double)lds_rows / (double)a->nrows;
-            SPAL_HIP_TRY(hipMalloc(&a->d_desc, (size_t)p.nblocks * sizeof(uint4)));
+            SPAL_HIP_TRY(dev_alloc((void **)&a->d_desc, (size_t)p.nblocks * sizeof(uint4)));
             SPAL_HIP_TRY(hipMemcpyAsync(a->d_desc, best_desc.data(), (size_t)p.nblocks * sizeof(uint4),
                                         hipMemcpyHostToDevice, a->stream));
             if (!a->d_col16) {
-                SPAL_HIP_TRY(hipMalloc(&a->d_col16, (size_t)a->cap_entries * sizeof(uint16_t)));
+                SPAL_HIP_TRY(dev_alloc((void **)&a->d_col16, (size_t)a->cap_entries * sizeof(uint16_t)));
                 SPAL_HIP_TRY(hipMemsetAsync(a->d_col16, 0, (size_t)a->cap_entries * sizeof(uint16_t), a->stream));
             }
             hipLaunchKernelGGL(csr_encode_col16, dim3(p.nblocks), dim3(256), 0, a->stream, a->d_rowptr,
@@ -442,7 +532,7 @@ int csr_plan_build(spal_csr *a) {
     p.lds_entries = use_lds ? ((best_cap + valign - 1) & ~(valign - 1)) : 0;
     if (!use_lds)
         for (auto &d : best_desc) d = make_uint4(0, 0, kModeVectorGlobal, 0);
-    SPAL_HIP_TRY(hipMalloc(&a->d_desc, (size_t)p.nblocks * sizeof(uint4)));
+    SPAL_HIP_TRY(dev_alloc((void **)&a->d_desc, (size_t)p.nblocks * sizeof(uint4)));
     SPAL_HIP_TRY(hipMemcpy(a->d_desc, best_desc.data(), (size_t)p.nblocks * sizeof(uint4),
                            hipMemcpyHostToDevice));
     return SPAL_OK;
@@ -450,13 +540,13 @@ int csr_plan_build(spal_csr *a) {
 
 static void csr_free(spal_csr *a) {
     if (!a) return;
-    (void)hipFree(a->d_rowptr);
-    (void)hipFree(a->d_colind);
-    (void)hipFree(a->d_values);
-    (void)hipFree(a->d_desc);
-    (void)hipFree(a->d_col16);
-    (void)hipFree(a->d_x);
-    (void)hipFree(a->d_y);
+    (void)dev_free(a->d_rowptr);
+    (void)dev_free(a->d_colind);
+    (void)dev_free(a->d_values);
+    (void)dev_free(a->d_desc);
+    (void)dev_free(a->d_col16);
+    (void)dev_free(a->d_x);
+    (void)dev_free(a->d_y);
     if (a->stream) (void)hipStreamDestroy(a->stream);
     delete a;
 }
@@ -485,15 +575,15 @@ int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, 
     if (cap_entries < need) {
         uint32_t *ci = nullptr;
         void *va = nullptr;
-        e = hipMalloc(&ci, need * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(&va, need * (size_t)elem_size);
+        e = dev_alloc((void **)&ci, need * sizeof(uint32_t));
+        if (e == hipSuccess) e = dev_alloc((void **)&va, need * (size_t)elem_size);
         if (e == hipSuccess) e = hipMemsetAsync(ci, 0, need * sizeof(uint32_t), a->stream);
         if (e == hipSuccess) e = hipMemsetAsync(va, 0, need * (size_t)elem_size, a->stream);
         if (e == hipSuccess && nnz) e = hipMemcpyAsync(ci, d_colind, nnz * sizeof(uint32_t), hipMemcpyDeviceToDevice, a->stream);
         if (e == hipSuccess && nnz) e = hipMemcpyAsync(va, d_values, nnz * (size_t)elem_size, hipMemcpyDeviceToDevice, a->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
         if (e != hipSuccess) {
-            (void)hipFree(ci); (void)hipFree(va);
+            (void)dev_free(ci); (void)dev_free(va);
             return bail(fail(e == hipErrorOutOfMemory ? SPAL_ERR_OUT_OF_MEMORY : SPAL_ERR_HIP,
                              "csr_adopt_device: %s", hipGetErrorString(e)));
         }
@@ -502,12 +592,12 @@ int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, 
     int st = csr_plan_build(a);
     if (st != SPAL_OK) {
         const bool swapped = a->d_colind != d_colind;
-        if (swapped) { (void)hipFree(a->d_colind); (void)hipFree(a->d_values); a->d_colind = d_colind; a->d_values = d_values; }
+        if (swapped) { (void)dev_free(a->d_colind); (void)dev_free(a->d_values); a->d_colind = d_colind; a->d_values = d_values; }
         return bail(st);
     }
     if (a->d_colind != d_colind) {  // the padded copies replaced the caller's arrays
-        (void)hipFree(d_colind);
-        (void)hipFree(d_values);
+        (void)dev_free(d_colind);
+        (void)dev_free(d_values);
     }
     *out = a;
     return SPAL_OK;
@@ -541,11 +631,11 @@ static int csr_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t
     });
     uint32_t *d_rp = nullptr, *d_ci = nullptr;
     void *d_v = nullptr;
-    auto cleanup = [&] { (void)hipFree(d_rp); (void)hipFree(d_ci); (void)hipFree(d_v); };
+    auto cleanup = [&] { (void)dev_free(d_rp); (void)dev_free(d_ci); (void)dev_free(d_v); };
     const uint64_t cap = nnz + kStreamPad;  // spare entries for the stream kernel's whole-step reads
-    hipError_t e = hipMalloc(&d_rp, (nrows + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_ci, cap * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&d_v, cap * sizeof(T));
+    hipError_t e = dev_alloc((void **)&d_rp, (nrows + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = dev_alloc((void **)&d_ci, cap * sizeof(uint32_t));
+    if (e == hipSuccess) e = dev_alloc((void **)&d_v, cap * sizeof(T));
     if (e == hipSuccess) e = hipMemset((char *)d_ci + nnz * sizeof(uint32_t), 0, kStreamPad * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset((char *)d_v + nnz * sizeof(T), 0, kStreamPad * sizeof(T));
     if (e == hipSuccess) e = hipMemcpy(d_rp, rp32.data(), (nrows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice);
@@ -580,8 +670,8 @@ static int csr_spmv_host(spal_csr_t a, const T *x, uint64_t x_len, T *y, uint64_
     DeviceGuard guard(a->device);
     if (guard.status != SPAL_OK) return guard.status;
     std::lock_guard<std::mutex> lock(a->mu);
-    if (!a->d_x) SPAL_HIP_TRY(hipMalloc(&a->d_x, a->ncols * sizeof(T)));
-    if (!a->d_y) SPAL_HIP_TRY(hipMalloc(&a->d_y, a->nrows * sizeof(T)));
+    if (!a->d_x) SPAL_HIP_TRY(dev_alloc((void **)&a->d_x, a->ncols * sizeof(T)));
+    if (!a->d_y) SPAL_HIP_TRY(dev_alloc((void **)&a->d_y, a->nrows * sizeof(T)));
     SPAL_HIP_TRY(hipMemcpyAsync(a->d_x, x, a->ncols * sizeof(T), hipMemcpyHostToDevice, a->stream));
     SPAL_TRY(csr_launch(a, a->d_x, a->d_y, a->stream));
     SPAL_HIP_TRY(hipMemcpyAsync(y, a->d_y, a->nrows * sizeof(T), hipMemcpyDeviceToHost, a->stream));
@@ -839,14 +929,14 @@ int spal_dev_malloc(int device, size_t bytes, void **ptr) {
     *ptr = nullptr;
     DeviceGuard guard(device);
     if (guard.status != SPAL_OK) return guard.status;
-    SPAL_HIP_TRY(hipMalloc(ptr, bytes ? bytes : 1));
+    SPAL_HIP_TRY(dev_alloc((void **)ptr, bytes ? bytes : 1));
     return SPAL_OK;
 }
 int spal_dev_free(int device, void *ptr) {
     if (!ptr) return SPAL_OK;
     DeviceGuard guard(device);
     if (guard.status != SPAL_OK) return guard.status;
-    SPAL_HIP_TRY(hipFree(ptr));
+    SPAL_HIP_TRY(dev_free(ptr));
     return SPAL_OK;
 }
 int spal_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes) {

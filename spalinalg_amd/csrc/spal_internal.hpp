@@ -50,6 +50,18 @@ struct DeviceGuard {
     ~DeviceGuard();
 };
 
+// ---- device memory ---------------------------------------------------------------
+// hipMalloc / hipFree of hundreds of MB cost milliseconds (and on some hosts
+// tens of ms) each; a handle that is assembled, used and destroyed in a loop
+// would pay that every time.  dev_alloc / dev_free keep a small per-device
+// cache of large freed blocks (exact-fit-ish reuse, bounded by
+// SPAL_CACHE_BYTES, default 8 GiB).  dev_free synchronises the device first,
+// like hipFree does, so a cached block is never handed out while work that used
+// it is still in flight.  Small blocks go straight to hipMalloc / hipFree.
+hipError_t dev_alloc(void **ptr, size_t bytes);   // on the current device
+hipError_t dev_free(void *ptr);                   // on the current device; NULL is fine
+void dev_cache_trim();                            // releases every cached block
+
 // ---- host helpers ------------------------------------------------------------
 unsigned host_threads();
 // fn(begin, end, tid) over [0, n) split into contiguous chunks, one per thread.

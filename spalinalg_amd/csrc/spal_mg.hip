@@ -94,9 +94,9 @@ static void mg_csr_free(spal_mg_csr *a) {
         if (a->shard[g]) spal_csr_destroy(a->shard[g]);
         if (a->ctx && g < (size_t)a->ctx->ngpus) {
             (void)hipSetDevice(a->ctx->devices[g]);
-            if (g < a->d_x.size()) (void)hipFree(a->d_x[g]);
-            if (g < a->d_yloc.size()) (void)hipFree(a->d_yloc[g]);
-            if (g < a->d_yall.size()) (void)hipFree(a->d_yall[g]);
+            if (g < a->d_x.size()) (void)dev_free(a->d_x[g]);
+            if (g < a->d_yloc.size()) (void)dev_free(a->d_yloc[g]);
+            if (g < a->d_yall.size()) (void)dev_free(a->d_yall[g]);
         }
     }
     delete a;
@@ -143,9 +143,9 @@ static int mg_csr_create(spal_mg *ctx, uint64_t nrows, uint64_t ncols, const uin
                                        e1 - e0, (const float *)values + e0, e1 - e0, &a->shard[g]);
         if (st != SPAL_OK) { mg_csr_free(a); return st; }
         hipError_t e = hipSetDevice(ctx->devices[g]);
-        if (e == hipSuccess) e = hipMalloc(&a->d_x[g], ncols * sizeof(T));
-        if (e == hipSuccess) e = hipMalloc(&a->d_yloc[g], a->max_rows * sizeof(T));
-        if (e == hipSuccess) e = hipMalloc(&a->d_yall[g], (size_t)G * a->max_rows * sizeof(T));
+        if (e == hipSuccess) e = dev_alloc((void **)&a->d_x[g], ncols * sizeof(T));
+        if (e == hipSuccess) e = dev_alloc((void **)&a->d_yloc[g], a->max_rows * sizeof(T));
+        if (e == hipSuccess) e = dev_alloc((void **)&a->d_yall[g], (size_t)G * a->max_rows * sizeof(T));
         if (e == hipSuccess) e = hipMemset(a->d_yloc[g], 0, a->max_rows * sizeof(T));
         if (e != hipSuccess) {
             mg_csr_free(a);
