@@ -209,14 +209,34 @@ __device__ __forceinline__ void vector_rows(const uint32_t *__restrict__ rowptr,
             // select, not multiply by zero: an idle lane must not inject x's NaN/Inf
             acc[u] = live[u] ? es.v[u] * xv[u] : T(0);
         }
-        // rows with more than L entries
+        // rows with more than L entries: four more (colind, value) pairs per lane go
+        // out together (clamped addresses, selects on the products) so that a long
+        // row costs a memory round trip per 4*L entries, not per L
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            for (uint32_t q = rs.p[u] + L; q < rs.e[u]; q += L) {
-                const uint32_t cc = load_stream(colind + q);
-                const T vv = load_stream(vals + q);
-                const T xv = INLDS ? xw[cc - cbase] : x[cc];
-                acc[u] = __builtin_fma(vv, xv, acc[u]);
+            uint32_t q = rs.p[u] + L;
+            const uint32_t e = rs.e[u];
+            while (__any(q < e)) {   // wave-uniform trip count (lanes of other rows idle along)
+                uint32_t cc[4];
+                T vv[4], xv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t qq = min(q + k * L, last_nz);
+                    cc[k] = load_stream(colind + qq);
+                    vv[k] = load_stream(vals + qq);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool live4 = q + k * L < e;
+                    const uint32_t c4 = live4 ? cc[k] : cbase;
+                    xv[k] = INLDS ? xw[c4 - cbase] : x[c4];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    keep_unconditional(xv[k]);
+                    if (q + k * L < e) acc[u] = __builtin_fma(vv[k], xv[k], acc[u]);
+                }
+                q += 4 * L;
             }
         }
 #pragma unroll

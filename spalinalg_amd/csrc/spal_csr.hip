@@ -410,8 +410,11 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
 int csr_plan_build(spal_csr *a) {
     CsrPlan &p = a->plan;
     const double mean = a->nrows ? (double)a->nnz / (double)a->nrows : 0.0;
-    if (!p.user_lanes) p.lanes_per_row = pick_lanes(mean);
-    if (!p.user_unroll) p.unroll = 4;
+    // vector kernel geometry, from measurements (tools/lab_ab.py): one lane per entry
+    // up to 64 entries per row; longer rows loop in batches of 4 L entries per
+    // lane group, which 16 lanes per row keep busiest (128/row: 65 %, L = 64: 38 %)
+    if (!p.user_lanes) p.lanes_per_row = mean > 64.0 ? 16 : pick_lanes(mean);
+    if (!p.user_unroll) p.unroll = (mean > 64.0 && mean <= 160.0) ? 2 : 4;
     if (!p.user_threads) p.threads = 1024;
     if (a->d_desc) {
         SPAL_HIP_TRY(dev_free(a->d_desc));

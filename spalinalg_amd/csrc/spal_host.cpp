@@ -143,13 +143,13 @@ static int gen_banded(uint64_t nrows, uint64_t ncols, uint32_t per_row, uint64_t
     if (!rowptr || !colind || !values)
         return fail(SPAL_ERR_INVALID_ARGUMENT, "gen_banded: null output");
     if (nrows == 0 || ncols == 0 || per_row == 0 || window == 0 || window > ncols ||
-        per_row > window || per_row > 64)
+        per_row > window || per_row > 256)
         return fail(SPAL_ERR_INVALID_ARGUMENT,
-                    "gen_banded: need 0 < per_row <= min(window, 64), window <= ncols");
+                    "gen_banded: need 0 < per_row <= min(window, 256), window <= ncols");
     if (row_begin > row_end || row_end > nrows)
         return fail(SPAL_ERR_INVALID_ARGUMENT, "gen_banded: bad row range");
     parallel_for(row_end - row_begin, [&](uint64_t b, uint64_t e, unsigned) {
-        uint64_t cols[64];
+        uint64_t cols[256];
         for (uint64_t local = b; local < e; ++local) {
             const uint64_t row = row_begin + local;
             SplitMix rng(seed ^ (ROW_MULT * (row + 1)));

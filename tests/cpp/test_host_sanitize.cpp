@@ -54,7 +54,7 @@ int main() {
         CHECK(spal_csr_validate(n, n, rp.data(), n + 1, ci.data(), n * 14, n * 14, &reason) == SPAL_OK);
         CHECK(spal_gen_banded_csr_f64(n, n, 14, n, 1, rp.data(), ci.data(), va.data()) == SPAL_OK);       // window == ncols
         CHECK(spal_gen_banded_csr_f64(n, n, 14, n + 1, 1, rp.data(), ci.data(), va.data()) == SPAL_ERR_INVALID_ARGUMENT);
-        CHECK(spal_gen_banded_csr_f64(n, n, 65, n, 1, rp.data(), ci.data(), va.data()) == SPAL_ERR_INVALID_ARGUMENT);
+        CHECK(spal_gen_banded_csr_f64(n, n, 257, n, 1, rp.data(), ci.data(), va.data()) == SPAL_ERR_INVALID_ARGUMENT);
         std::vector<uint64_t> srp(101), sci(100 * 14);
         std::vector<float> sva(100 * 14);
         CHECK(spal_gen_banded_csr_rows_f32(n, n, 14, 64, 1, n - 100, n, srp.data(), sci.data(), sva.data()) == SPAL_OK);
