@@ -6,7 +6,7 @@
 // (hardware f64/f32 atomics), so parity with the sequential CPU order is to
 // rounding (<= 1e-10 relative, tested), not bitwise.
 //
-// Two scatter paths in one launch, chosen per SUPER-TILE of 1024 columns:
+// Two scatter paths in one launch, chosen per SUPER-TILE of 512 columns:
 //   LDS-privatised : the rows a super-tile touches form a window
 //                    [rmin, rmax]; when it fits LDS the adds go to an LDS copy
 //                    of that window (ds_add_f64: conflicts cost cycles, not
@@ -21,7 +21,7 @@
 namespace spal {
 
 constexpr int kCscBlock = 256;
-constexpr int kCscCols = 1024;                 // columns per super-tile
+constexpr int kCscCols = 512;                  // columns per super-tile
 constexpr uint32_t kCscWindowBytes = 48 * 1024;  // LDS y window budget (+ 8 KiB x tile)
 constexpr uint32_t kCscModeGlobal = 0, kCscModeLds = 1;
 

@@ -140,7 +140,7 @@ struct spal_csc {
     uint32_t *d_rowind = nullptr;  // nnz (+pad)
     void *d_values = nullptr;      // nnz (+pad)
     uint32_t *d_meta = nullptr;    // nnz (+pad): (row - window base) | (col - tile base) << 16
-    uint4 *d_desc = nullptr;       // per 1024-column super-tile {window base row, length, mode, 0}
+    uint4 *d_desc = nullptr;       // per 512-column super-tile {window base row, length, mode, 0}
     uint32_t nblocks = 0;
     uint32_t lds_entries = 0;      // largest LDS y window (elements); 0 = global scatter only
     double lds_col_fraction = 0.0;
