@@ -6,11 +6,14 @@
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over the whole matrix with every input
-already resident in HBM: each rank runs the HIP kernel on its row range, then
-(N > 1) the y slices are all-gathered over RCCL so that every rank holds the
-complete y.  x is broadcast ONCE from rank 0 before the timed region (its time
-is reported as x_bcast_ms).  The matrix is fixed as N grows ("scaling":
-"strong").  value = 2*nnz / time per step, whole job.
+already resident in HBM: each rank runs the HIP kernel on its row range; with
+N > 1 the ranks then exchange what the next product needs (--exchange: by
+default the halo of y each rank's rows reference, point-to-point; or an
+all-gather of the whole y).  x is broadcast ONCE from rank 0 before the timed
+region (x_bcast_ms) and, in halo mode, the y slices are all-gathered once at
+the end of the timed region.  The matrix is fixed as N grows ("scaling":
+"strong").  value = 2*nnz / time per step, whole job; compute_only and
+allgather_every_step give the other two readings of the same run.
 
 Rank 0 prints ONE JSON line.  `roofline` is computed from the ALGORITHMIC
 bytes of the rank-local launch (SURVEY.md section 8d:
@@ -51,10 +54,13 @@ def parse():
                     help="torch.distributed backend; gloo only to rehearse the N > 1 path on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
-    ap.add_argument("--exchange", default="allgather", choices=["allgather", "halo"],
-                    help="N > 1 only: per-step exchange of y. allgather (default, what BASELINE's north_star "
-                         "describes: every rank ends with the whole y) or halo (SURVEY 8f-4: each rank receives "
-                         "only the entries its rows reference; banded shards: +-W/2 from the neighbours)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "allgather", "halo"],
+                    help="N > 1 only: what moves between the GPUs.  halo: per step every rank receives only the "
+                         "entries of y its rows reference as columns (point-to-point over xGMI; banded shards: "
+                         "+-W/2 from the neighbours), and the y slices are all-gathered ONCE at the end of the "
+                         "timed region (north_star: 'x broadcast once ... y slices gathered at the end').  "
+                         "allgather: the whole y is all-gathered after every step.  auto (default): halo when the "
+                         "halo is at most a quarter of a slice and its plan succeeded on every rank, else allgather")
     return ap.parse_args()
 
 
@@ -270,10 +276,25 @@ def main():
     plan = dev.describe()
 
     op = RowPartitionedSpmv.from_shard(dev, bounds, rank, world, device)
-    if world > 1 and args.exchange == "halo":
-        if nrows != ncols:
-            sys.exit("--exchange halo needs a square matrix (y feeds back as x)")
-        op.plan_halo(int(ci.min()), int(ci.max()) + 1)
+    exchange = "none" if world == 1 else args.exchange
+    if world > 1 and exchange in ("auto", "halo"):
+        ok = 1
+        try:
+            if nrows != ncols:
+                raise ValueError("halo exchange needs a square matrix (y feeds back as x)")
+            op.plan_halo(int(ci.min()), int(ci.max()) + 1)
+            small = op.halo_bytes * 4 <= (r1 - r0) * esz
+        except Exception as exc:  # noqa: BLE001  (every rank must still reach the agreement below)
+            ok, small = 0, False
+            print(f"[rank {rank}] halo plan failed: {exc}", file=sys.stderr)
+        agree = torch.tensor([ok, int(small)], dtype=torch.int32, device=device)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree[0]) == 0:
+            if args.exchange == "halo":
+                sys.exit("--exchange halo: the halo plan failed (see stderr)")
+            exchange = "allgather"
+        elif args.exchange == "auto":
+            exchange = "halo" if int(agree[1]) else "allgather"
 
     # ---- x: generated on rank 0, broadcast once over RCCL
     if rank == 0:
@@ -288,13 +309,28 @@ def main():
     torch.cuda.synchronize()
     x_bcast_ms = (time.perf_counter() - tb) * 1e3 if world > 1 else 0.0
     y = torch.empty(nrows, dtype=t_dt, device=device)
+    if exchange == "halo":
+        # dry run of one halo step; any rank failing sends everyone to the all-gather
+        ok = 1
+        try:
+            op.spmv_halo(x, y)
+            torch.cuda.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            ok = 0
+            print(f"[rank {rank}] halo exchange failed: {exc}", file=sys.stderr)
+        agree = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree[0]) == 0:
+            if args.exchange == "halo":
+                sys.exit("--exchange halo: the halo exchange failed (see stderr)")
+            exchange = "allgather"
     # setup: let the library pick between its kernel variants on this device (results are identical)
     plan = dev.autotune(x, op.y_local[: r1 - r0], iters=30)
 
     def step():
         if world == 1:
             dev.spmv_torch(x, out=y)       # y is the rank's (= the whole) slice
-        elif args.exchange == "halo":
+        elif exchange == "halo":
             op.spmv_halo(x, y)
         else:
             op.spmv(x, y)
@@ -310,6 +346,8 @@ def main():
     e0.record()
     for _ in range(args.steps):
         step()
+    if exchange == "halo":
+        op.gather_y(y)          # "per-GPU y slices gathered at the end": once, inside the timed region
     e1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -322,6 +360,24 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     total_ms = float(elapsed.item())
     ms_per_step = total_ms / args.steps
+
+    # ---- for transparency: the same K steps with an all-gather of y after EVERY step
+    allgather_ms = None
+    if exchange == "halo":
+        for _ in range(min(args.warmup, 5)):
+            op.spmv(x, y)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(args.steps):
+            op.spmv(x, y)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        ag = torch.tensor([(time.perf_counter() - ta) * 1e3 / args.steps], dtype=torch.float64, device=device)
+        dist.all_reduce(ag, op=dist.ReduceOp.MAX)
+        allgather_ms = float(ag.item())
 
     # ---- the dominant kernel alone (HIP events on the launch stream = torch's current stream)
     k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -395,11 +451,13 @@ def main():
                         + (f" W={window}" if args.dist == "banded" else "")
                         + f" (BASELINE configs[{2 if args.config == 3 else 1}]), "
                         + ("single GPU" if world == 1 else
-                           f"rows partitioned over {world} GPUs, x bcast once, "
-                           + ("y all-gather per step (RCCL)" if args.exchange == "allgather" else
-                              f"halo exchange per step (RCCL send/recv, {getattr(op, 'halo_bytes', 0)} B received per rank)")),
+                           f"rows partitioned over {world} GPUs, x bcast once (RCCL), "
+                           + ("y all-gather after every step (RCCL)" if exchange == "allgather" else
+                              f"per step a halo exchange (RCCL send/recv, {getattr(op, 'halo_bytes', 0)} B received "
+                              f"per rank), y slices all-gathered once at the end of the timed region")),
             "nrows": nrows, "ncols": ncols, "nnz": nnz, "algorithmic_index_bits": 32,
             "partition": "none" if world == 1 else f"rows/{world}",
+            "exchange": exchange,
             "plan": plan,
         },
         "achieved_hbm_pct": round(100.0 * whole_bytes / (ms_per_step * 1e-3) / (world * sp.synth.HBM_PEAK_BYTES_PER_S), 2),
@@ -422,6 +480,9 @@ def main():
             "unit": "GFLOP/s",
         },
         "x_bcast_ms": round(x_bcast_ms, 4),
+        "allgather_every_step": None if allgather_ms is None else {
+            "ms_per_step": round(allgather_ms, 6),
+            "value": round(sp.synth.spmv_flops(nnz) / (allgather_ms * 1e-3) / 1e9, 3), "unit": "GFLOP/s"},
         "setup_s": {"generate": round(t_gen, 2), "validate_narrow_upload_plan": round(t_upload, 2)},
     }
 

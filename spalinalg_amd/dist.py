@@ -135,6 +135,22 @@ class RowPartitionedSpmv:
             w.wait()
         return y_vec
 
+    def gather_y(self, y_full):
+        """all-gather of the slices computed by the last product (self.y_local)
+        into y_full on every rank."""
+        dist = self.torch.distributed
+        if self.world == 1:
+            y_full.copy_(self.y_local[: self.nrows])
+            return y_full
+        if self.equal:
+            dist.all_gather_into_tensor(y_full, self.y_local, group=self.group)
+        else:
+            dist.all_gather_into_tensor(self._gather, self.y_local, group=self.group)
+            for g in range(self.world):
+                a, b = int(self.bounds[g]), int(self.bounds[g + 1])
+                y_full[a:b].copy_(self._gather[g * self.max_rows: g * self.max_rows + (b - a)])
+        return y_full
+
     def spmv(self, x, y_full):
         """y_full (nrows, on every rank) = A * x."""
         dist = self.torch.distributed

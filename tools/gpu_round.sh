@@ -37,7 +37,7 @@ for s in "$@"; do
     ab)     step 600 lab_ab.log python tools/lab_ab.py $AB_ARGS ;;
     bench)  step 400 bench.log python bench.py ;;
     rehearse2) step 600 rehearse2.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29631 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --same-device --config 2 ;;
-    rehearse2h) step 600 rehearse2h.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29632 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --same-device --config 2 --exchange halo ;;
+    rehearse2h) step 600 rehearse2h.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29632 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --same-device --config 2 --exchange auto ;;
     rehearse1) step 600 rehearse1.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29633 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline ;;
     bench4) step 400 bench4.log python bench.py --config 4 ;;
     bench5) step 600 bench5.log python bench.py --config 5 ;;
