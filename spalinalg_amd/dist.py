@@ -121,9 +121,8 @@ class RowPartitionedSpmv:
         their owners.  x and y_vec are full-length buffers; only the own slice
         and the halo regions hold meaningful data."""
         dist = self.torch.distributed
-        own = y_vec[self.r0:self.r1]
-        self.local_spmv(x, self.y_local)
-        own.copy_(self.y_local[: self.r1 - self.r0])
+        self.local_spmv(x, y_vec[self.r0:self.r1])   # the kernel writes the own slice in place
+        self._y_in = y_vec                           # (gather_y reads the slice from here)
         if self.world == 1 or not (self.halo_recv or self.halo_send):
             return y_vec
         ops = []
@@ -139,6 +138,10 @@ class RowPartitionedSpmv:
         """all-gather of the slices computed by the last product (self.y_local)
         into y_full on every rank."""
         dist = self.torch.distributed
+        src = getattr(self, "_y_in", None)
+        if src is not None:      # the last product was a halo step: its slice lives in the vector itself
+            self.y_local[: self.r1 - self.r0].copy_(src[self.r0:self.r1])
+            self._y_in = None
         if self.world == 1:
             y_full.copy_(self.y_local[: self.nrows])
             return y_full
@@ -155,6 +158,7 @@ class RowPartitionedSpmv:
         """y_full (nrows, on every rank) = A * x."""
         dist = self.torch.distributed
         self.local_spmv(x, self.y_local)
+        self._y_in = None
         if self.world == 1:
             y_full.copy_(self.y_local[: self.nrows])
             return y_full
