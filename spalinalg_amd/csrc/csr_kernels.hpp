@@ -23,8 +23,9 @@ namespace spal {
 constexpr int kWave = 64;
 
 // how a row block gets its x (desc[b].z): gathered from global memory, from an
-// LDS-staged window, or (stream kernel) LDS window + 16-bit relative columns
-constexpr uint32_t kModeVectorGlobal = 0, kModeVectorLds = 1, kModeStream = 2;
+// LDS-staged window, (stream kernel) LDS window + 16-bit relative columns, or
+// (stream kernel, window too wide for LDS) x gathered from global with 32-bit columns
+constexpr uint32_t kModeVectorGlobal = 0, kModeVectorLds = 1, kModeStream = 2, kModeStreamGlobal = 3;
 
 // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the
 // blocks that share an XCD).  Map them so that each XCD owns one contiguous
@@ -169,7 +170,7 @@ __device__ __forceinline__ EntryStep<T, U> load_entries(const uint32_t *__restri
     return o;
 }
 
-template <typename T, int L, int U, bool INLDS, bool USE_DPP, int BLOCK>
+template <typename T, int L, int U, bool INLDS, bool USE_DPP, int BLOCK, int LB = 1>
 __device__ __forceinline__ void vector_rows(const uint32_t *__restrict__ rowptr,
                                             const uint32_t *__restrict__ colind,
                                             const T *__restrict__ vals, const T *__restrict__ x,
@@ -209,34 +210,49 @@ __device__ __forceinline__ void vector_rows(const uint32_t *__restrict__ rowptr,
             // select, not multiply by zero: an idle lane must not inject x's NaN/Inf
             acc[u] = live[u] ? es.v[u] * xv[u] : T(0);
         }
-        // rows with more than L entries: four more (colind, value) pairs per lane go
-        // out together (clamped addresses, selects on the products) so that a long
-        // row costs a memory round trip per 4*L entries, not per L
+        // rows with more than L entries
+        if constexpr (LB == 1) {
+            // one more (colind, value) pair per lane and iteration: the lean form, used
+            // wherever rows seldom exceed L (keeps the hot loop's registers out of scratch)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            uint32_t q = rs.p[u] + L;
-            const uint32_t e = rs.e[u];
-            while (__any(q < e)) {   // wave-uniform trip count (lanes of other rows idle along)
-                uint32_t cc[4];
-                T vv[4], xv[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t qq = min(q + k * L, last_nz);
-                    cc[k] = load_stream(colind + qq);
-                    vv[k] = load_stream(vals + qq);
+            for (int u = 0; u < U; ++u) {
+                for (uint32_t q = rs.p[u] + L; q < rs.e[u]; q += L) {
+                    const uint32_t cc = load_stream(colind + q);
+                    const T vv = load_stream(vals + q);
+                    const T xv = INLDS ? xw[cc - cbase] : x[cc];
+                    acc[u] = __builtin_fma(vv, xv, acc[u]);
                 }
+            }
+        } else {
+            // long rows (planner: mean above 64 entries): LB more pairs per lane go out
+            // together (clamped addresses, selects on the products), so a row costs a
+            // memory round trip per LB*L entries, not per L
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool live4 = q + k * L < e;
-                    const uint32_t c4 = live4 ? cc[k] : cbase;
-                    xv[k] = INLDS ? xw[c4 - cbase] : x[c4];
-                }
+            for (int u = 0; u < U; ++u) {
+                uint32_t q = rs.p[u] + L;
+                const uint32_t e = rs.e[u];
+                while (__any(q < e)) {   // wave-uniform trip count (lanes of other rows idle along)
+                    uint32_t cc[LB];
+                    T vv[LB], xv[LB];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    keep_unconditional(xv[k]);
-                    if (q + k * L < e) acc[u] = __builtin_fma(vv[k], xv[k], acc[u]);
+                    for (int k = 0; k < LB; ++k) {
+                        const uint32_t qq = min(q + k * L, last_nz);
+                        cc[k] = load_stream(colind + qq);
+                        vv[k] = load_stream(vals + qq);
+                    }
+#pragma unroll
+                    for (int k = 0; k < LB; ++k) {
+                        const bool live4 = q + k * L < e;
+                        const uint32_t c4 = live4 ? cc[k] : cbase;
+                        xv[k] = INLDS ? xw[c4 - cbase] : x[c4];
+                    }
+#pragma unroll
+                    for (int k = 0; k < LB; ++k) {
+                        keep_unconditional(xv[k]);
+                        if (q + k * L < e) acc[u] = __builtin_fma(vv[k], xv[k], acc[u]);
+                    }
+                    q += LB * L;
                 }
-                q += 4 * L;
             }
         }
 #pragma unroll
@@ -255,7 +271,7 @@ __device__ __forceinline__ void vector_rows(const uint32_t *__restrict__ rowptr,
     }
 }
 
-template <typename T, int L, int U, bool LDSX, bool USE_DPP, int BLOCK>
+template <typename T, int L, int U, bool LDSX, bool USE_DPP, int BLOCK, int LB = 1>
 __global__ __launch_bounds__(BLOCK, 8) void csr_spmv_vector(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
     const T *__restrict__ vals, const T *__restrict__ x, T *__restrict__ y,
@@ -275,13 +291,13 @@ __global__ __launch_bounds__(BLOCK, 8) void csr_spmv_vector(
         if (d.z == kModeVectorLds) {
             stage_window<T, BLOCK>(xw, x, d.x, d.y);
             __syncthreads();
-            vector_rows<T, L, U, true, USE_DPP, BLOCK>(rowptr, colind, vals, x, xw, y, row0, row1,
-                                                       d.x, last_nz);
+            vector_rows<T, L, U, true, USE_DPP, BLOCK, LB>(rowptr, colind, vals, x, xw, y, row0, row1,
+                                                           d.x, last_nz);
             return;
         }
     }
-    vector_rows<T, L, U, false, USE_DPP, BLOCK>(rowptr, colind, vals, x, nullptr, y, row0, row1, 0u,
-                                                last_nz);
+    vector_rows<T, L, U, false, USE_DPP, BLOCK, LB>(rowptr, colind, vals, x, nullptr, y, row0, row1, 0u,
+                                                    last_nz);
 }
 
 // ---- the "stream" kernel: one lane per row, products parked in LDS ----------
@@ -406,12 +422,125 @@ __device__ __forceinline__ void stream_compute(const StreamTile<T> &t, const T *
     }
 }
 
+// ---- stream tiles whose x window does not fit LDS ------------------------------
+// Same tiles, same lane-per-row sums (still bit-identical to the reference
+// order); the columns come from the 32-bit array and x is gathered from global
+// memory (L2 / Infinity Cache), all gathers of a tile in flight together.
+template <typename T>
+struct StreamTileG {
+    typename Pair<T>::type v[kStreamSteps];
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+    u32x2 c[kStreamSteps];     // two 32-bit columns
+    uint32_t rp0, rp1, start, steps;
+};
+
+template <typename T, int RPT>
+__device__ __forceinline__ void stream_load_g(StreamTileG<T> &t, const uint32_t *__restrict__ rowptr,
+                                              const uint32_t *__restrict__ colind,
+                                              const T *__restrict__ vals, uint32_t row0,
+                                              uint32_t row1, uint32_t b, uint32_t e, uint32_t lane) {
+    using pair_t = typename Pair<T>::type;
+    const uint32_t rlast = min(row0 + (uint32_t)RPT, row1);
+    t.start = b & ~1u;
+    t.steps = (e - t.start + 127u) >> 7;
+    const uint32_t e0 = t.start + lane * 2;
+#pragma unroll
+    for (int j = 0; j < kStreamSteps; ++j) {
+        if ((uint32_t)j < t.steps) {  // uniform
+            t.v[j] = __builtin_nontemporal_load(reinterpret_cast<const pair_t *>(vals + e0 + j * 128));
+            t.c[j] = __builtin_nontemporal_load(
+                reinterpret_cast<const typename StreamTileG<T>::u32x2 *>(colind + e0 + j * 128));
+        }
+    }
+    t.rp0 = rowptr[min(row0 + lane, rlast)];
+    t.rp1 = rowptr[min(row0 + lane + 1, rlast)];
+}
+
+template <typename T, int RPT>
+__device__ __forceinline__ void stream_compute_g(const StreamTileG<T> &t, const T *__restrict__ x,
+                                                 uint32_t cmax, T *prod, T *__restrict__ y,
+                                                 uint32_t row0, uint32_t row1, uint32_t lane,
+                                                 bool nt_store) {
+    using pair_t = typename Pair<T>::type;
+    pair_t *prod2 = reinterpret_cast<pair_t *>(prod);
+    T xa[kStreamSteps], xb[kStreamSteps];
+#pragma unroll
+    for (int j = 0; j < kStreamSteps; ++j) {
+        if ((uint32_t)j < t.steps) {  // uniform; entries past the tile's end: clamp into x
+            xa[j] = x[min(t.c[j].x, cmax)];
+            xb[j] = x[min(t.c[j].y, cmax)];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kStreamSteps; ++j) {
+        if ((uint32_t)j < t.steps) {
+            pair_t p;
+            p.x = t.v[j].x * xa[j];
+            p.y = t.v[j].y * xb[j];
+            prod2[j * 64 + lane] = p;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t off = t.rp0 - t.start;
+    const uint32_t len = t.rp1 - t.rp0;
+    T acc = T(0);
+    if (len) {
+        acc = prod[off];
+        uint32_t k = 1;
+        for (; k + 4 <= len; k += 4) {
+            const T p0 = prod[off + k], p1 = prod[off + k + 1], p2 = prod[off + k + 2],
+                    p3 = prod[off + k + 3];
+            acc = acc + p0;
+            acc = acc + p1;
+            acc = acc + p2;
+            acc = acc + p3;
+        }
+        for (; k < len; ++k) acc = acc + prod[off + k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (row0 + lane < min(row0 + (uint32_t)RPT, row1)) {
+        if (nt_store) __builtin_nontemporal_store(acc, &y[row0 + lane]);
+        else y[row0 + lane] = acc;
+    }
+}
+
+// one super-tile in stream-global mode (no window, no workgroup barrier)
+template <typename T, int TPW, int RPT>
+__device__ __forceinline__ void stream_global_super_tile(const uint32_t *__restrict__ rowptr,
+                                                         const uint32_t *__restrict__ colind,
+                                                         const T *__restrict__ vals,
+                                                         const T *__restrict__ x, T *__restrict__ y,
+                                                         T *prod, uint32_t row0, uint32_t row1,
+                                                         uint32_t ncols, bool nt_store) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = threadIdx.x / kWave;
+    const uint32_t wrow = row0 + wave * (TPW * (uint32_t)RPT);
+    if (wrow >= row1) return;  // wave-uniform
+    const uint32_t tb_lane = rowptr[min(wrow + min(lane, (uint32_t)TPW) * (uint32_t)RPT, row1)];
+    uint32_t tb[TPW + 1];
+#pragma unroll
+    for (int k = 0; k <= TPW; ++k) tb[k] = __builtin_amdgcn_readlane(tb_lane, k);
+    StreamTileG<T> cur, nxt;
+    stream_load_g<T, RPT>(cur, rowptr, colind, vals, wrow, row1, tb[0], tb[1], lane);
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        const uint32_t r0 = wrow + k * (uint32_t)RPT;
+        if (r0 >= row1) break;  // wave-uniform
+        const uint32_t rn = r0 + (uint32_t)RPT;
+        const bool more = (k + 1 < TPW) && rn < row1;
+        if (more) stream_load_g<T, RPT>(nxt, rowptr, colind, vals, rn, row1, tb[k + 1],
+                                        tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
+        stream_compute_g<T, RPT>(cur, x, ncols - 1, prod, y, r0, row1, lane, nt_store);
+        if (more) cur = nxt;
+    }
+}
+
 // desc[b] = {window base column, window length, mode, 0}
 template <typename T, int L, int U, bool USE_DPP, int TPW, int RPT>
 __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
     const uint16_t *__restrict__ col16, const T *__restrict__ vals, const T *__restrict__ x,
-    T *__restrict__ y, const uint4 *__restrict__ desc, uint32_t nrows, uint32_t nnz,
+    T *__restrict__ y, const uint4 *__restrict__ desc, uint32_t nrows, uint32_t ncols, uint32_t nnz,
     uint32_t nblocks, uint32_t per_xcd, uint32_t flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
     const bool nt_store = flags & 1u;
@@ -457,6 +586,12 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
         }
         return;
     }
+    if (d.z == kModeStreamGlobal) {
+        stream_global_super_tile<T, TPW, RPT>(rowptr, colind, vals, x, y,
+                                              prod_all + (threadIdx.x / kWave) * kStreamTileNnz, row0,
+                                              row1, ncols, nt_store);
+        return;
+    }
     const uint32_t last_nz = nnz - 1;
     if (d.z == kModeVectorLds) {
         stage_window<T, kStreamBlock>(xw, x, d.x, d.y);
@@ -483,7 +618,7 @@ template <typename T, int L, int U, bool USE_DPP, int TPW, int RPT>
 __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
     const uint16_t *__restrict__ col16, const T *__restrict__ vals, const T *__restrict__ x,
-    T *__restrict__ y, const uint4 *__restrict__ desc, uint32_t nrows, uint32_t nnz,
+    T *__restrict__ y, const uint4 *__restrict__ desc, uint32_t nrows, uint32_t ncols, uint32_t nnz,
     uint32_t nblocks, uint32_t per_xcd, uint32_t chunk, uint32_t flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
     const bool nt_store = flags & 1u;
@@ -559,6 +694,10 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
                 }
             }
             cur_valid = fetched_next;
+        } else if (d.z == kModeStreamGlobal) {
+            cur_valid = false;   // (no window involved: no barrier needed)
+            stream_global_super_tile<T, TPW, RPT>(rowptr, colind, vals, x, y, prod, row0, row1, ncols,
+                                                  nt_store);
         } else {
             cur_valid = false;
             __syncthreads();

@@ -202,12 +202,12 @@ static hipError_t raise_lds_cap(K kern, int device, size_t lds, std::atomic<uint
     return e;
 }
 
-template <typename T, int L, int U, bool LDSX, int BLOCK>
+template <typename T, int L, int U, bool LDSX, int BLOCK, int LB = 1>
 static hipError_t launch_vec(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     const CsrPlan &p = a->plan;
     const uint32_t per_xcd = (p.nblocks + 7) / 8;
     const size_t lds = LDSX ? (size_t)p.lds_entries * sizeof(T) : 0;
-    auto kern = csr_spmv_vector<T, L, U, LDSX, true, BLOCK>;
+    auto kern = csr_spmv_vector<T, L, U, LDSX, true, BLOCK, LB>;
     static std::atomic<uint64_t> configured{0};
     hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
     if (e != hipSuccess) return e;
@@ -219,6 +219,11 @@ static hipError_t launch_vec(const spal_csr *a, const void *x, void *y, hipStrea
 
 template <typename T, int L, int U, bool LDSX>
 static hipError_t launch_vec_block(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    if constexpr (L == 16) {  // the long-row form exists for 16 lanes per row only (the planner's choice)
+        if (a->plan.long_rows)
+            return a->plan.threads == 1024 ? launch_vec<T, L, U, LDSX, 1024, 4>(a, x, y, st)
+                                           : launch_vec<T, L, U, LDSX, 512, 4>(a, x, y, st);
+    }
     return a->plan.threads == 1024 ? launch_vec<T, L, U, LDSX, 1024>(a, x, y, st)
                                    : launch_vec<T, L, U, LDSX, 512>(a, x, y, st);
 }
@@ -252,7 +257,7 @@ static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, h
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
                        a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc,
-                       (uint32_t)a->nrows, (uint32_t)a->nnz, p.nblocks, per_xcd,
+                       (uint32_t)a->nrows, (uint32_t)a->ncols, (uint32_t)a->nnz, p.nblocks, per_xcd,
                        (uint32_t)(p.nt_store ? 1 : 0));
     return hipGetLastError();
 }
@@ -273,7 +278,7 @@ static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, voi
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(used * 8), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
                        a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc,
-                       (uint32_t)a->nrows, (uint32_t)a->nnz, p.nblocks, per_xcd, chunk,
+                       (uint32_t)a->nrows, (uint32_t)a->ncols, (uint32_t)a->nnz, p.nblocks, per_xcd, chunk,
                        (uint32_t)(p.nt_store ? 1 : 0));
     return hipGetLastError();
 }
@@ -393,7 +398,13 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
         }
         const uint32_t cb = w.x & ~(valign - 1);
         const uint32_t len = w.y - cb;
-        if (len > budget) continue;  // vector kernel, x from global
+        if (len > budget) {  // window too wide for LDS: x through L2
+            if (ok[b] && a->plan.stream_global) {
+                desc[b] = make_uint4(0, 0, kModeStreamGlobal, 0);
+                rows_stream += rows;
+            }
+            continue;        // (else: vector kernel, x from global)
+        }
         cap = std::max(cap, len);
         if (ok[b] && len <= 65536u) {
             desc[b] = make_uint4(cb, len, kModeStream, 0);
@@ -414,6 +425,7 @@ int csr_plan_build(spal_csr *a) {
     // up to 64 entries per row; longer rows loop in batches of 4 L entries per
     // lane group, which 16 lanes per row keep busiest (128/row: 65 %, L = 64: 38 %)
     if (!p.user_lanes) p.lanes_per_row = mean > 64.0 ? 16 : pick_lanes(mean);
+    p.long_rows = mean > 64.0 ? 1 : 0;
     if (!p.user_unroll) p.unroll = (mean > 64.0 && mean <= 160.0) ? 2 : 4;
     if (!p.user_threads) p.threads = 1024;
     if (a->d_desc) {
@@ -464,7 +476,7 @@ int csr_plan_build(spal_csr *a) {
             p.stream_row_fraction = best_frac;
             uint64_t lds_rows = 0;
             for (uint32_t b = 0; b < p.nblocks; ++b)
-                if (best_desc[b].z != kModeVectorGlobal)
+                if (best_desc[b].z == kModeVectorLds || best_desc[b].z == kModeStream)
                     lds_rows += std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
             p.lds_row_fraction = (double)lds_rows / (double)a->nrows;
             SPAL_HIP_TRY(dev_alloc((void **)&a->d_desc, (size_t)p.nblocks * sizeof(uint4)));
@@ -869,6 +881,9 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         else if (value != 1 && value != 2 && value != 4)
             return fail(SPAL_ERR_INVALID_ARGUMENT, "unroll must be 1, 2 or 4");
         else { p.unroll = (int)value; p.user_unroll = true; }
+    } else if (!strcmp(key, "stream_global")) {
+        if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "stream_global must be 0 or 1");
+        p.stream_global = (int)value;
     } else if (!strcmp(key, "nt_store")) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "nt_store must be 0 or 1");
         p.nt_store = (int)value;

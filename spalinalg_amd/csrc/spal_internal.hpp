@@ -83,11 +83,13 @@ struct CsrPlan {
     int user_kernel = 0;     // 0 = auto
     int lanes_per_row = 0;   // L in {2,4,8,16,32,64}
     int unroll = 1;          // row groups in flight per wave iteration
+    int long_rows = 0;       // vector kernel: batched rest-of-row loop (mean row length above 64)
     int threads = 512;       // workgroup size: 512 or 1024
     int tiles_per_wave = 4;  // stream kernel: tiles per wave (4 or 8)
     int rows_per_tile = 64;  // stream kernel: rows of a wave-tile (64, 32 or 16)
     int persistent = 0;      // stream kernel: fixed grid walking chunks of super-tiles
     int nt_store = 0;        // stream kernel: non-temporal stores of y
+    int stream_global = 1;   // stream kernel: tiles whose window exceeds LDS gather x from global
     int persistent_blocks = 512;  // its grid (2 workgroups per CU on 256 CUs)
     int rows_per_block = 0;  // R
     int lds_x = 0;           // stage the block's x window in LDS

@@ -135,6 +135,26 @@ def test_stream_kernel_narrow_tiles_bit_identical(oracle, maxlen, rpt, dtype):
         same(dev.spmv(x), d2["stream_row_fraction"])
 
 
+def test_stream_global_mode_bit_identical(oracle):
+    """column windows too wide for LDS: the stream kernel gathers x through L2
+    instead (32-bit columns), still summing each row in the reference order."""
+    n = 300_000
+    for window, dtype in ((20_000, np.float64), (None, np.float64), (30_000, np.float32)):
+        rp, ci, va = sp.synth.banded_csr(n, n, 14, window or n, 5, dtype=dtype)
+        x = sp.synth.vector(n, dtype=dtype)
+        dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+        d = dev.describe()
+        assert d["kernel"] == "stream" and d["stream_row_fraction"] == 1.0, d
+        assert d["lds_row_fraction"] < (0.05 if window else 1e-9), d     # (banded: only the clamped edges fit LDS)
+        y_ref = oracle.csr_spmv(rp, ci, va, x)
+        assert np.array_equal(dev.spmv(x), y_ref)
+        dev.set_option("persistent", 1)
+        assert np.array_equal(dev.spmv(x), y_ref)
+        dev.set_option("stream_global", 0)          # the old behaviour: vector kernel, global gathers
+        assert dev.describe()["kernel"] == "vector"
+        np.testing.assert_allclose(dev.spmv(x), y_ref, rtol=1e-10 if dtype == np.float64 else 1e-4, atol=1e-6)
+
+
 def test_long_rows_go_to_the_vector_kernel(oracle):
     rng = np.random.default_rng(140)
     nr, nc = 20_000, 5000
@@ -238,7 +258,7 @@ def test_config2_banded_and_uniform(oracle, dtype, window):
     dev = check(oracle, rp, ci, va, x, n)
     d = dev.describe()
     assert d["lds_x"] == (1 if window else 0)
-    assert d["kernel"] == ("stream" if window else "vector")
+    assert d["kernel"] == "stream"          # uniform columns: stream tiles, x through L2
     check(oracle, rp, ci, va, x, n, kernel=1)
 
 
@@ -264,6 +284,7 @@ def test_autotune_keeps_results(oracle):
     # a matrix the vector kernel handles: nothing to tune, still fine
     rp, ci, va = sp.synth.banded_csr(n, n, 14, n, 9)
     dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    dev.set_option("kernel", 1)
     assert dev.autotune(xd, yd, iters=2)["autotune_us"] == [0.0] * 4
 
 

@@ -22,9 +22,9 @@ for s in "$@"; do
     tests)  step 900 pytest_gpu.log python -m pytest tests -x -q -m gpu ;;
     testsall) step 900 pytest_gpu.log python -m pytest tests -q -m gpu ;;
     lab)    step 600 lab.log python tools/lab_csr.py --out gpurun_out/lab.json ;;
-    other)  step 900 lab_other.log python tools/lab_other.py $OTHER_ARGS ;;
+    other)  step 900 lab_other.log python tools/lab_other.py ${OTHER_ARGS:-} ;;
     profother) export TMPDIR=/tmp
-            step 600 prof_other.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_other -o other -- python3 tools/lab_other.py $OTHER_ARGS ;;
+            step 600 prof_other.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_other -o other -- python3 tools/lab_other.py ${OTHER_ARGS:-} ;;
     prof45) export TMPDIR=/tmp
             step 400 prof4.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof4 -o c4 -- python3 bench.py --config 4 --steps 100 --warmup 10 --no-cpu-baseline
             step 600 prof5.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof5 -o c5 -- python3 bench.py --config 5 --steps 10 --warmup 2 --no-cpu-baseline
