@@ -12,7 +12,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspal_hip.so")
+# SPAL_HIP_LIB: developer override (A/B of differently built libraries, tools/)
+LIB_PATH = os.environ.get("SPAL_HIP_LIB") or os.path.join(_HERE, "lib", "libspal_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "spal.h")
 
 SPAL_OK = 0

@@ -143,14 +143,25 @@ static hipError_t exclusive_scan_u32(const uint32_t *in, uint32_t *out, uint64_t
 // --------------------------------------------------------------------------
 // stable LSD radix sort: (u32 key, u32 aux, T value), 8 bits per pass
 // --------------------------------------------------------------------------
-constexpr int kSortThreads = 256;
+#ifndef SPAL_SORT_THREADS
+#define SPAL_SORT_THREADS 256
+#endif
+#ifndef SPAL_SORT_XCD
+#define SPAL_SORT_XCD 1
+#endif
+#ifndef SPAL_SORT_ITEMS
+#define SPAL_SORT_ITEMS 16
+#endif
+constexpr int kSortThreads = SPAL_SORT_THREADS;           // scatter workgroup
 constexpr int kSortWaves = kSortThreads / 64;
-constexpr int kSortItems = 16;                            // per thread
+constexpr int kSortItems = SPAL_SORT_ITEMS;               // per thread
 constexpr int kSortTile = kSortThreads * kSortItems;      // 4096 entries per workgroup
-constexpr int kWaveChunk = 64 * kSortItems;               // 1024 consecutive entries per wave
+constexpr int kWaveChunk = 64 * kSortItems;               // consecutive entries per wave
+constexpr int kHistThreads = 256;
+constexpr int kHistItems = kSortTile / kHistThreads;
 
 // counts[d * nblk + blk] = number of keys of tile blk with digit d
-__global__ __launch_bounds__(kSortThreads) void radix_hist(const uint32_t *__restrict__ keys,
+__global__ __launch_bounds__(kHistThreads) void radix_hist(const uint32_t *__restrict__ keys,
                                                            uint64_t len, uint32_t shift,
                                                            uint32_t *__restrict__ counts,
                                                            uint32_t nblk) {
@@ -159,8 +170,8 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist(const uint32_t *__res
     __syncthreads();
     const uint64_t t0 = (uint64_t)blockIdx.x * kSortTile;
 #pragma unroll
-    for (int j = 0; j < kSortItems; ++j) {
-        const uint64_t i = t0 + (uint64_t)j * kSortThreads + threadIdx.x;
+    for (int j = 0; j < kHistItems; ++j) {
+        const uint64_t i = t0 + (uint64_t)j * kHistThreads + threadIdx.x;
         if (i < len) atomicAdd(&h[(keys[i] >> shift) & 0xffu], 1u);
     }
     __syncthreads();
@@ -180,7 +191,7 @@ template <typename T>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter(
     const uint32_t *__restrict__ kin, const uint32_t *__restrict__ ain, const T *__restrict__ vin,
     uint32_t *__restrict__ kout, uint32_t *__restrict__ aout, T *__restrict__ vout, uint64_t len,
-    uint32_t shift, const uint32_t *__restrict__ offs, uint32_t nblk) {
+    uint32_t shift, const uint32_t *__restrict__ offs, uint32_t nblk, uint32_t per_xcd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_sort_smem[];
     T *s_val = reinterpret_cast<T *>(spal_sort_smem);                       // kSortTile
     uint32_t *s_key = reinterpret_cast<uint32_t *>(s_val + kSortTile);      // kSortTile
@@ -190,12 +201,21 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(
     volatile uint32_t *cnt = s_aux + kSortTile;                             // [kSortWaves][256]
     uint32_t *s_start = const_cast<uint32_t *>(cnt) + kSortWaves * 256;      // [256] tile-local digit start
     uint32_t *s_delta = s_start + 256;                                       // [256] global - local
+    uint32_t *s_wsum = s_delta + 256;                                        // [4] digit-scan wave sums
 
+    // tiles that run side by side on one XCD are neighbours in tile order, so the
+    // partial cache lines they leave at the end of each digit's run meet in one L2
+#if SPAL_SORT_XCD
+    const uint32_t tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+#else
+    const uint32_t tile = blockIdx.x;
+#endif
+    if (tile >= nblk) return;  // block-uniform
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (uint32_t i = threadIdx.x; i < kSortWaves * 256; i += kSortThreads) cnt[i] = 0;
     __syncthreads();
 
-    const uint64_t tile0 = (uint64_t)blockIdx.x * kSortTile;
+    const uint64_t tile0 = (uint64_t)tile * kSortTile;
     const uint64_t w0 = tile0 + (uint64_t)w * kWaveChunk;
     const uint64_t lt = (1ull << lane) - 1ull;
     uint32_t key[kSortItems], aux[kSortItems], rank[kSortItems];
@@ -229,18 +249,28 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(
     // per digit: exclusive prefix over the waves; tile-local start of the digit;
     // distance between the digit's global run and its place in the tile
     {
-        const uint32_t d = threadIdx.x;  // 256 threads = 256 digits
-        uint32_t run = 0;
+        const uint32_t d = threadIdx.x;  // the first 256 threads (whole waves) take the 256 digits
+        uint32_t run = 0, inc = 0;
+        if (d < 256) {
 #pragma unroll
-        for (int ww = 0; ww < kSortWaves; ++ww) {
-            const uint32_t c = cnt[ww * 256 + d];
-            cnt[ww * 256 + d] = run;
-            run += c;
+            for (int ww = 0; ww < kSortWaves; ++ww) {
+                const uint32_t c = cnt[ww * 256 + d];
+                cnt[ww * 256 + d] = run;
+                run += c;
+            }
+            inc = wave_inclusive_scan(run);
+            if (lane == 63) s_wsum[w] = inc;
         }
-        uint32_t total;
-        const uint32_t start = block_exclusive_scan(run, &total);
-        s_start[d] = start;
-        s_delta[d] = offs[(uint64_t)d * nblk + blockIdx.x] - start;
+        __syncthreads();
+        if (d < 256) {
+            uint32_t base = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i)
+                if (i < w) base += s_wsum[i];
+            const uint32_t start = base + inc - run;
+            s_start[d] = start;
+            s_delta[d] = offs[(uint64_t)d * nblk + tile] - start;
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -280,7 +310,7 @@ struct SortBuffers {
 
 template <typename T>
 static size_t sort_lds_bytes() {
-    return (size_t)kSortTile * (sizeof(T) + 8) + (size_t)(kSortWaves * 256 + 512) * 4;
+    return (size_t)kSortTile * (sizeof(T) + 8) + (size_t)(kSortWaves * 256 + 512 + 4) * 4;
 }
 
 // Sorts by bits [lo_bit, lo_bit + nbits) of key, stably.  The first pass reads
@@ -296,7 +326,7 @@ static hipError_t radix_sort_bits(SortBuffers<T> &b, uint64_t len, uint32_t lo_b
     const size_t lds = sort_lds_bytes<T>();
     {  // > 64 KiB of dynamic LDS needs the cap raised (per device; cheap, so every call)
         hipError_t e = hipFuncSetAttribute((const void *)radix_scatter<T>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     for (uint32_t shift = lo_bit; shift < lo_bit + nbits; shift += 8) {
@@ -304,12 +334,14 @@ static hipError_t radix_sort_bits(SortBuffers<T> &b, uint64_t len, uint32_t lo_b
         const uint32_t *ai = k_in ? a_in : b.aux[cur];
         const T *vi = k_in ? v_in : b.val[cur];
         const int dst = k_in ? cur : (cur ^ 1);
-        hipLaunchKernelGGL(radix_hist, dim3(nblk), dim3(kSortThreads), 0, st, ki, len, shift, b.counts,
+        hipLaunchKernelGGL(radix_hist, dim3(nblk), dim3(kHistThreads), 0, st, ki, len, shift, b.counts,
                            nblk);
         hipError_t e = exclusive_scan_u32(b.counts, b.counts, ncounts, b.sums, nullptr, st);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(radix_scatter<T>, dim3(nblk), dim3(kSortThreads), lds, st, ki, ai, vi,
-                           b.key[dst], b.aux[dst], b.val[dst], len, shift, b.counts, nblk);
+        const uint32_t per_xcd = (nblk + 7) / 8;
+        hipLaunchKernelGGL(radix_scatter<T>, dim3(SPAL_SORT_XCD ? per_xcd * 8 : nblk), dim3(kSortThreads),
+                           lds, st, ki, ai, vi, b.key[dst], b.aux[dst], b.val[dst], len, shift, b.counts,
+                           nblk, per_xcd);
         cur = dst;
         k_in = nullptr;
     }

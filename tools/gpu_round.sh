@@ -48,6 +48,13 @@ for s in "$@"; do
             step 400 prof_fetch.log rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -o bench -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
             step 400 prof_write.log rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -o bench -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
             ;;
+    variants) # VARIANTS="name ..." under spalinalg_amd/lib_var/: COO parity tests + lab per variant ("main" = the shipped library)
+            for v in ${VARIANTS:-main}; do
+              if [ "$v" = main ]; then unset SPAL_HIP_LIB; else export SPAL_HIP_LIB=$PWD/spalinalg_amd/lib_var/$v/libspal_hip.so; fi
+              step 300 var_${v}_tests.log python -m pytest tests/test_gpu_csc_coo.py -x -q -m gpu -k "coo or assembl"
+              step 300 var_${v}_lab.log python tools/lab_other.py ${VARIANT_LAB:-coo}
+            done
+            unset SPAL_HIP_LIB ;;
     *) echo "unknown step $s" ;;
   esac
 done
