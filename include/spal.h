@@ -203,6 +203,9 @@ int spal_coo_assemble_csr(spal_coo_t c, void *stream, spal_csr_t *out);
 /* Same assembly compressed by columns: replaces
  * `impl From<&CooMatrix<T>> for CscMatrix<T>` (src/csc/conv/coo.rs:4-115). */
 int spal_coo_assemble_csc(spal_coo_t c, void *stream, spal_csc_t *out);
+/* JSON description of the handle and of the route its last assembly took
+ * ("local_sort" with its tile geometry, or "general"); for logs and tests. */
+int spal_coo_describe(spal_coo_t c, char *buf, size_t buf_len);
 /* One-call convenience: upload + assemble + free the COO copy. */
 int spal_coo_to_csr_f64(int device, uint64_t nrows, uint64_t ncols, uint64_t len,
                         const uint64_t *rows, const uint64_t *cols,

@@ -161,18 +161,35 @@ constexpr int kHistThreads = 256;
 constexpr int kHistItems = kSortTile / kHistThreads;
 
 // counts[d * nblk + blk] = number of keys of tile blk with digit d
+// (the order inside the tile does not matter here: 16-byte loads, 4 keys per lane)
 __global__ __launch_bounds__(kHistThreads) void radix_hist(const uint32_t *__restrict__ keys,
                                                            uint64_t len, uint32_t shift,
                                                            uint32_t *__restrict__ counts,
                                                            uint32_t nblk) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t t0 = (uint64_t)blockIdx.x * kSortTile;
+    const uint64_t t0 = (uint64_t)blockIdx.x * kSortTile;  // multiple of 4: 16-byte aligned
+    static_assert(kSortTile % (4 * kHistThreads) == 0, "tile = whole rounds of 4 keys per thread");
+    if (t0 + kSortTile <= len) {
+        u32x4 k[kHistItems / 4];
 #pragma unroll
-    for (int j = 0; j < kHistItems; ++j) {
-        const uint64_t i = t0 + (uint64_t)j * kHistThreads + threadIdx.x;
-        if (i < len) atomicAdd(&h[(keys[i] >> shift) & 0xffu], 1u);
+        for (int j = 0; j < kHistItems / 4; ++j)
+            k[j] = *reinterpret_cast<const u32x4 *>(keys + t0 + ((uint64_t)j * kHistThreads + threadIdx.x) * 4);
+#pragma unroll
+        for (int j = 0; j < kHistItems / 4; ++j) {
+            atomicAdd(&h[(k[j].x >> shift) & 0xffu], 1u);
+            atomicAdd(&h[(k[j].y >> shift) & 0xffu], 1u);
+            atomicAdd(&h[(k[j].z >> shift) & 0xffu], 1u);
+            atomicAdd(&h[(k[j].w >> shift) & 0xffu], 1u);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kHistItems; ++j) {
+            const uint64_t i = t0 + (uint64_t)j * kHistThreads + threadIdx.x;
+            if (i < len) atomicAdd(&h[(keys[i] >> shift) & 0xffu], 1u);
+        }
     }
     __syncthreads();
     counts[(uint64_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
@@ -379,193 +396,268 @@ __global__ __launch_bounds__(256) void rows_lower_bound(const uint32_t *__restri
     start[r] = lo;
 }
 
-constexpr int kTileRows = 64;
-constexpr int kTileCap = 1024;  // entries a 64-row tile may hold for the LDS local sort
+// start[r] = first sorted entry whose row is >= r, r in [0, nrows], by ONE
+// streaming pass over the sorted keys: entry i with row[i] != row[i-1] is the
+// first of its row and of every empty row in between.  (The binary search above
+// costs 26 dependent loads per row; this reads every key once.)
+__global__ __launch_bounds__(256) void rows_boundaries(const uint32_t *__restrict__ sorted_row,
+                                                       uint32_t n, uint32_t nrows,
+                                                       uint32_t *__restrict__ start) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    // four consecutive entries per thread (one 16-byte load) + the key before them
+    const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 > n) return;
+    // virtual row -1 before the first entry (0xffffffff + 1 == 0), nrows after the last one
+    uint32_t prev = i0 == 0 ? 0xffffffffu : sorted_row[i0 - 1];
+    uint32_t k[4];
+    if (i0 + 4 <= n) {
+        const u32x4 q = *reinterpret_cast<const u32x4 *>(sorted_row + i0);
+        k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k[j] = (i0 + j < n) ? sorted_row[i0 + j] : nrows;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint64_t i = i0 + j;
+        if (i > n) break;
+        // rows prev + 1 .. k[j] start at i (empty unless the row changes here)
+        for (uint32_t r = prev + 1u; r <= k[j]; ++r) start[r] = (uint32_t)i;
+        prev = k[j];
+    }
+}
+
+// start[] of a sorted key array: the streaming pass, unless rows outnumber entries
+// so much that one thread of it would fill long stretches of empty rows
+static void launch_row_starts(const uint32_t *sorted_row, uint32_t n, uint32_t nrows, uint32_t *start,
+                              hipStream_t st) {
+    if ((uint64_t)nrows > 8ull * n + 1024)
+        hipLaunchKernelGGL(rows_lower_bound, dim3((uint32_t)(((uint64_t)nrows + 1 + 255) / 256)), dim3(256), 0,
+                           st, sorted_row, n, nrows, start);
+    else
+        hipLaunchKernelGGL(rows_boundaries, dim3((uint32_t)(((uint64_t)n / 4 + 1 + 255) / 256)), dim3(256), 0,
+                           st, sorted_row, n, nrows, start);
+}
+
+constexpr int kTileCap = 1024;  // entries a tile may hold for the LDS local sort
 constexpr int kRowCap = 128;    // longest row the quadratic local sort takes
 
-// flag[0] = 1 if some 64-row tile holds more than kTileCap entries or some row more than kRowCap
+// part[blk] = {longest row, entries of the fullest 64-, 32-, 16-row tile} over the
+// rows this workgroup visits (grid-stride; loads are unconditional so that the
+// unrolled iterations overlap).  No atomics: thousands of waves raising four
+// shared maxima serialise on them; tiles_check_final folds the partial results.
+constexpr int kCheckBlocks = 1024;
 __global__ __launch_bounds__(256) void tiles_check(const uint32_t *__restrict__ start, uint32_t nrows,
-                                                   uint32_t *__restrict__ flag) {
-    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t r0 = t * kTileRows;
-    if (r0 >= nrows) return;
-    const uint32_t r1 = (uint32_t)min<uint64_t>(r0 + kTileRows, nrows);
-    bool bad = start[r1] - start[r0] > (uint32_t)kTileCap;
-    for (uint32_t r = (uint32_t)r0; r < r1 && !bad; ++r) bad = start[r + 1] - start[r] > (uint32_t)kRowCap;
-    if (bad) atomicOr(flag, 1u);
-}
-
-// A wave copies the n <= kTileCap (col, val) pairs starting at entry e0 into its
-// LDS strips.  All of a lane's loads are issued before the first LDS write: one
-// memory round trip per tile instead of one per 64 entries.
-template <typename T>
-__device__ __forceinline__ void tile_load(uint32_t *c, T *v, const uint32_t *__restrict__ cols,
-                                          const T *__restrict__ vals, uint32_t e0, uint32_t n,
-                                          uint32_t lane) {
-    constexpr int K = kTileCap / 64;  // 16
-    uint32_t rc[K];
-    T rv[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const uint32_t i = lane + 64u * k;
-        const uint32_t ic = min(i, n - 1);  // n >= 1 here; clamped lanes re-read the last entry
-        rc[k] = cols[e0 + ic];
-        rv[k] = vals[e0 + ic];
+                                                   uint4 *__restrict__ part) {
+    __shared__ uint32_t s_max[4][4];
+    uint32_t v[4] = {0, 0, 0, 0};
+#pragma unroll 4
+    for (uint64_t r64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; r64 < nrows; r64 += (uint64_t)gridDim.x * 256) {
+        const uint32_t r = (uint32_t)r64, s0 = start[r];
+        const uint32_t s1 = start[r + 1], s16 = start[min(r + 16u, nrows)], s32 = start[min(r + 32u, nrows)],
+                       s64 = start[min(r + 64u, nrows)];
+        v[0] = max(v[0], s1 - s0);
+        v[1] = max(v[1], (r & 63u) ? 0u : s64 - s0);
+        v[2] = max(v[2], (r & 31u) ? 0u : s32 - s0);
+        v[3] = max(v[3], (r & 15u) ? 0u : s16 - s0);
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const uint32_t i = lane + 64u * k;
-        if (i < n) {
-            c[i] = rc[k];
-            v[i] = rv[k];
-        }
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[q] = max(v[q], (uint32_t)__shfl_xor((int)v[q], o, 64));
+        if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6][q] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint4 o;
+        o.x = max(max(s_max[0][0], s_max[1][0]), max(s_max[2][0], s_max[3][0]));
+        o.y = max(max(s_max[0][1], s_max[1][1]), max(s_max[2][1], s_max[3][1]));
+        o.z = max(max(s_max[0][2], s_max[1][2]), max(s_max[2][2], s_max[3][2]));
+        o.w = max(max(s_max[0][3], s_max[1][3]), max(s_max[2][3], s_max[3][3]));
+        part[blockIdx.x] = o;
+    }
+}
+// one workgroup: m[0..3] = element-wise maximum of part[0..nparts)
+__global__ __launch_bounds__(256) void tiles_check_final(const uint4 *__restrict__ part, uint32_t nparts,
+                                                         uint32_t *__restrict__ m) {
+    __shared__ uint32_t s_max[4][4];
+    uint32_t v[4] = {0, 0, 0, 0};
+    for (uint32_t i = threadIdx.x; i < nparts; i += 256) {
+        const uint4 p = part[i];
+        v[0] = max(v[0], p.x); v[1] = max(v[1], p.y); v[2] = max(v[2], p.z); v[3] = max(v[3], p.w);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[q] = max(v[q], (uint32_t)__shfl_xor((int)v[q], o, 64));
+        if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6][q] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const uint32_t q = threadIdx.x;
+        m[q] = max(max(s_max[0][q], s_max[1][q]), max(s_max[2][q], s_max[3][q]));
     }
 }
 
-// One wave per 64-row tile; the tile's (col, val) are staged in LDS.
-//   1. ranking, entry-parallel: lane l takes entries l, l+64, ... of the tile and
-//      computes each one's stable rank inside its row -- the number of entries j
-//      of that row with col_j < col_i, or col_j == col_i and j < i.  The work
-//      (sum of n_r^2) is spread evenly over the 64 lanes and the LDS reads of
-//      the inner loop are independent (unrolled, pipelined); the inverse
-//      permutation is scattered to a small LDS array.
-//   2. consuming, row-parallel: lane l walks row (first + l) in sorted order:
-//      runs of equal columns are summed left to right = insertion order
-//      (coo.rs:42-46), zero sums dropped (coo.rs:64), survivors written to the
-//      front of the row's segment in global memory (in place: the whole tile
-//      already sits in LDS); kept[row] = how many.
-template <typename T>
+// One wave per 64-row tile of the row-sorted entries (rows of a tile are
+// contiguous: entries [start[r0], start[r1])).  Everything is entry-parallel --
+// lane l owns entries l, l+64, ... -- so the LDS reads of a phase are
+// independent of each other and pipeline; nothing walks a row lane by lane.
+//   0. one batch of global loads: (row, col, val) of every entry -> registers;
+//      the columns also go to LDS in arrival order.
+//   1. rank: the stable rank of an entry inside its row = number of entries j of
+//      that row with col_j < col_i, or col_j == col_i and j < i.  The entry is
+//      scattered to LDS position rs[row] + rank: the tile is now sorted by
+//      (row, col), equal (row, col) in insertion order.
+//   2. run heads: a sorted position starts a run when its (row, col) differs
+//      from its predecessor's.  The head sums its run left to right = insertion
+//      order (coo.rs:42-46); zero sums are dropped (coo.rs:64).
+//   3. survivors are numbered by ballots in sorted order and written in place
+//      to the FRONT of the tile's segment in global memory (the whole tile sits
+//      in registers / LDS by then), already in final CSR order; kept[row] =
+//      survivors of the row (LDS counters).
+template <typename T, int CAP, int ROWS>
 __global__ __launch_bounds__(256) void coo_tile_sort(const uint32_t *__restrict__ start,
                                                      const uint32_t *__restrict__ sorted_row,
                                                      uint32_t *__restrict__ cols, T *__restrict__ vals,
                                                      uint32_t nrows, uint32_t *__restrict__ kept) {
-    __shared__ uint32_t s_col[4][kTileCap];
-    __shared__ T s_val[4][kTileCap];
-    __shared__ uint16_t s_inv[4][kTileCap];
-    __shared__ uint32_t s_rs[4][kTileRows + 1];
+    constexpr int K = CAP / 64;
+    __shared__ T s_val2[4][CAP];
+    __shared__ uint32_t s_col[4][CAP];
+    __shared__ uint32_t s_col2[4][CAP];
+    __shared__ uint32_t s_rs[4][ROWS + 1];
+    __shared__ uint32_t s_kept[4][ROWS];
+    __shared__ uint8_t s_row2[4][CAP];
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t tile = (uint64_t)blockIdx.x * 4 + w;
-    const uint64_t r0 = tile * kTileRows;
+    const uint64_t r0 = tile * ROWS;
     if (r0 >= nrows) return;  // wave-uniform
-    const uint32_t r1 = (uint32_t)min<uint64_t>(r0 + kTileRows, nrows);
+    const uint32_t r1 = (uint32_t)min<uint64_t>(r0 + ROWS, nrows);
     const uint32_t e0 = start[r0], e1 = start[r1];
-    const uint32_t n = e1 - e0;  // <= kTileCap (checked by tiles_check)
-    uint32_t *c = s_col[w];
-    T *v = s_val[w];
-    uint16_t *inv = s_inv[w];
-    uint32_t *rs = s_rs[w];
-    if (n) tile_load<T>(c, v, cols, vals, e0, n, lane);
-    rs[lane] = start[min((uint32_t)r0 + lane, r1)] - e0;
-    if (lane == 0) rs[kTileRows] = start[r1] - e0;
-    __builtin_amdgcn_wave_barrier();
-    // 1. ranks (the row of every entry: one batch of loads)
-    uint32_t rowid[kTileCap / 64];
-#pragma unroll
-    for (int k = 0; k < kTileCap / 64; ++k) {
-        const uint32_t i = lane + 64u * k;
-        rowid[k] = (i < n) ? sorted_row[e0 + i] : (uint32_t)r0;
-    }
-#pragma unroll
-    for (int k = 0; k < kTileCap / 64; ++k) {
-        const uint32_t i = lane + 64u * k;
-        if (i >= n) break;
-        const uint32_t lr = rowid[k] - (uint32_t)r0;
-        const uint32_t a = rs[lr], b = rs[lr + 1];
-        const uint32_t ci = c[i];
-        uint32_t rank = 0, j = a;
-        for (; j + 4 <= b; j += 4) {
-            const uint32_t c0 = c[j], c1 = c[j + 1], c2 = c[j + 2], c3 = c[j + 3];
-            rank += (uint32_t)((c0 < ci) | ((c0 == ci) & (j < i)));
-            rank += (uint32_t)((c1 < ci) | ((c1 == ci) & (j + 1 < i)));
-            rank += (uint32_t)((c2 < ci) | ((c2 == ci) & (j + 2 < i)));
-            rank += (uint32_t)((c3 < ci) | ((c3 == ci) & (j + 3 < i)));
-        }
-        for (; j < b; ++j) {
-            const uint32_t cj = c[j];
-            rank += (uint32_t)((cj < ci) | ((cj == ci) & (j < i)));
-        }
-        inv[a + rank] = (uint16_t)i;
-    }
-    __builtin_amdgcn_wave_barrier();
-    // 2. runs
+    const uint32_t n = e1 - e0;  // <= CAP (the host picks CAP from tiles_check's maximum)
+    uint32_t *c = s_col[w], *c2 = s_col2[w], *rs = s_rs[w], *rk = s_kept[w];
+    T *v2 = s_val2[w];
+    uint8_t *r2 = s_row2[w];
     const uint32_t r = (uint32_t)r0 + lane;
-    if (r < r1) {
-        const uint32_t a = rs[lane], b = rs[lane + 1];
-        uint32_t out = e0 + a;  // global position of the next survivor
-        uint32_t q = a;
-        while (q < b) {
-            uint32_t i = inv[q];
-            const uint32_t ck = c[i];
-            T acc = v[i];
-            for (++q; q < b; ++q) {
-                i = inv[q];
-                if (c[i] != ck) break;
-                acc = acc + v[i];
+    if (n == 0) {
+        if (lane < (uint32_t)ROWS && r < r1) kept[r] = 0;
+        return;
+    }
+    // 0. loads (clamped lanes re-read the last entry)
+    uint32_t rc[K], rid[K];
+    T rv[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t ic = min(lane + 64u * k, n - 1);
+        rc[k] = cols[e0 + ic];
+        rv[k] = vals[e0 + ic];
+        rid[k] = sorted_row[e0 + ic] - (uint32_t)r0;
+    }
+    if (lane <= (uint32_t)ROWS) rs[lane] = start[min(r, r1)] - e0;   // ROWS < 64: entry ROWS included
+    if (ROWS == 64 && lane == 0) rs[ROWS] = n;
+    if (lane < (uint32_t)ROWS) rk[lane] = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t i = lane + 64u * k;
+        if (i < n) c[i] = rc[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // 1. ranks -> sorted order
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t i = lane + 64u * k;
+        if (64u * k >= n) break;  // wave-uniform
+        if (i < n) {
+            const uint32_t lr = rid[k];
+            const uint32_t a = rs[lr], b = rs[lr + 1];
+            const uint32_t ci = rc[k];
+            uint32_t rank = 0, j = a;
+            for (; j + 4 <= b; j += 4) {
+                const uint32_t c0 = c[j], c1 = c[j + 1], c2_ = c[j + 2], c3 = c[j + 3];
+                rank += (uint32_t)((c0 < ci) | ((c0 == ci) & (j < i)));
+                rank += (uint32_t)((c1 < ci) | ((c1 == ci) & (j + 1 < i)));
+                rank += (uint32_t)((c2_ < ci) | ((c2_ == ci) & (j + 2 < i)));
+                rank += (uint32_t)((c3 < ci) | ((c3 == ci) & (j + 3 < i)));
             }
-            if (acc != T(0)) {
-                cols[out] = ck;
-                vals[out] = acc;
-                ++out;
+            for (; j < b; ++j) {
+                const uint32_t cj = c[j];
+                rank += (uint32_t)((cj < ci) | ((cj == ci) & (j < i)));
+            }
+            const uint32_t p = a + rank;
+            c2[p] = ci;
+            v2[p] = rv[k];
+            r2[p] = (uint8_t)lr;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // 2. + 3. heads, run sums, numbering, in-place write
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t base = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (64u * k >= n) break;  // wave-uniform
+        const uint32_t p = lane + 64u * k;
+        const bool live = p < n;
+        const uint32_t pc = live ? p : n - 1, pp = pc ? pc - 1 : 0, pn = min(pc + 1, n - 1);
+        const uint32_t cp = c2[pc], cprev = c2[pp], cnext = c2[pn];
+        const uint32_t rp = r2[pc], rprev = r2[pp], rnext = r2[pn];
+        T acc = v2[pc];
+        const bool head = live && (pc == 0 || cprev != cp || rprev != rp);
+        const bool dup = head && pn != pc && cnext == cp && rnext == rp;
+        if (__any(dup)) {  // duplicates are rare: most waves skip this
+            if (dup) {
+                for (uint32_t q = pc + 1; q < n && c2[q] == cp && r2[q] == rp; ++q) acc = acc + v2[q];
             }
         }
-        kept[r] = out - (e0 + a);
+        const bool keep = head && acc != T(0);
+        const uint64_t m = __ballot(keep);
+        if (keep) {
+            const uint32_t o = e0 + base + (uint32_t)__popcll(m & lt);
+            cols[o] = cp;
+            vals[o] = acc;
+            atomicAdd(&rk[rp], 1u);
+        }
+        base += (uint32_t)__popcll(m);
     }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < (uint32_t)ROWS && r < r1) kept[r] = rk[lane];
 }
 
-// Packs the kept entries of every row at rowptr[row].  One wave per 64-row
-// tile, entry-parallel: the tile's output range [rowptr[first], rowptr[last+1])
-// is contiguous; lane l takes output positions l, l+64, ..., finds the row of
-// each by a binary search over the tile's 65 row offsets (LDS) and copies the
-// entry from its place in the row's segment.  All loads are independent and the
-// stores are coalesced.
-template <typename T>
+// Moves the survivors of every tile (contiguous at the front of the tile's
+// segment, see above) to their final place rowptr[first row of the tile]: one
+// wave per tile, a straight coalesced copy.
+template <typename T, int CAP, int ROWS>
 __global__ __launch_bounds__(256) void coo_tile_pack(const uint32_t *__restrict__ start,
                                                      const uint32_t *__restrict__ rowptr,
                                                      const uint32_t *__restrict__ cols,
                                                      const T *__restrict__ vals, uint32_t nrows,
                                                      uint32_t *__restrict__ out_col,
                                                      T *__restrict__ out_val) {
-    __shared__ uint32_t s_rp[4][kTileRows + 1], s_st[4][kTileRows + 1];
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t tile = (uint64_t)blockIdx.x * 4 + w;
-    const uint64_t r0 = tile * kTileRows;
+    const uint64_t r0 = tile * ROWS;
     if (r0 >= nrows) return;
-    const uint32_t r1 = (uint32_t)min<uint64_t>(r0 + kTileRows, nrows);
-    uint32_t *rp = s_rp[w], *st = s_st[w];
-    const uint32_t rl = min((uint32_t)r0 + lane, r1);
-    rp[lane] = rowptr[rl];
-    st[lane] = start[rl];
-    if (lane == 0) { rp[kTileRows] = rowptr[r1]; st[kTileRows] = start[r1]; }
-    __builtin_amdgcn_wave_barrier();
-    const uint32_t o0 = rp[0], o1 = rp[kTileRows];   // rows past r1 repeat rowptr[r1]
-    constexpr int K = kTileCap / 64;
+    const uint32_t r1 = (uint32_t)min<uint64_t>(r0 + ROWS, nrows);
+    const uint32_t e0 = start[r0], o0 = rowptr[r0], cnt = rowptr[r1] - o0;
+    constexpr int K = CAP / 64;
     uint32_t rc[K];
     T rv[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const uint32_t o = o0 + lane + 64u * k;
+        const uint32_t j = lane + 64u * k;
         rc[k] = 0;
         rv[k] = T(0);
-        if (o < o1) {
-            // largest row index r (0..64) with rp[r] <= o; empty rows share an offset
-            // with their successor, the search lands on the last of them, whose
-            // successor offset is > o: the row that owns position o
-            uint32_t lo = 0, hi = kTileRows;  // invariant: rp[lo] <= o < rp[hi]
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (rp[mid] <= o) lo = mid; else hi = mid;
-            }
-            const uint32_t src = st[lo] + (o - rp[lo]);
-            rc[k] = cols[src];
-            rv[k] = vals[src];
+        if (j < cnt) {
+            rc[k] = cols[e0 + j];
+            rv[k] = vals[e0 + j];
         }
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const uint32_t o = o0 + lane + 64u * k;
-        if (o < o1) {
-            out_col[o] = rc[k];
-            out_val[o] = rv[k];
+        const uint32_t j = lane + 64u * k;
+        if (j < cnt) {
+            out_col[o0 + j] = rc[k];
+            out_val[o0 + j] = rv[k];
         }
     }
 }
@@ -637,7 +729,7 @@ static CooWorkspace coo_workspace_layout(uint64_t len, uint64_t nrows, size_t el
     w.off_sums = take(((scan_n + kScanTile - 1) / kScanTile) * 4);
     w.off_start = take((nrows + 1) * 4);
     w.off_kept = take((nrows + 1) * 4);
-    w.off_flag = take(4);
+    w.off_flag = take(16 + (size_t)kCheckBlocks * 16);  // maxima + per-workgroup partial maxima
     w.off_total = take(4);
     w.bytes = o;
     return w;
@@ -698,23 +790,51 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
     int cur = 0;
     SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, 0, rbits, cur, st, d_major, d_minor,
                                     (const T *)c->d_vals));
-    // ---- 2. row offsets, tile check
-    const uint32_t g_rows = (uint32_t)(((uint64_t)nrows + 1 + 255) / 256);
-    hipLaunchKernelGGL(rows_lower_bound, dim3(g_rows), dim3(256), 0, st, sb.key[cur], (uint32_t)len,
-                       nrows, start.as<uint32_t>());
-    SPAL_HIP_TRY(hipMemsetAsync(flag.p, 0, 4, st));
-    const uint32_t ntiles = (uint32_t)(((uint64_t)nrows + kTileRows - 1) / kTileRows);
-    hipLaunchKernelGGL(tiles_check, dim3((ntiles + 255) / 256), dim3(256), 0, st, start.as<uint32_t>(),
-                       nrows, flag.as<uint32_t>());
-    uint32_t too_long = 0;
-    SPAL_HIP_TRY(hipMemcpyAsync(&too_long, flag.p, 4, hipMemcpyDeviceToHost, st));
+    // ---- 2. row offsets; longest row and fullest tiles
+    launch_row_starts(sb.key[cur], (uint32_t)len, nrows, start.as<uint32_t>(), st);
+    {
+        const uint32_t nparts = std::max<uint32_t>(std::min<uint32_t>((nrows + 255) / 256, (uint32_t)kCheckBlocks), 1u);
+        uint4 *part = reinterpret_cast<uint4 *>(flag.p + 16);
+        hipLaunchKernelGGL(tiles_check, dim3(nparts), dim3(256), 0, st, start.as<uint32_t>(), nrows, part);
+        hipLaunchKernelGGL(tiles_check_final, dim3(1), dim3(256), 0, st, part, nparts, flag.as<uint32_t>());
+    }
+    uint32_t chk[4] = {0, 0, 0, 0};
+    SPAL_HIP_TRY(hipMemcpyAsync(chk, flag.p, 16, hipMemcpyDeviceToHost, st));
     SPAL_HIP_TRY(hipStreamSynchronize(st));
+    // Tile geometry of the local sort: LDS is 17 B per entry of capacity, so the
+    // smaller the tiles the more waves a CU holds while others wait on their
+    // loads.  Widest tile whose fullest instance stays within 512 entries;
+    // failing that 16-row tiles of up to 1024; failing that the general route.
+    int tile_rows = 0, tile_cap = 0;
+    if (chk[0] <= (uint32_t)kRowCap) {
+        for (int q = 1; q <= 3 && !tile_rows; ++q)
+            if (chk[q] <= 512) { tile_rows = 128 >> q; tile_cap = chk[q] <= 256 ? 256 : 512; }
+        if (!tile_rows && chk[3] <= (uint32_t)kTileCap) { tile_rows = 16; tile_cap = kTileCap; }
+    }
+    c->last_tile_rows = tile_rows;
+    c->last_tile_cap = tile_cap;
+    if (getenv("SPAL_COO_DEBUG"))
+        fprintf(stderr, "[spal coo] longest row %u, fullest tile 64/32/16 rows: %u %u %u -> tile %d x %d\n",
+                chk[0], chk[1], chk[2], chk[3], tile_rows, tile_cap);
 
     uint32_t nnz = 0;
     DevBuf ocol, oval;
-    if (!too_long) {
+    if (tile_rows) {
         // ---- 3. per-row stable sort by column + run sums + zero drop, in LDS
-        hipLaunchKernelGGL(coo_tile_sort<T>, dim3((ntiles + 3) / 4), dim3(256), 0, st,
+        const uint32_t ntiles = (uint32_t)(((uint64_t)nrows + tile_rows - 1) / tile_rows);
+        void (*k_sort)(const uint32_t *, const uint32_t *, uint32_t *, T *, uint32_t, uint32_t *) = nullptr;
+        void (*k_pack)(const uint32_t *, const uint32_t *, const uint32_t *, const T *, uint32_t, uint32_t *,
+                       T *) = nullptr;
+#define SPAL_TILE_GEOM(R, C)                                                        \
+    if (tile_rows == R && tile_cap == C) {                                          \
+        k_sort = coo_tile_sort<T, C, R>;                                            \
+        k_pack = coo_tile_pack<T, C, R>;                                            \
+    }
+        SPAL_TILE_GEOM(64, 256) SPAL_TILE_GEOM(64, 512) SPAL_TILE_GEOM(32, 256) SPAL_TILE_GEOM(32, 512)
+        SPAL_TILE_GEOM(16, 256) SPAL_TILE_GEOM(16, 512) SPAL_TILE_GEOM(16, 1024)
+#undef SPAL_TILE_GEOM
+        if (!k_sort) return fail(SPAL_ERR_UNSUPPORTED, "internal: no tile geometry");
+        hipLaunchKernelGGL(k_sort, dim3((ntiles + 3) / 4), dim3(256), 0, st,
                            start.as<uint32_t>(), sb.key[cur], sb.aux[cur], sb.val[cur], nrows,
                            kept.as<uint32_t>());
         // ---- 4. rowptr = scan of the kept counts; pack
@@ -727,7 +847,7 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
         SPAL_HIP_TRY(oval.alloc(cap * sizeof(T)));
         SPAL_HIP_TRY(hipMemsetAsync((char *)ocol.p + (size_t)nnz * 4, 0, 256 * 4, st));
         SPAL_HIP_TRY(hipMemsetAsync((char *)oval.p + (size_t)nnz * sizeof(T), 0, 256 * sizeof(T), st));
-        hipLaunchKernelGGL(coo_tile_pack<T>, dim3((ntiles + 3) / 4), dim3(256), 0, st,
+        hipLaunchKernelGGL(k_pack, dim3((ntiles + 3) / 4), dim3(256), 0, st,
                            start.as<uint32_t>(), rowptr.as<uint32_t>(), sb.aux[cur], sb.val[cur], nrows,
                            ocol.as<uint32_t>(), oval.as<T>());
         SPAL_HIP_TRY(hipGetLastError());
@@ -765,8 +885,7 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
         SPAL_HIP_TRY(hipMemsetAsync((char *)oval.p + (size_t)nnz * sizeof(T), 0, 256 * sizeof(T), st));
         hipLaunchKernelGGL(coo_compact<T>, dim3(g256), dim3(256), 0, st, s_row, s_col, runsum, d_keep,
                            d_pos, len, orow.as<uint32_t>(), ocol.as<uint32_t>(), oval.as<T>());
-        hipLaunchKernelGGL(rows_lower_bound, dim3(g_rows), dim3(256), 0, st, orow.as<uint32_t>(), nnz,
-                           nrows, rowptr.as<uint32_t>());
+        launch_row_starts(orow.as<uint32_t>(), nnz, nrows, rowptr.as<uint32_t>(), st);
         SPAL_HIP_TRY(hipGetLastError());
         SPAL_HIP_TRY(hipStreamSynchronize(st));
         res.ptr = (uint32_t *)rowptr.release(); res.ind = (uint32_t *)ocol.release();
@@ -829,8 +948,7 @@ static int transpose_t(int device, uint64_t nmajor, uint64_t nminor, uint64_t nn
         int cur = 0;
         SPAL_HIP_TRY(radix_sort_bits<T>(sb, nnz, 0, bits_for(nminor), cur, st, d_ind,
                                         major.as<uint32_t>(), d_val));
-        hipLaunchKernelGGL(rows_lower_bound, dim3((uint32_t)((nminor + 1 + 255) / 256)), dim3(256), 0, st,
-                           sb.key[cur], (uint32_t)nnz, (uint32_t)nminor, optr.as<uint32_t>());
+        launch_row_starts(sb.key[cur], (uint32_t)nnz, (uint32_t)nminor, optr.as<uint32_t>(), st);
         SPAL_HIP_TRY(hipMemcpyAsync(oind.p, sb.aux[cur], nnz * 4, hipMemcpyDeviceToDevice, st));
         SPAL_HIP_TRY(hipMemcpyAsync(oval.p, sb.val[cur], nnz * sizeof(T), hipMemcpyDeviceToDevice, st));
         SPAL_HIP_TRY(hipGetLastError());
@@ -949,6 +1067,16 @@ int spal_coo_destroy(spal_coo_t c) {
     if (!c) return SPAL_OK;
     DeviceGuard guard(c->device);
     coo_free(c);
+    return SPAL_OK;
+}
+int spal_coo_describe(spal_coo_t c, char *buf, size_t buf_len) {
+    if (!c || !buf || !buf_len) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_coo_describe: null argument");
+    snprintf(buf, buf_len,
+             "{\"format\": \"coo\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"len\": %llu, "
+             "\"last_route\": \"%s\", \"tile_rows\": %d, \"tile_cap\": %d}",
+             c->elem_size == 8 ? "f64" : "f32", (unsigned long long)c->nrows, (unsigned long long)c->ncols,
+             (unsigned long long)c->len, c->last_tile_rows ? "local_sort" : "general", c->last_tile_rows,
+             c->last_tile_cap);
     return SPAL_OK;
 }
 int spal_coo_assemble_csr(spal_coo_t c, void *stream, spal_csr_t *out) {

@@ -196,6 +196,12 @@ class DeviceCoo:
         check(_ffi.lib().spal_coo_assemble_csc(self._h, _stream_ptr(stream), C.byref(out)))
         return DeviceCsc(out, self.dtype, self.device)
 
+    def describe(self) -> dict:
+        """The handle and the route its last assembly took (tile geometry of the local sort)."""
+        buf = C.create_string_buffer(1024)
+        check(_ffi.lib().spal_coo_describe(self._h, buf, C.c_size_t(len(buf))))
+        return json.loads(buf.value.decode())
+
     def close(self):
         if self._h is not None:
             _ffi.lib().spal_coo_destroy(self._h)

@@ -75,7 +75,7 @@ def main():
             t_up = time.time() - t0
             torch.cuda.synchronize()
             ts = []
-            for _ in range(3):
+            for _ in range(8):
                 t0 = time.perf_counter()
                 csr = d.assemble_csr()
                 torch.cuda.synchronize()
