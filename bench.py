@@ -54,6 +54,10 @@ def parse():
                     help="torch.distributed backend; gloo only to rehearse the N > 1 path on a 1-GPU box")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--copies", type=int, default=0,
+                    help="single-GPU configs 2 and 4: rotate the launches over this many independent copies of "
+                         "(matrix, x, y) so that the 188 MB working set is not served from the 256 MB Infinity "
+                         "Cache (SURVEY 8d).  Default 0 = 3 copies for configs 2 and 4, 1 for config 3 (1.9 GB)")
     ap.add_argument("--exchange", default="auto", choices=["auto", "allgather", "halo"],
                     help="N > 1 only: what moves between the GPUs.  halo: per step every rank receives only the "
                          "entries of y its rows reference as columns (point-to-point over xGMI; banded shards: "
@@ -78,6 +82,16 @@ def timed(fn, steps, warmup, torch):
     return e0.elapsed_time(e1) / steps
 
 
+def rotating(fns):
+    """Call fns[0], fns[1], ... in turn, one per invocation."""
+    state = {"i": 0}
+
+    def call():
+        fns[state["i"] % len(fns)]()
+        state["i"] += 1
+    return call
+
+
 def bench_csc(args):
     """BASELINE config 4: CscMatrix f64 SpMV (atomic scatter path), CSC of the config-2 matrix."""
     import torch
@@ -92,28 +106,38 @@ def bench_csc(args):
     csc.sort_indices()
     cp, ri, cv = csc.indptr.astype(np.uint64), csc.indices.astype(np.uint64), csc.data.astype(np_dt)
     m = sp.CscMatrix(n, n, cp, ri, cv)
-    dev = m.device()
-    for kv in args.opt:
-        k, v = kv.split("=")
-        dev.set_option(k, int(v))
+    # 188 MB of matrix + vectors would sit in the 256 MB Infinity Cache: rotate over copies
+    copies = args.copies if args.copies > 0 else 3
+    devs = [m.device() for _ in range(copies)]
+    for d in devs:
+        for kv in args.opt:
+            k, v = kv.split("=")
+            d.set_option(k, int(v))
+    dev = devs[0]
     xh = sp.synth.vector(n, dtype=np_dt)
-    x = torch.from_numpy(xh).cuda()
-    y = torch.empty_like(x)
+    xs = [torch.from_numpy(xh).cuda() for _ in range(copies)]
+    ys = [torch.empty_like(xs[0]) for _ in range(copies)]
+    x, y = xs[0], ys[0]
     # the library's default for CSC handles is the transposed route (CSC -> CSR once
     # on the device, then the CSR stream kernel); config 4 names the atomic scatter
     # path, so THAT is what `value` measures; the other route is reported beside it
-    dev.set_option("kernel", 2)
-    dev.autotune(x, y, iters=30)
-    ms_transposed = timed(lambda: dev.spmv_torch(x, out=y), args.steps, args.warmup, torch)
+    for d, xx, yy in zip(devs, xs, ys):
+        d.set_option("kernel", 2)
+        d.autotune(xx, yy, iters=30)
+    launches = [(lambda d=d, xx=xx, yy=yy: d.spmv_torch(xx, out=yy)) for d, xx, yy in zip(devs, xs, ys)]
+    ms_transposed = timed(rotating(launches), args.steps, args.warmup, torch)
     y_transposed = y.clone()
-    dev.set_option("kernel", 1)
-    ms = timed(lambda: dev.spmv_torch(x, out=y), args.steps, args.warmup, torch)
+    for d in devs:
+        d.set_option("kernel", 1)
+    ms = timed(rotating(launches), args.steps, args.warmup, torch)
     nnz = n * per_row
     B = sp.synth.spmv_bytes(nnz, n, n, n, esz)
     out = base_record(args, "CSC SpMV GFLOP/s (f64, 1Mx1M, 14M nnz, atomic scatter)",
                       sp.synth.spmv_flops(nnz) / (ms * 1e-3) / 1e9, "GFLOP/s", ms,
                       f"CscMatrix {args.dtype} SpMV y=A*x by atomic scatter, {n}x{n}, {nnz} nnz, CSC of the "
-                      f"config-2 banded matrix (BASELINE configs[3]), single GPU", dev.describe())
+                      f"config-2 banded matrix (BASELINE configs[3]), single GPU; launches rotate over {copies} "
+                      f"independent copies of (A, x, y) = {copies * B / 1e6:.0f} MB > the 256 MB Infinity Cache",
+                      dev.describe())
     out["roofline"] = {"bound": "hbm", "achieved": round(B / (ms * 1e-3) / 1e9, 2), "peak": 8000.0,
                        "unit": "GB/s", "frac": round(B / (ms * 1e-3) / 8e12, 4), "traffic": None,
                        "kernel": "csc_spmv_scatter (+ y memset)", "kernel_ms": round(ms, 6),
@@ -326,10 +350,27 @@ def main():
             exchange = "allgather"
     # setup: let the library pick between its kernel variants on this device (results are identical)
     plan = dev.autotune(x, op.y_local[: r1 - r0], iters=30)
+    # config 2 on one GPU: 188 MB would be served from the 256 MB Infinity Cache, so the
+    # launches rotate over independent copies of (A, x, y); config 3 is 1.9 GB
+    copies = args.copies if args.copies > 0 else (3 if (args.config == 2 and world == 1) else 1)
+    if world > 1:
+        copies = 1
+    single = [lambda: dev.spmv_torch(x, out=y)]     # y is the rank's (= the whole) slice
+    keep = []
+    for _ in range(copies - 1):
+        d2 = shard.device(local_rank)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            d2.set_option(k, int(v))
+        x2, y2 = x.clone(), torch.empty_like(y)
+        d2.autotune(x2, y2, iters=30)
+        keep.append((d2, x2, y2))
+        single.append(lambda d2=d2, x2=x2, y2=y2: d2.spmv_torch(x2, out=y2))
+    single_step = rotating(single)
 
     def step():
         if world == 1:
-            dev.spmv_torch(x, out=y)       # y is the rank's (= the whole) slice
+            single_step()
         elif exchange == "halo":
             op.spmv_halo(x, y)
         else:
@@ -450,7 +491,9 @@ def main():
                         f"({nnz} nnz), {args.dist} columns"
                         + (f" W={window}" if args.dist == "banded" else "")
                         + f" (BASELINE configs[{2 if args.config == 3 else 1}]), "
-                        + ("single GPU" if world == 1 else
+                        + ((f"single GPU" + (f"; launches rotate over {copies} independent copies of (A, x, y), "
+                                             f"together larger than the 256 MB Infinity Cache" if copies > 1 else ""))
+                           if world == 1 else
                            f"rows partitioned over {world} GPUs, x bcast once (RCCL), "
                            + ("y all-gather after every step (RCCL)" if exchange == "allgather" else
                               f"per step a halo exchange (RCCL send/recv, {getattr(op, 'halo_bytes', 0)} B received "
