@@ -211,10 +211,11 @@ def bench_coo(args):
                       csr.describe())
     out["roofline"] = {"bound": "hbm", "achieved": round(lb / (ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                        "frac": round(lb / (ms * 1e-3) / 8e12, 4), "traffic": None,
-                       "kernel": "radix_scatter x3 + coo_tile_sort + coo_tile_pack (whole assembly call)",
+                       "kernel": "radix_hist/scatter x2 + coo_group_sort + coo_group_pack + CSR planning (whole assembly call)",
                        "kernel_ms": round(ms, 6), "algorithmic_bytes_per_launch": lb,
                        "note": "algorithmic = lower bound 16*len + 12*nnz_out + 4*(nrows+1); a multi-pass sort "
-                               "inherently moves several times this"}
+                               "inherently moves several times this",
+                       "route": d.describe()}
     out["spmv_on_result"] = {"ms": round(spmv_ms, 6),
                              "gflops": round(sp.synth.spmv_flops(nnz) / (spmv_ms * 1e-3) / 1e9, 2)}
     if not args.no_cpu_baseline:

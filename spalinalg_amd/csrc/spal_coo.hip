@@ -10,22 +10,24 @@
 // reordering step is stable and each run is summed by ONE thread in insertion
 // order.
 //
-// Pipeline (device only; one host sync for the data-dependent output size):
-//   1. stable LSD radix sort by ROW only (ceil(rbits / 8) passes), carrying
-//      (col, value) as payload -- entries of a row end up contiguous, still in
-//      insertion order.  Each pass: per-tile digit histogram -> scan -> scatter
-//      that first reorders the tile in LDS so every digit leaves as one
-//      contiguous, coalesced run.
-//   2. row offsets by binary search in the sorted rows.
-//   3. per 64-row tile (one wave, entries staged in LDS): each lane sorts its
-//      row by column with a stable insertion sort, sums runs of equal columns
-//      in order, drops zeros, compacts its row in place, counts what is left.
-//   4. scan of the per-row counts = rowptr; the tiles are compacted into the
-//      final colind / values.
-// If some 64-row tile holds more than 1024 entries, or some row more than 128
-// (the local sort is quadratic in the row length), the assembly runs the general route -- LSD passes
-// over the column bits first, then the row bits -- and a lane-sequential run
-// summation, which is correct for any input, only slower.
+// Pipeline (device only; two small read-backs: the fullest group, the output size):
+//   1. stable LSD radix sort by the ROW BITS ABOVE gbits only (8 bits per pass:
+//      2 passes at config 5), carrying (col, value) as payload -- the entries of
+//      a group of 2^gbits consecutive rows (about a thousand entries) end up
+//      contiguous, still in insertion order.  Each pass: per-tile digit
+//      histogram -> scan -> scatter that first reorders the tile in LDS so every
+//      digit leaves as one contiguous, coalesced run.
+//   2. group offsets by one streaming pass over the sorted keys; the fullest
+//      group decides the LDS capacity of step 3 (512 ... 2048 entries).
+//   3. one workgroup per group, everything in LDS and entry-parallel: counting
+//      sort by the low row bits, stable rank by column inside each row, run
+//      heads sum their runs in insertion order, zeros dropped, survivors written
+//      in place at the front of the group's segment, per-row counts.
+//   4. scan of the per-row counts = rowptr; the groups are copied to their place
+//      in the final colind / values.
+// If some group holds more than 2048 entries the assembly runs the general
+// route -- LSD passes over the column bits first, then all row bits -- and a
+// lane-sequential run summation, which is correct for any input, only slower.
 #include "spal_internal.hpp"
 
 namespace spal {
@@ -382,16 +384,18 @@ struct DevBuf {
 // --------------------------------------------------------------------------
 // after the row sort
 // --------------------------------------------------------------------------
+// Row starts of an array of keys that is sorted by (key >> shift): with shift = 0
+// rows, otherwise groups of 2^shift consecutive rows ("row" below = key >> shift).
 // start[r] = first sorted entry whose row is >= r   (r in [0, nrows])
 __global__ __launch_bounds__(256) void rows_lower_bound(const uint32_t *__restrict__ sorted_row,
-                                                        uint32_t n, uint32_t nrows,
+                                                        uint32_t n, uint32_t nrows, uint32_t shift,
                                                         uint32_t *__restrict__ start) {
     const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (r > nrows) return;
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
-        if ((uint64_t)sorted_row[mid] < r) lo = mid + 1; else hi = mid;
+        if ((uint64_t)(sorted_row[mid] >> shift) < r) lo = mid + 1; else hi = mid;
     }
     start[r] = lo;
 }
@@ -401,21 +405,21 @@ __global__ __launch_bounds__(256) void rows_lower_bound(const uint32_t *__restri
 // first of its row and of every empty row in between.  (The binary search above
 // costs 26 dependent loads per row; this reads every key once.)
 __global__ __launch_bounds__(256) void rows_boundaries(const uint32_t *__restrict__ sorted_row,
-                                                       uint32_t n, uint32_t nrows,
+                                                       uint32_t n, uint32_t nrows, uint32_t shift,
                                                        uint32_t *__restrict__ start) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     // four consecutive entries per thread (one 16-byte load) + the key before them
     const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i0 > n) return;
     // virtual row -1 before the first entry (0xffffffff + 1 == 0), nrows after the last one
-    uint32_t prev = i0 == 0 ? 0xffffffffu : sorted_row[i0 - 1];
+    uint32_t prev = i0 == 0 ? 0xffffffffu : sorted_row[i0 - 1] >> shift;
     uint32_t k[4];
     if (i0 + 4 <= n) {
         const u32x4 q = *reinterpret_cast<const u32x4 *>(sorted_row + i0);
-        k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
+        k[0] = q.x >> shift; k[1] = q.y >> shift; k[2] = q.z >> shift; k[3] = q.w >> shift;
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) k[j] = (i0 + j < n) ? sorted_row[i0 + j] : nrows;
+        for (int j = 0; j < 4; ++j) k[j] = (i0 + j < n) ? sorted_row[i0 + j] >> shift : nrows;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -430,221 +434,264 @@ __global__ __launch_bounds__(256) void rows_boundaries(const uint32_t *__restric
 // start[] of a sorted key array: the streaming pass, unless rows outnumber entries
 // so much that one thread of it would fill long stretches of empty rows
 static void launch_row_starts(const uint32_t *sorted_row, uint32_t n, uint32_t nrows, uint32_t *start,
-                              hipStream_t st) {
+                              hipStream_t st, uint32_t shift = 0) {
     if ((uint64_t)nrows > 8ull * n + 1024)
         hipLaunchKernelGGL(rows_lower_bound, dim3((uint32_t)(((uint64_t)nrows + 1 + 255) / 256)), dim3(256), 0,
-                           st, sorted_row, n, nrows, start);
+                           st, sorted_row, n, nrows, shift, start);
     else
         hipLaunchKernelGGL(rows_boundaries, dim3((uint32_t)(((uint64_t)n / 4 + 1 + 255) / 256)), dim3(256), 0,
-                           st, sorted_row, n, nrows, start);
+                           st, sorted_row, n, nrows, shift, start);
 }
 
-constexpr int kTileCap = 1024;  // entries a tile may hold for the LDS local sort
-constexpr int kRowCap = 128;    // longest row the quadratic local sort takes
+constexpr int kGroupCap = 2048;  // entries a group of rows may hold for the LDS local sort
 
-// part[blk] = {longest row, entries of the fullest 64-, 32-, 16-row tile} over the
-// rows this workgroup visits (grid-stride; loads are unconditional so that the
-// unrolled iterations overlap).  No atomics: thousands of waves raising four
-// shared maxima serialise on them; tiles_check_final folds the partial results.
+// part[blk] = entries of the fullest group among those this workgroup visits
+// (no atomics: thousands of waves raising one shared maximum serialise on it;
+// groups_check_final folds the partial results)
 constexpr int kCheckBlocks = 1024;
-__global__ __launch_bounds__(256) void tiles_check(const uint32_t *__restrict__ start, uint32_t nrows,
-                                                   uint4 *__restrict__ part) {
-    __shared__ uint32_t s_max[4][4];
-    uint32_t v[4] = {0, 0, 0, 0};
+__global__ __launch_bounds__(256) void groups_check(const uint32_t *__restrict__ gstart, uint32_t ngroups,
+                                                    uint32_t *__restrict__ part) {
+    __shared__ uint32_t s_max[4];
+    uint32_t v = 0;
 #pragma unroll 4
-    for (uint64_t r64 = (uint64_t)blockIdx.x * 256 + threadIdx.x; r64 < nrows; r64 += (uint64_t)gridDim.x * 256) {
-        const uint32_t r = (uint32_t)r64, s0 = start[r];
-        const uint32_t s1 = start[r + 1], s16 = start[min(r + 16u, nrows)], s32 = start[min(r + 32u, nrows)],
-                       s64 = start[min(r + 64u, nrows)];
-        v[0] = max(v[0], s1 - s0);
-        v[1] = max(v[1], (r & 63u) ? 0u : s64 - s0);
-        v[2] = max(v[2], (r & 31u) ? 0u : s32 - s0);
-        v[3] = max(v[3], (r & 15u) ? 0u : s16 - s0);
-    }
+    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (uint64_t)gridDim.x * 256)
+        v = max(v, gstart[g + 1] - gstart[g]);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v[q] = max(v[q], (uint32_t)__shfl_xor((int)v[q], o, 64));
-        if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6][q] = v[q];
-    }
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint4 o;
-        o.x = max(max(s_max[0][0], s_max[1][0]), max(s_max[2][0], s_max[3][0]));
-        o.y = max(max(s_max[0][1], s_max[1][1]), max(s_max[2][1], s_max[3][1]));
-        o.z = max(max(s_max[0][2], s_max[1][2]), max(s_max[2][2], s_max[3][2]));
-        o.w = max(max(s_max[0][3], s_max[1][3]), max(s_max[2][3], s_max[3][3]));
-        part[blockIdx.x] = o;
-    }
+    if (threadIdx.x == 0) part[blockIdx.x] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
 }
-// one workgroup: m[0..3] = element-wise maximum of part[0..nparts)
-__global__ __launch_bounds__(256) void tiles_check_final(const uint4 *__restrict__ part, uint32_t nparts,
-                                                         uint32_t *__restrict__ m) {
-    __shared__ uint32_t s_max[4][4];
-    uint32_t v[4] = {0, 0, 0, 0};
-    for (uint32_t i = threadIdx.x; i < nparts; i += 256) {
-        const uint4 p = part[i];
-        v[0] = max(v[0], p.x); v[1] = max(v[1], p.y); v[2] = max(v[2], p.z); v[3] = max(v[3], p.w);
-    }
+__global__ __launch_bounds__(256) void groups_check_final(const uint32_t *__restrict__ part, uint32_t nparts,
+                                                          uint32_t *__restrict__ m) {
+    __shared__ uint32_t s_max[4];
+    uint32_t v = 0;
+    for (uint32_t i = threadIdx.x; i < nparts; i += 256) v = max(v, part[i]);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v[q] = max(v[q], (uint32_t)__shfl_xor((int)v[q], o, 64));
-        if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6][q] = v[q];
-    }
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x < 4) {
-        const uint32_t q = threadIdx.x;
-        m[q] = max(max(s_max[0][q], s_max[1][q]), max(s_max[2][q], s_max[3][q]));
-    }
+    if (threadIdx.x == 0) m[0] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
 }
 
-// One wave per 64-row tile of the row-sorted entries (rows of a tile are
-// contiguous: entries [start[r0], start[r1])).  Everything is entry-parallel --
-// lane l owns entries l, l+64, ... -- so the LDS reads of a phase are
-// independent of each other and pipeline; nothing walks a row lane by lane.
-//   0. one batch of global loads: (row, col, val) of every entry -> registers;
-//      the columns also go to LDS in arrival order.
-//   1. rank: the stable rank of an entry inside its row = number of entries j of
-//      that row with col_j < col_i, or col_j == col_i and j < i.  The entry is
-//      scattered to LDS position rs[row] + rank: the tile is now sorted by
-//      (row, col), equal (row, col) in insertion order.
-//   2. run heads: a sorted position starts a run when its (row, col) differs
-//      from its predecessor's.  The head sums its run left to right = insertion
-//      order (coo.rs:42-46); zero sums are dropped (coo.rs:64).
-//   3. survivors are numbered by ballots in sorted order and written in place
-//      to the FRONT of the tile's segment in global memory (the whole tile sits
-//      in registers / LDS by then), already in final CSR order; kept[row] =
-//      survivors of the row (LDS counters).
-template <typename T, int CAP, int ROWS>
-__global__ __launch_bounds__(256) void coo_tile_sort(const uint32_t *__restrict__ start,
-                                                     const uint32_t *__restrict__ sorted_row,
-                                                     uint32_t *__restrict__ cols, T *__restrict__ vals,
-                                                     uint32_t nrows, uint32_t *__restrict__ kept) {
-    constexpr int K = CAP / 64;
-    __shared__ T s_val2[4][CAP];
-    __shared__ uint32_t s_col[4][CAP];
-    __shared__ uint32_t s_col2[4][CAP];
-    __shared__ uint32_t s_rs[4][ROWS + 1];
-    __shared__ uint32_t s_kept[4][ROWS];
-    __shared__ uint8_t s_row2[4][CAP];
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint64_t tile = (uint64_t)blockIdx.x * 4 + w;
-    const uint64_t r0 = tile * ROWS;
-    if (r0 >= nrows) return;  // wave-uniform
-    const uint32_t r1 = (uint32_t)min<uint64_t>(r0 + ROWS, nrows);
-    const uint32_t e0 = start[r0], e1 = start[r1];
-    const uint32_t n = e1 - e0;  // <= CAP (the host picks CAP from tiles_check's maximum)
-    uint32_t *c = s_col[w], *c2 = s_col2[w], *rs = s_rs[w], *rk = s_kept[w];
-    T *v2 = s_val2[w];
-    uint8_t *r2 = s_row2[w];
-    const uint32_t r = (uint32_t)r0 + lane;
-    if (n == 0) {
-        if (lane < (uint32_t)ROWS && r < r1) kept[r] = 0;
+// The local sort.  The radix passes order the entries by the row bits ABOVE gbits
+// only, so a group of 2^gbits consecutive rows is one contiguous segment
+// [gstart[grp], gstart[grp + 1]) that still holds its entries in insertion order.
+// One workgroup (4 waves) per group finishes the job in LDS -- in effect the last
+// radix pass, the per-row column sort, the duplicate sums and the zero drop in
+// one kernel, with one read and one write of the data.  All phases are
+// entry-parallel:
+//   0. one batch of global loads: (row, col, val) of every entry -> registers.
+//      Wave w owns the entries [w * chunk, (w + 1) * chunk) and walks them 64 at
+//      a time, so insertion order = (wave, round, lane).
+//   1. stable counting sort by the low row bits: the rank of an entry among the
+//      group's entries of the same row = entries of earlier waves + earlier
+//      rounds of this wave + earlier lanes of this round (ballots and per-wave
+//      counters, no atomics); a scan of the row totals gives the row starts rs[].
+//      The column goes to c1[rs[row] + rank]: rows contiguous, insertion order
+//      inside each row.
+//   2. the stable rank of an entry by column inside its row = number of entries
+//      j of the row with col_j < col_i, or col_j == col_i and j before i.  The
+//      entry is scattered to position rs[row] + rank of c2 / v2 / r2: the group
+//      is now sorted by (row, col), equal (row, col) in insertion order.
+//      (Quadratic in the row length, which the group capacity bounds.)
+//   3. a sorted position starts a run when its (row, col) differs from its
+//      predecessor's; the head sums its run left to right = insertion order
+//      (coo.rs:42-46); sums that compare equal to zero are dropped (coo.rs:64).
+//   4. survivors are numbered in sorted order (ballots + a scan of the 4 x K
+//      wave counts) and written in place to the FRONT of the group's segment
+//      (the whole group sits in registers / LDS by then), already in final CSR
+//      order; kept[row] = survivors of the row (LDS counters).
+template <typename T, int CAP>
+__global__ __launch_bounds__(256) void coo_group_sort(const uint32_t *__restrict__ gstart,
+                                                      const uint32_t *__restrict__ sorted_row,
+                                                      uint32_t *__restrict__ cols, T *__restrict__ vals,
+                                                      uint32_t nrows, uint32_t gbits,
+                                                      uint32_t *__restrict__ kept) {
+    constexpr int K = CAP / 256;  // rounds per wave = sorted positions per thread
+    __shared__ T s_v2[CAP];
+    __shared__ uint32_t s_c1[CAP];
+    uint32_t *s_c2 = s_c1;   // (row, col) order replaces the row order in place (a barrier in between)
+    __shared__ uint32_t s_rs[257];
+    __shared__ uint32_t s_rk[256];
+    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_wc[K * 4];
+    __shared__ uint8_t s_r2[CAP];
+    // volatile: lanes of a wave hand counts to each other through this array
+    // between two rounds; the compiler must re-read it every round
+    __shared__ volatile uint32_t s_cnt[4][256];
+
+    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint32_t grp = blockIdx.x;
+    const uint32_t r0 = grp << gbits;                     // < nrows (the grid has ceil(nrows / 2^gbits) groups)
+    const uint32_t nr = min(1u << gbits, nrows - r0);     // rows of this group, <= 256
+    const uint32_t e0 = gstart[grp], n = gstart[grp + 1] - e0;  // n <= CAP (checked by the host)
+    if (n == 0) {  // block-uniform
+        if (t < nr) kept[r0 + t] = 0;
         return;
     }
-    // 0. loads (clamped lanes re-read the last entry)
-    uint32_t rc[K], rid[K];
+    // 0. loads (clamped lanes re-read the last entry) and counter reset
+    const uint32_t chunk = ((n + 255) / 256) * 64;        // entries per wave, a multiple of 64, <= 64 K
+    uint32_t rc[K], rid[K], pos[K];
     T rv[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const uint32_t ic = min(lane + 64u * k, n - 1);
+        const uint32_t ic = min(w * chunk + 64u * k + lane, n - 1);
         rc[k] = cols[e0 + ic];
         rv[k] = vals[e0 + ic];
-        rid[k] = sorted_row[e0 + ic] - (uint32_t)r0;
+        rid[k] = sorted_row[e0 + ic] - r0;
     }
-    if (lane <= (uint32_t)ROWS) rs[lane] = start[min(r, r1)] - e0;   // ROWS < 64: entry ROWS included
-    if (ROWS == 64 && lane == 0) rs[ROWS] = n;
-    if (lane < (uint32_t)ROWS) rk[lane] = 0;
+    for (uint32_t i = t; i < 4 * 256; i += 256) s_cnt[i >> 8][i & 255] = 0;
+    s_rk[t] = 0;
+    __syncthreads();
+    // 1. stable counting sort by row inside the group
+    const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const uint32_t i = lane + 64u * k;
-        if (i < n) c[i] = rc[k];
+        if (64u * k >= chunk) break;  // block-uniform
+        const bool ok = w * chunk + 64u * k + lane < n;
+        const uint32_t d = rid[k];
+        uint64_t peers = __ballot(ok);   // lanes of this round with the same row
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t before = ok ? s_cnt[w][d] : 0u;
+        pos[k] = before + (uint32_t)__popcll(peers & lt);
+        // the lowest peer lane publishes the new count (one writer per row)
+        if (ok && (peers & lt) == 0) s_cnt[w][d] = before + (uint32_t)__popcll(peers);
     }
-    __builtin_amdgcn_wave_barrier();
-    // 1. ranks -> sorted order
+    __syncthreads();
+    {   // thread d: exclusive prefix of row d's counts over the waves, then the row starts
+        uint32_t run = 0;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const uint32_t c = s_cnt[ww][t];
+            s_cnt[ww][t] = run;
+            run += c;
+        }
+        const uint32_t inc = wave_inclusive_scan(run);
+        if (lane == 63) s_wsum[w] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i)
+            if (i < w) base += s_wsum[i];
+        s_rs[t] = base + inc - run;
+        if (t == 255) s_rs[256] = base + inc;  // = n
+    }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const uint32_t i = lane + 64u * k;
-        if (64u * k >= n) break;  // wave-uniform
-        if (i < n) {
-            const uint32_t lr = rid[k];
-            const uint32_t a = rs[lr], b = rs[lr + 1];
-            const uint32_t ci = rc[k];
-            uint32_t rank = 0, j = a;
-            for (; j + 4 <= b; j += 4) {
-                const uint32_t c0 = c[j], c1 = c[j + 1], c2_ = c[j + 2], c3 = c[j + 3];
-                rank += (uint32_t)((c0 < ci) | ((c0 == ci) & (j < i)));
-                rank += (uint32_t)((c1 < ci) | ((c1 == ci) & (j + 1 < i)));
-                rank += (uint32_t)((c2_ < ci) | ((c2_ == ci) & (j + 2 < i)));
-                rank += (uint32_t)((c3 < ci) | ((c3 == ci) & (j + 3 < i)));
-            }
-            for (; j < b; ++j) {
-                const uint32_t cj = c[j];
-                rank += (uint32_t)((cj < ci) | ((cj == ci) & (j < i)));
-            }
-            const uint32_t p = a + rank;
-            c2[p] = ci;
-            v2[p] = rv[k];
-            r2[p] = (uint8_t)lr;
+        if (64u * k >= chunk) break;
+        if (w * chunk + 64u * k + lane < n) {
+            pos[k] += s_rs[rid[k]] + s_cnt[w][rid[k]];   // place in row order, insertion order inside the row
+            s_c1[pos[k]] = rc[k];
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    // 2. + 3. heads, run sums, numbering, in-place write
-    const uint64_t lt = (1ull << lane) - 1ull;
-    uint32_t base = 0;
+    __syncthreads();
+    // 2. rank by column inside the row -> (row, col) order
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        if (64u * k >= n) break;  // wave-uniform
-        const uint32_t p = lane + 64u * k;
+        if (64u * k >= chunk) break;
+        if (w * chunk + 64u * k + lane < n) {
+            const uint32_t d = rid[k], a = s_rs[d], b = s_rs[d + 1], ci = rc[k], i = pos[k];
+            uint32_t rank = 0, j = a;
+            for (; j + 4 <= b; j += 4) {
+                const uint32_t q0 = s_c1[j], q1 = s_c1[j + 1], q2 = s_c1[j + 2], q3 = s_c1[j + 3];
+                rank += (uint32_t)((q0 < ci) | ((q0 == ci) & (j < i)));
+                rank += (uint32_t)((q1 < ci) | ((q1 == ci) & (j + 1 < i)));
+                rank += (uint32_t)((q2 < ci) | ((q2 == ci) & (j + 2 < i)));
+                rank += (uint32_t)((q3 < ci) | ((q3 == ci) & (j + 3 < i)));
+            }
+            for (; j < b; ++j) {
+                const uint32_t q = s_c1[j];
+                rank += (uint32_t)((q < ci) | ((q == ci) & (j < i)));
+            }
+            pos[k] = a + rank;
+        }
+    }
+    __syncthreads();   // every rank is known: the row-ordered columns may be overwritten
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (64u * k >= chunk) break;
+        if (w * chunk + 64u * k + lane < n) {
+            s_c2[pos[k]] = rc[k];
+            s_v2[pos[k]] = rv[k];
+            s_r2[pos[k]] = (uint8_t)rid[k];
+        }
+    }
+    __syncthreads();
+    // 3. heads and run sums; thread t takes the sorted positions t, t + 256, ...
+    T acc[K];
+    uint64_t keepm[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        keepm[k] = 0;
+        acc[k] = T(0);
+        if (256u * k >= n) continue;  // block-uniform
+        const uint32_t p = 256u * k + t;
         const bool live = p < n;
         const uint32_t pc = live ? p : n - 1, pp = pc ? pc - 1 : 0, pn = min(pc + 1, n - 1);
-        const uint32_t cp = c2[pc], cprev = c2[pp], cnext = c2[pn];
-        const uint32_t rp = r2[pc], rprev = r2[pp], rnext = r2[pn];
-        T acc = v2[pc];
+        const uint32_t cp = s_c2[pc], cprev = s_c2[pp], cnext = s_c2[pn];
+        const uint32_t rp = s_r2[pc], rprev = s_r2[pp], rnext = s_r2[pn];
+        T a = s_v2[pc];
         const bool head = live && (pc == 0 || cprev != cp || rprev != rp);
         const bool dup = head && pn != pc && cnext == cp && rnext == rp;
         if (__any(dup)) {  // duplicates are rare: most waves skip this
             if (dup) {
-                for (uint32_t q = pc + 1; q < n && c2[q] == cp && r2[q] == rp; ++q) acc = acc + v2[q];
+                for (uint32_t q = pc + 1; q < n && s_c2[q] == cp && s_r2[q] == rp; ++q) a = a + s_v2[q];
             }
         }
-        const bool keep = head && acc != T(0);
-        const uint64_t m = __ballot(keep);
-        if (keep) {
-            const uint32_t o = e0 + base + (uint32_t)__popcll(m & lt);
-            cols[o] = cp;
-            vals[o] = acc;
-            atomicAdd(&rk[rp], 1u);
-        }
-        base += (uint32_t)__popcll(m);
+        const bool keep = head && a != T(0);
+        acc[k] = a;
+        keepm[k] = __ballot(keep);
+        if (lane == 0) s_wc[k * 4 + w] = (uint32_t)__popcll(keepm[k]);
     }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < (uint32_t)ROWS && r < r1) kept[r] = rk[lane];
+    __syncthreads();
+    // 4. numbering in sorted order = (round, wave, lane); in-place write; row counts
+    if (t < 64) {  // K * 4 <= 64 wave counts: one wave scans them
+        const uint32_t kk = min(t, (uint32_t)(K * 4 - 1));
+        const uint32_t c = (t < (uint32_t)(K * 4) && 256u * (kk >> 2) < n) ? s_wc[kk] : 0u;
+        const uint32_t inc = wave_inclusive_scan(c);
+        if (t < (uint32_t)(K * 4)) s_wc[t] = inc - c;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (256u * k >= n) continue;
+        if ((keepm[k] >> lane) & 1ull) {
+            const uint32_t p = 256u * k + t;
+            const uint32_t o = e0 + s_wc[k * 4 + w] + (uint32_t)__popcll(keepm[k] & lt);
+            cols[o] = s_c2[p];
+            vals[o] = acc[k];
+            atomicAdd(&s_rk[s_r2[p]], 1u);
+        }
+    }
+    __syncthreads();
+    if (t < nr) kept[r0 + t] = s_rk[t];
 }
 
-// Moves the survivors of every tile (contiguous at the front of the tile's
-// segment, see above) to their final place rowptr[first row of the tile]: one
-// wave per tile, a straight coalesced copy.
-template <typename T, int CAP, int ROWS>
-__global__ __launch_bounds__(256) void coo_tile_pack(const uint32_t *__restrict__ start,
-                                                     const uint32_t *__restrict__ rowptr,
-                                                     const uint32_t *__restrict__ cols,
-                                                     const T *__restrict__ vals, uint32_t nrows,
-                                                     uint32_t *__restrict__ out_col,
-                                                     T *__restrict__ out_val) {
-    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint64_t tile = (uint64_t)blockIdx.x * 4 + w;
-    const uint64_t r0 = tile * ROWS;
-    if (r0 >= nrows) return;
-    const uint32_t r1 = (uint32_t)min<uint64_t>(r0 + ROWS, nrows);
-    const uint32_t e0 = start[r0], o0 = rowptr[r0], cnt = rowptr[r1] - o0;
-    constexpr int K = CAP / 64;
+// Moves the survivors of every group (contiguous at the front of the group's
+// segment, see above) to their final place rowptr[first row of the group]: a
+// straight coalesced copy, one workgroup per group.
+template <typename T, int CAP>
+__global__ __launch_bounds__(256) void coo_group_pack(const uint32_t *__restrict__ gstart,
+                                                      const uint32_t *__restrict__ rowptr,
+                                                      const uint32_t *__restrict__ cols,
+                                                      const T *__restrict__ vals, uint32_t nrows,
+                                                      uint32_t gbits, uint32_t *__restrict__ out_col,
+                                                      T *__restrict__ out_val) {
+    constexpr int K = CAP / 256;
+    const uint32_t grp = blockIdx.x;
+    const uint32_t r0 = grp << gbits, r1 = r0 + min(1u << gbits, nrows - r0);
+    const uint32_t e0 = gstart[grp], o0 = rowptr[r0], cnt = rowptr[r1] - o0;
     uint32_t rc[K];
     T rv[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const uint32_t j = lane + 64u * k;
+        const uint32_t j = threadIdx.x + 256u * k;
         rc[k] = 0;
         rv[k] = T(0);
         if (j < cnt) {
@@ -654,7 +701,7 @@ __global__ __launch_bounds__(256) void coo_tile_pack(const uint32_t *__restrict_
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const uint32_t j = lane + 64u * k;
+        const uint32_t j = threadIdx.x + 256u * k;
         if (j < cnt) {
             out_col[o0 + j] = rc[k];
             out_val[o0 + j] = rv[k];
@@ -785,58 +832,48 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
     sb.counts = (uint32_t *)(wb + ws.off_counts);
     sb.sums = sums.as<uint32_t>();
 
-    // ---- 1. stable sort by row, (col, value) carried along; the first pass
-    // reads the uploaded triplets directly (they stay untouched)
+    // ---- 1. stable sort by the row bits above gbits, (col, value) carried along; the
+    // first pass reads the uploaded triplets directly (they stay untouched).  Groups
+    // of 2^gbits rows (about a thousand entries on average) are finished in LDS.
+    const double mean = (double)len / (double)nrows;
+    uint32_t gbits = 8;
+    while (gbits > 0 && mean * (double)(1u << gbits) > 1400.0) --gbits;
+    if (gbits >= rbits) gbits = rbits - 1;  // at least one pass: it also brings the triplets into the workspace
     int cur = 0;
-    SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, 0, rbits, cur, st, d_major, d_minor,
+    SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, gbits, rbits - gbits, cur, st, d_major, d_minor,
                                     (const T *)c->d_vals));
-    // ---- 2. row offsets; longest row and fullest tiles
-    launch_row_starts(sb.key[cur], (uint32_t)len, nrows, start.as<uint32_t>(), st);
+    // ---- 2. group offsets; the fullest group
+    const uint32_t ngroups = (uint32_t)(((uint64_t)nrows + (1u << gbits) - 1) >> gbits);
+    launch_row_starts(sb.key[cur], (uint32_t)len, ngroups, start.as<uint32_t>(), st, gbits);
     {
-        const uint32_t nparts = std::max<uint32_t>(std::min<uint32_t>((nrows + 255) / 256, (uint32_t)kCheckBlocks), 1u);
-        uint4 *part = reinterpret_cast<uint4 *>(flag.p + 16);
-        hipLaunchKernelGGL(tiles_check, dim3(nparts), dim3(256), 0, st, start.as<uint32_t>(), nrows, part);
-        hipLaunchKernelGGL(tiles_check_final, dim3(1), dim3(256), 0, st, part, nparts, flag.as<uint32_t>());
+        const uint32_t nparts = std::max<uint32_t>(std::min<uint32_t>((ngroups + 255) / 256, (uint32_t)kCheckBlocks), 1u);
+        uint32_t *part = reinterpret_cast<uint32_t *>(flag.p + 16);
+        hipLaunchKernelGGL(groups_check, dim3(nparts), dim3(256), 0, st, start.as<uint32_t>(), ngroups, part);
+        hipLaunchKernelGGL(groups_check_final, dim3(1), dim3(256), 0, st, part, nparts, flag.as<uint32_t>());
     }
-    uint32_t chk[4] = {0, 0, 0, 0};
-    SPAL_HIP_TRY(hipMemcpyAsync(chk, flag.p, 16, hipMemcpyDeviceToHost, st));
+    uint32_t fullest = 0;
+    SPAL_HIP_TRY(hipMemcpyAsync(&fullest, flag.p, 4, hipMemcpyDeviceToHost, st));
     SPAL_HIP_TRY(hipStreamSynchronize(st));
-    // Tile geometry of the local sort: LDS is 17 B per entry of capacity, so the
-    // smaller the tiles the more waves a CU holds while others wait on their
-    // loads.  Widest tile whose fullest instance stays within 512 entries;
-    // failing that 16-row tiles of up to 1024; failing that the general route.
-    int tile_rows = 0, tile_cap = 0;
-    if (chk[0] <= (uint32_t)kRowCap) {
-        for (int q = 1; q <= 3 && !tile_rows; ++q)
-            if (chk[q] <= 512) { tile_rows = 128 >> q; tile_cap = chk[q] <= 256 ? 256 : 512; }
-        if (!tile_rows && chk[3] <= (uint32_t)kTileCap) { tile_rows = 16; tile_cap = kTileCap; }
-    }
-    c->last_tile_rows = tile_rows;
-    c->last_tile_cap = tile_cap;
+    // LDS of the group kernel is 17 B per entry of capacity: the smallest capacity
+    // that holds the fullest group (more workgroups per CU); none -> general route
+    const int group_cap = fullest <= 512 ? 512 : fullest <= 1024 ? 1024 : fullest <= 1536 ? 1536
+                          : fullest <= (uint32_t)kGroupCap ? kGroupCap : 0;
+    c->last_group_rows = group_cap ? (int)(1u << gbits) : 0;
+    c->last_group_cap = group_cap;
     if (getenv("SPAL_COO_DEBUG"))
-        fprintf(stderr, "[spal coo] longest row %u, fullest tile 64/32/16 rows: %u %u %u -> tile %d x %d\n",
-                chk[0], chk[1], chk[2], chk[3], tile_rows, tile_cap);
+        fprintf(stderr, "[spal coo] %.2f entries/row -> groups of %u rows, fullest %u -> capacity %d%s\n", mean,
+                1u << gbits, fullest, group_cap, group_cap ? "" : " (general route)");
 
     uint32_t nnz = 0;
     DevBuf ocol, oval;
-    if (tile_rows) {
-        // ---- 3. per-row stable sort by column + run sums + zero drop, in LDS
-        const uint32_t ntiles = (uint32_t)(((uint64_t)nrows + tile_rows - 1) / tile_rows);
-        void (*k_sort)(const uint32_t *, const uint32_t *, uint32_t *, T *, uint32_t, uint32_t *) = nullptr;
-        void (*k_pack)(const uint32_t *, const uint32_t *, const uint32_t *, const T *, uint32_t, uint32_t *,
-                       T *) = nullptr;
-#define SPAL_TILE_GEOM(R, C)                                                        \
-    if (tile_rows == R && tile_cap == C) {                                          \
-        k_sort = coo_tile_sort<T, C, R>;                                            \
-        k_pack = coo_tile_pack<T, C, R>;                                            \
-    }
-        SPAL_TILE_GEOM(64, 256) SPAL_TILE_GEOM(64, 512) SPAL_TILE_GEOM(32, 256) SPAL_TILE_GEOM(32, 512)
-        SPAL_TILE_GEOM(16, 256) SPAL_TILE_GEOM(16, 512) SPAL_TILE_GEOM(16, 1024)
-#undef SPAL_TILE_GEOM
-        if (!k_sort) return fail(SPAL_ERR_UNSUPPORTED, "internal: no tile geometry");
-        hipLaunchKernelGGL(k_sort, dim3((ntiles + 3) / 4), dim3(256), 0, st,
-                           start.as<uint32_t>(), sb.key[cur], sb.aux[cur], sb.val[cur], nrows,
-                           kept.as<uint32_t>());
+    if (group_cap) {
+        // ---- 3. per group: rows, columns, run sums, zero drop -- in LDS
+        auto k_sort = group_cap == 512 ? coo_group_sort<T, 512> : group_cap == 1024 ? coo_group_sort<T, 1024>
+                      : group_cap == 1536 ? coo_group_sort<T, 1536> : coo_group_sort<T, kGroupCap>;
+        auto k_pack = group_cap == 512 ? coo_group_pack<T, 512> : group_cap == 1024 ? coo_group_pack<T, 1024>
+                      : group_cap == 1536 ? coo_group_pack<T, 1536> : coo_group_pack<T, kGroupCap>;
+        hipLaunchKernelGGL(k_sort, dim3(ngroups), dim3(256), 0, st, start.as<uint32_t>(), sb.key[cur],
+                           sb.aux[cur], sb.val[cur], nrows, gbits, kept.as<uint32_t>());
         // ---- 4. rowptr = scan of the kept counts; pack
         SPAL_HIP_TRY(exclusive_scan_u32(kept.as<uint32_t>(), rowptr.as<uint32_t>(), nrows,
                                         sums.as<uint32_t>(), total.as<uint32_t>(), st, true));
@@ -847,9 +884,9 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
         SPAL_HIP_TRY(oval.alloc(cap * sizeof(T)));
         SPAL_HIP_TRY(hipMemsetAsync((char *)ocol.p + (size_t)nnz * 4, 0, 256 * 4, st));
         SPAL_HIP_TRY(hipMemsetAsync((char *)oval.p + (size_t)nnz * sizeof(T), 0, 256 * sizeof(T), st));
-        hipLaunchKernelGGL(k_pack, dim3((ntiles + 3) / 4), dim3(256), 0, st,
-                           start.as<uint32_t>(), rowptr.as<uint32_t>(), sb.aux[cur], sb.val[cur], nrows,
-                           ocol.as<uint32_t>(), oval.as<T>());
+        hipLaunchKernelGGL(k_pack, dim3(ngroups), dim3(256), 0, st, start.as<uint32_t>(),
+                           rowptr.as<uint32_t>(), sb.aux[cur], sb.val[cur], nrows, gbits, ocol.as<uint32_t>(),
+                           oval.as<T>());
         SPAL_HIP_TRY(hipGetLastError());
         SPAL_HIP_TRY(hipStreamSynchronize(st));
         res.ptr = (uint32_t *)rowptr.release(); res.ind = (uint32_t *)ocol.release();
@@ -1073,10 +1110,10 @@ int spal_coo_describe(spal_coo_t c, char *buf, size_t buf_len) {
     if (!c || !buf || !buf_len) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_coo_describe: null argument");
     snprintf(buf, buf_len,
              "{\"format\": \"coo\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"len\": %llu, "
-             "\"last_route\": \"%s\", \"tile_rows\": %d, \"tile_cap\": %d}",
+             "\"last_route\": \"%s\", \"group_rows\": %d, \"group_cap\": %d}",
              c->elem_size == 8 ? "f64" : "f32", (unsigned long long)c->nrows, (unsigned long long)c->ncols,
-             (unsigned long long)c->len, c->last_tile_rows ? "local_sort" : "general", c->last_tile_rows,
-             c->last_tile_cap);
+             (unsigned long long)c->len, c->last_group_rows ? "local_sort" : "general", c->last_group_rows,
+             c->last_group_cap);
     return SPAL_OK;
 }
 int spal_coo_assemble_csr(spal_coo_t c, void *stream, spal_csr_t *out) {

@@ -164,7 +164,7 @@ struct spal_coo {
     void *d_work = nullptr;   // sort buffers + scratch of the assembly, allocated at upload
     size_t work_bytes = 0;
     std::mutex mu;            // serialises assemblies on one handle (shared workspace)
-    int last_tile_rows = 0, last_tile_cap = 0;  // geometry of the last assembly's local sort (0 = general route)
+    int last_group_rows = 0, last_group_cap = 0;  // geometry of the last assembly's local sort (0 = general route)
 };
 
 namespace spal {

@@ -275,27 +275,29 @@ def test_config5_scaled_assembly(oracle):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_coo_local_sort_geometries(oracle, dtype):
-    """Every tile geometry of the LDS local sort (64/32/16 rows x 256/512/1024
-    entries), the general route (a row above 128 entries) and very sparse rows
-    (row starts by binary search), each bit-exact against the oracle.  Empty rows,
-    duplicates (same (row, col) several times) and exact zeros in every case."""
+    """Every geometry of the LDS local sort (groups of 256 ... 8 rows, capacities
+    512 / 1024 / 1536 / 2048 entries), the general route (a group above 2048 entries)
+    and very sparse rows (group starts by binary search), each bit-exact against
+    the oracle.  Empty rows, duplicates (same (row, col) several times) and exact
+    zeros in every case."""
     rng = np.random.default_rng(77)
     seen = set()
     for nr, per_row in [(20_000, 1), (20_000, 3), (20_000, 6), (20_000, 12), (12_000, 24),
-                        (8_000, 45), (4_000, 100), (300_000, 0.01), (20_001, 7)]:
+                        (8_000, 45), (4_000, 100), (300_000, 0.01), (20_001, 7), (20_000, 10),
+                        (200, 600), (64, 1500), (300, 850)]:   # the last three: groups of 2 rows / 1 row, long rows
         n = max(1, int(nr * per_row))
         nc = 50 if per_row < 1 else 4 * max(1, int(per_row))     # few columns: many duplicates
         r = rng.integers(0, nr, n).astype(np.uint64)
         r[r % 11 == 3] = r[r % 11 == 3] // 11 * 11                 # empty rows, some fuller rows
-        if per_row >= 100:
-            r[: 400] = 17                                         # a row above the 128-entry cap
+        if per_row == 100:
+            r[: 3000] = 17                                        # a row above the group capacity
         c = rng.integers(0, nc, n).astype(np.uint64)
         v = rng.integers(-3, 4, n).astype(dtype) * dtype(0.37)    # sums that cancel exactly do occur
         coo = sp.CooMatrix.with_triplets(nr, nc, r, c, v)
         dev = coo.upload()
         got = dev.assemble_csr()
         d = dev.describe()
-        seen.add((d["last_route"], d["tile_rows"], d["tile_cap"]))
+        seen.add((d["last_route"], d["group_rows"], d["group_cap"]))
         p, i, w = oracle.coo_to_csr(nr, nc, r, c, v)
         gp, gi, gw = got.download()
         bits = np.uint64 if dtype == np.float64 else np.uint32
@@ -304,5 +306,5 @@ def test_coo_local_sort_geometries(oracle, dtype):
         got.close()
         dev.close()
     assert ("general", 0, 0) in seen
-    assert {g[1] for g in seen} >= {64, 32, 16}, seen
-    assert {g[2] for g in seen} >= {256, 512, 1024}, seen
+    assert len({g[1] for g in seen}) >= 5, seen                  # 256, 128, 64, 32, ... rows per group
+    assert {g[2] for g in seen} >= {512, 1024, 1536, 2048}, seen
