@@ -20,8 +20,14 @@
 
 namespace spal {
 
-constexpr int kCscBlock = 256;
-constexpr int kCscCols = 512;                  // columns per super-tile
+#ifndef SPAL_CSC_BLOCK
+#define SPAL_CSC_BLOCK 1024
+#endif
+#ifndef SPAL_CSC_COLS
+#define SPAL_CSC_COLS 1024
+#endif
+constexpr int kCscBlock = SPAL_CSC_BLOCK;      // threads of the scatter kernel
+constexpr int kCscCols = SPAL_CSC_COLS;        // columns per super-tile
 constexpr uint32_t kCscWindowBytes = 48 * 1024;  // LDS y window budget (+ 8 KiB x tile)
 constexpr uint32_t kCscModeGlobal = 0, kCscModeLds = 1;
 
@@ -71,11 +77,11 @@ __device__ __forceinline__ void lds_add(T *p, T v) {
 
 // desc[b] = {window base row, window length, mode, 0}
 template <typename T, int L>
-__global__ __launch_bounds__(kCscBlock, 2) void csc_spmv_scatter(
+__global__ __launch_bounds__(kCscBlock, kCscBlock >= 1024 ? 1 : 2) void csc_spmv_scatter(
     const uint32_t *__restrict__ colptr, const uint32_t *__restrict__ rowind,
     const uint32_t *__restrict__ meta, const T *__restrict__ vals, const T *__restrict__ x,
     T *__restrict__ y, const uint4 *__restrict__ desc, uint32_t ncols, uint32_t nblocks,
-    uint32_t per_xcd) {
+    uint32_t per_xcd, uint32_t last_pair, T *__restrict__ windows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
     using pair_t = typename Pair<T>::type;
     using u2_t = __attribute__((ext_vector_type(2))) uint32_t;
@@ -100,7 +106,9 @@ __global__ __launch_bounds__(kCscBlock, 2) void csc_spmv_scatter(
             u2_t m[U];
 #pragma unroll
             for (uint32_t u = 0; u < U; ++u) {
-                const uint32_t e = base + u * (kCscBlock * 2);  // the arrays are padded: no clamp
+                // unconditional loads; a step may reach past the super-tile's last entry: stay
+                // inside the allocation (last_pair = last even index of the padded arrays)
+                const uint32_t e = min(base + u * (kCscBlock * 2), last_pair);
                 v[u] = __builtin_nontemporal_load(reinterpret_cast<const pair_t *>(vals + e));
                 m[u] = __builtin_nontemporal_load(reinterpret_cast<const u2_t *>(meta + e));
             }
@@ -112,6 +120,13 @@ __global__ __launch_bounds__(kCscBlock, 2) void csc_spmv_scatter(
             }
         }
         __syncthreads();
+        if (windows) {
+            // two-phase flush: the window goes to this super-tile's slot (plain coalesced
+            // stores); csc_window_reduce adds the overlapping windows row by row
+            T *slot = windows + d.w;
+            for (uint32_t i = threadIdx.x; i < d.y; i += kCscBlock) slot[i] = yw[i];
+            return;
+        }
         // flush: contiguous, one atomic per touched row (adding 0.0 changes nothing)
         for (uint32_t i = threadIdx.x; i < d.y; i += kCscBlock) {
             const T s = yw[i];
@@ -131,6 +146,41 @@ __global__ __launch_bounds__(kCscBlock, 2) void csc_spmv_scatter(
             const uint32_t i = load_stream(rowind + p);
             const T v = load_stream(vals + p);
             atomicAdd(&y[i], v * xk);  // -munsafe-fp-atomics: global_atomic_add_f64 / _f32
+        }
+    }
+}
+
+// Second phase of the two-phase flush: one workgroup per chunk of kCscChunk rows adds
+// the windows of the super-tiles that overlap the chunk, in ascending super-tile
+// (= column) order, and writes y (ASSIGN: no super-tile went the global-atomic way,
+// y was not zeroed) or adds to it (the kernel before has finished: plain update).
+constexpr uint32_t kCscChunk = 1024;
+template <typename T, bool ASSIGN>
+__global__ __launch_bounds__(256) void csc_window_reduce(const T *__restrict__ windows,
+                                                         const uint4 *__restrict__ desc,
+                                                         const uint32_t *__restrict__ chunk_ptr,
+                                                         const uint32_t *__restrict__ chunk_blk,
+                                                         T *__restrict__ y, uint32_t nrows) {
+    const uint32_t c0 = chunk_ptr[blockIdx.x], c1 = chunk_ptr[blockIdx.x + 1];  // uniform
+    if (!ASSIGN && c0 == c1) return;
+    const uint32_t r0 = blockIdx.x * kCscChunk;
+    T acc[kCscChunk / 256];
+#pragma unroll
+    for (uint32_t k = 0; k < kCscChunk / 256; ++k) acc[k] = T(0);
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint4 d = desc[chunk_blk[c]];  // uniform: {window base, length, mode, slot offset}
+#pragma unroll
+        for (uint32_t k = 0; k < kCscChunk / 256; ++k) {
+            const uint32_t i = r0 + threadIdx.x + 256u * k;
+            if (i >= d.x && i - d.x < d.y) acc[k] = acc[k] + windows[d.w + (i - d.x)];
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kCscChunk / 256; ++k) {
+        const uint32_t i = r0 + threadIdx.x + 256u * k;
+        if (i < nrows) {
+            if (ASSIGN) y[i] = acc[k];
+            else y[i] = y[i] + acc[k];
         }
     }
 }
@@ -158,23 +208,38 @@ static hipError_t csc_launch_l(const spal_csc *a, const void *x, void *y, hipStr
     }
     hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(kCscBlock), lds, st, a->d_colptr, a->d_rowind,
                        a->d_meta, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc,
-                       (uint32_t)a->ncols, a->nblocks, per_xcd);
+                       (uint32_t)a->ncols, a->nblocks, per_xcd,
+                       (uint32_t)(((a->nnz + kStreamPad) & ~(uint64_t)1) - 2),
+                       (a->flush && a->d_windows) ? (T *)a->d_windows : (T *)nullptr);
     return hipGetLastError();
 }
 
 template <typename T>
 static hipError_t csc_launch_t(const spal_csc *a, const void *x, void *y, hipStream_t st) {
-    hipError_t e = hipMemsetAsync(y, 0, a->nrows * sizeof(T), st);
+    const bool two_phase = a->flush && a->d_windows;
+    const bool assign = two_phase && a->all_lds;   // the reduce writes every row of y: no memset
+    hipError_t e = hipSuccess;
+    if (!assign || a->nnz == 0) e = hipMemsetAsync(y, 0, a->nrows * sizeof(T), st);
     if (e != hipSuccess || a->nnz == 0) return e;
     switch (a->lanes_per_col) {
-        case 2: return csc_launch_l<T, 2>(a, x, y, st);
-        case 4: return csc_launch_l<T, 4>(a, x, y, st);
-        case 8: return csc_launch_l<T, 8>(a, x, y, st);
-        case 16: return csc_launch_l<T, 16>(a, x, y, st);
-        case 32: return csc_launch_l<T, 32>(a, x, y, st);
-        case 64: return csc_launch_l<T, 64>(a, x, y, st);
+        case 2: e = csc_launch_l<T, 2>(a, x, y, st); break;
+        case 4: e = csc_launch_l<T, 4>(a, x, y, st); break;
+        case 8: e = csc_launch_l<T, 8>(a, x, y, st); break;
+        case 16: e = csc_launch_l<T, 16>(a, x, y, st); break;
+        case 32: e = csc_launch_l<T, 32>(a, x, y, st); break;
+        case 64: e = csc_launch_l<T, 64>(a, x, y, st); break;
         default: return hipErrorInvalidValue;
     }
+    if (e != hipSuccess || !two_phase) return e;
+    if (assign)
+        hipLaunchKernelGGL((csc_window_reduce<T, true>), dim3(a->nchunks), dim3(256), 0, st,
+                           (const T *)a->d_windows, a->d_desc, a->d_chunk_ptr, a->d_chunk_blk, (T *)y,
+                           (uint32_t)a->nrows);
+    else
+        hipLaunchKernelGGL((csc_window_reduce<T, false>), dim3(a->nchunks), dim3(256), 0, st,
+                           (const T *)a->d_windows, a->d_desc, a->d_chunk_ptr, a->d_chunk_blk, (T *)y,
+                           (uint32_t)a->nrows);
+    return hipGetLastError();
 }
 
 static int csc_ensure_csr(spal_csc *a);
@@ -194,6 +259,12 @@ static int csc_launch(spal_csc *a, const void *x, void *y, hipStream_t st) {
 static int csc_plan_build(spal_csc *a) {
     a->nblocks = (uint32_t)((a->ncols + kCscCols - 1) / kCscCols);
     if (a->d_desc) { SPAL_HIP_TRY(dev_free(a->d_desc)); a->d_desc = nullptr; }
+    if (a->d_windows) { SPAL_HIP_TRY(dev_free(a->d_windows)); a->d_windows = nullptr; }
+    if (a->d_chunk_ptr) { SPAL_HIP_TRY(dev_free(a->d_chunk_ptr)); a->d_chunk_ptr = nullptr; }
+    if (a->d_chunk_blk) { SPAL_HIP_TRY(dev_free(a->d_chunk_blk)); a->d_chunk_blk = nullptr; }
+    a->windows_entries = 0;
+    a->all_lds = 0;
+    a->nchunks = 0;
     a->lds_entries = 0;
     a->lds_col_fraction = 0.0;
     std::vector<uint4> desc(a->nblocks, make_uint4(0, 0, kCscModeGlobal, 0));
@@ -209,18 +280,46 @@ static int csc_plan_build(spal_csc *a) {
         (void)dev_free(d_win);
         SPAL_HIP_TRY(e);
         const uint32_t budget = std::min<uint32_t>(kCscWindowBytes / (uint32_t)a->elem_size, 65536u);
-        uint64_t cols_lds = 0;
+        uint64_t cols_lds = 0, slot = 0;
+        bool all_lds = true;
+        a->nchunks = (uint32_t)((a->nrows + kCscChunk - 1) / kCscChunk);
+        std::vector<uint32_t> cover_count(a->nchunks + 1, 0);
         for (uint32_t b = 0; b < a->nblocks; ++b) {
             const uint2 w = win[b];
             if (w.y == 0) continue;  // no entries: the global path finds nothing to do
             const uint32_t len = w.y - w.x;
-            if (len <= budget) {
-                desc[b] = make_uint4(w.x, len, kCscModeLds, 0);
+            if (len <= budget && slot + len < 0xffffffffull) {
+                desc[b] = make_uint4(w.x, len, kCscModeLds, (uint32_t)slot);
+                slot += (len + 1) & ~1ull;   // slots start on even elements
                 a->lds_entries = std::max(a->lds_entries, len);
                 cols_lds += std::min<uint64_t>(kCscCols, a->ncols - (uint64_t)b * kCscCols);
+                for (uint32_t c = w.x / kCscChunk; c <= (w.y - 1) / kCscChunk; ++c) ++cover_count[c + 1];
+            } else {
+                all_lds = false;
             }
         }
         a->lds_col_fraction = (double)cols_lds / (double)a->ncols;
+        a->all_lds = all_lds ? 1 : 0;
+        // cover lists (chunk of rows -> LDS-mode super-tiles whose window overlaps it, ascending)
+        for (uint32_t c = 0; c < a->nchunks; ++c) cover_count[c + 1] += cover_count[c];
+        std::vector<uint32_t> cover(cover_count[a->nchunks]), fill(cover_count.begin(), cover_count.end() - 1);
+        for (uint32_t b = 0; b < a->nblocks; ++b) {
+            if (desc[b].z != kCscModeLds) continue;
+            for (uint32_t c = desc[b].x / kCscChunk; c <= (desc[b].x + desc[b].y - 1) / kCscChunk; ++c)
+                cover[fill[c]++] = b;
+        }
+        a->windows_entries = slot;
+        if (slot) {
+            SPAL_HIP_TRY(dev_alloc(&a->d_windows, (size_t)slot * a->elem_size));
+            SPAL_HIP_TRY(dev_alloc((void **)&a->d_chunk_ptr, (size_t)(a->nchunks + 1) * 4));
+            SPAL_HIP_TRY(dev_alloc((void **)&a->d_chunk_blk, std::max<size_t>(cover.size(), 1) * 4));
+            SPAL_HIP_TRY(hipMemcpyAsync(a->d_chunk_ptr, cover_count.data(), (size_t)(a->nchunks + 1) * 4,
+                                        hipMemcpyHostToDevice, a->stream));
+            if (!cover.empty())
+                SPAL_HIP_TRY(hipMemcpyAsync(a->d_chunk_blk, cover.data(), cover.size() * 4,
+                                            hipMemcpyHostToDevice, a->stream));
+            SPAL_HIP_TRY(hipStreamSynchronize(a->stream));  // the host vectors go out of scope
+        }
     }
     SPAL_HIP_TRY(dev_alloc((void **)&a->d_desc, (size_t)a->nblocks * sizeof(uint4)));
     SPAL_HIP_TRY(hipMemcpyAsync(a->d_desc, desc.data(), (size_t)a->nblocks * sizeof(uint4),
@@ -269,6 +368,7 @@ int csc_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, 
     auto bail = [&](int st) {
         a->d_colptr = nullptr; a->d_rowind = nullptr; a->d_values = nullptr;  // stay with the caller
         (void)dev_free(a->d_meta); (void)dev_free(a->d_desc);
+        (void)dev_free(a->d_windows); (void)dev_free(a->d_chunk_ptr); (void)dev_free(a->d_chunk_blk);
         if (a->stream) (void)hipStreamDestroy(a->stream);
         delete a;
         return st;
@@ -293,6 +393,9 @@ static void csc_free(spal_csc *a) {
     (void)dev_free(a->d_values);
     (void)dev_free(a->d_meta);
     (void)dev_free(a->d_desc);
+    (void)dev_free(a->d_windows);
+    (void)dev_free(a->d_chunk_ptr);
+    (void)dev_free(a->d_chunk_blk);
     (void)dev_free(a->d_x);
     (void)dev_free(a->d_y);
     if (a->stream) (void)hipStreamDestroy(a->stream);
@@ -529,6 +632,14 @@ int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value) {
         if (a->kernel == 2) return csc_ensure_csr(a);
         return SPAL_OK;
     }
+    if (!strcmp(key, "flush")) {
+        // 0 (default) = window rows flushed with global atomics; 1 = LDS windows stored per super-tile,
+        // then an ordered reduce (no global atomics; measured 89.6 vs 80.1 us at config 4: the LDS
+        // atomics, not the flush, bound the kernel)
+        if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "flush must be 0 or 1");
+        a->flush = (int)value;
+        return SPAL_OK;
+    }
     if (!strcmp(key, "lds")) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "lds must be 0 or 1");
         a->use_lds = (int)value;
@@ -541,13 +652,15 @@ int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len) {
     snprintf(buf, buf_len,
              "{\"format\": \"csc\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"nnz\": %llu, "
              "\"kernel\": \"%s\", \"cols_per_block\": %d, \"blocks\": %u, \"lanes_per_col\": %d, "
-             "\"lds_window_bytes\": %llu, \"lds_col_fraction\": %.4f}",
+             "\"lds_window_bytes\": %llu, \"lds_col_fraction\": %.4f, \"flush\": \"%s\", "
+             "\"window_store_bytes\": %llu}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz,
              a->kernel == 2 ? "transposed_csr" : a->lds_entries ? "lds_privatised_scatter" : "atomic_scatter",
              kCscCols, a->nblocks,
              a->lanes_per_col, (unsigned long long)a->lds_entries * (unsigned long long)a->elem_size,
-             a->lds_col_fraction);
+             a->lds_col_fraction, (a->flush && a->d_windows) ? "windows_then_reduce" : "global_atomics",
+             (unsigned long long)a->windows_entries * (unsigned long long)a->elem_size);
     return SPAL_OK;
 }
 

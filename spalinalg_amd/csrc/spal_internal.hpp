@@ -142,7 +142,15 @@ struct spal_csc {
     uint32_t *d_rowind = nullptr;  // nnz (+pad)
     void *d_values = nullptr;      // nnz (+pad)
     uint32_t *d_meta = nullptr;    // nnz (+pad): (row - window base) | (col - tile base) << 16
-    uint4 *d_desc = nullptr;       // per 512-column super-tile {window base row, length, mode, 0}
+    uint4 *d_desc = nullptr;       // per super-tile of columns {window base row, length, mode, offset of its window in d_windows}
+    // two-phase flush (flush == 1): LDS-mode super-tiles store their y windows here; csc_window_reduce
+    // adds, for every chunk of 1024 rows, the windows that overlap it (ascending super-tile = column order)
+    void *d_windows = nullptr;     // sum of the LDS-mode window lengths, elements
+    uint32_t *d_chunk_ptr = nullptr, *d_chunk_blk = nullptr;  // CSR-like cover lists: chunk -> super-tiles
+    uint32_t nchunks = 0;
+    uint64_t windows_entries = 0;
+    int flush = 0;                 // 0 = global atomics per window row (default: measured faster), 1 = windows + ordered reduce
+    int all_lds = 0;               // every super-tile with entries is in LDS mode: y needs no memset
     uint32_t nblocks = 0;
     uint32_t lds_entries = 0;      // largest LDS y window (elements); 0 = global scatter only
     double lds_col_fraction = 0.0;

@@ -120,7 +120,12 @@ def test_csc_lds_and_global_paths(oracle):
     dev.set_option("kernel", 1)
     d = dev.describe()
     assert d["kernel"] == "lds_privatised_scatter" and 0.8 < d["lds_col_fraction"] < 1.0
+    assert d["flush"] == "global_atomics"                    # default: window rows flushed with atomics
     assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10)
+    dev.set_option("flush", 1)                               # windows stored, then an ordered reduce
+    assert dev.describe()["flush"] == "windows_then_reduce"
+    assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10)
+    dev.set_option("flush", 0)
     dev.set_option("lds", 0)
     assert dev.describe()["kernel"] == "atomic_scatter"
     assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10)
@@ -142,6 +147,9 @@ def test_csc_config4(oracle):
     y_ref = oracle.csc_spmv(n, cp, ri, cv, x)
     assert_spmv_close(y, y_ref, oracle.csr_abs_bound(rp, ci, va, x), 1e-10)
     assert m.device().describe()["lds_col_fraction"] > 0.99
+    m.device().set_option("flush", 1)           # windows + ordered reduce (writes y without a memset here)
+    assert_spmv_close(m * x, y_ref, oracle.csr_abs_bound(rp, ci, va, x), 1e-10)
+    m.device().set_option("flush", 0)
     m32 = sp.CscMatrix(n, n, cp, ri, cv.astype(np.float32))
     m32.device().set_option("kernel", 1)
     y32 = m32 * x.astype(np.float32)

@@ -51,7 +51,7 @@ for s in "$@"; do
     variants) # VARIANTS="name ..." under spalinalg_amd/lib_var/: COO parity tests + lab per variant ("main" = the shipped library)
             for v in ${VARIANTS:-main}; do
               if [ "$v" = main ]; then unset SPAL_HIP_LIB; else export SPAL_HIP_LIB=$PWD/spalinalg_amd/lib_var/$v/libspal_hip.so; fi
-              step 300 var_${v}_tests.log python -m pytest tests/test_gpu_csc_coo.py -x -q -m gpu -k "coo or assembl"
+              step 300 var_${v}_tests.log python -m pytest tests/test_gpu_csc_coo.py -x -q -m gpu -k "${VARIANT_TESTS:-coo or assembl}"
               step 300 var_${v}_lab.log python tools/lab_other.py ${VARIANT_LAB:-coo}
             done
             unset SPAL_HIP_LIB ;;

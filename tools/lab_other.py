@@ -61,10 +61,11 @@ def main():
         y = torch.empty_like(x)
         B = sp.synth.spmv_bytes(n * 14, n, n, n, 8)
         dev.set_option("kernel", 1)
-        for lds in (1, 0):
+        for lds, flush in ((1, 1), (1, 0), (0, 0)):
             dev.set_option("lds", lds)
+            dev.set_option("flush", flush)
             t = timeit(lambda: dev.spmv_torch(x, out=y), 50)
-            print(f"cfg4 CSC scatter f64 lds={lds}             {t*1e3:9.1f} us {B/t/1e6:8.1f} GB/s "
+            print(f"cfg4 CSC scatter f64 lds={lds} flush={flush}     {t*1e3:9.1f} us {B/t/1e6:8.1f} GB/s "
                   f"{100*B/t/1e6/8000:6.2f} %peak {dev.describe()}", flush=True)
     if "coo" in which:
         for length, nr in ((5_000_000, 500_000), (50_000_000, 5_000_000)):
