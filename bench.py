@@ -469,6 +469,8 @@ def main():
         try:
             t = json.load(open(tpath))
             key = f"config{args.config}_{args.dist}_{args.dtype}_n{world}"
+            if plan.get("persistent"):      # the form the autotune kept has its own counter run
+                key += "_persistent"
             traffic = t.get(key, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
