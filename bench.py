@@ -340,6 +340,15 @@ def main():
         try:
             op.spmv_halo(x, y)
             torch.cuda.synchronize()
+            # ... and its result is checked against the all-gather of the same kernel's
+            # slices on the columns this rank's rows reference (must be bit-identical)
+            y_ag = torch.empty_like(y)
+            op.spmv(x, y_ag)
+            torch.cuda.synchronize()
+            lo, hi = int(ci.min()), int(ci.max()) + 1
+            if not torch.equal(y[lo:hi], y_ag[lo:hi]):
+                raise RuntimeError("halo exchange disagrees with the all-gather on the needed columns")
+            del y_ag
         except Exception as exc:  # noqa: BLE001
             ok = 0
             print(f"[rank {rank}] halo exchange failed: {exc}", file=sys.stderr)

@@ -125,12 +125,16 @@ class RowPartitionedSpmv:
         self._y_in = y_vec                           # (gather_y reads the slice from here)
         if self.world == 1 or not (self.halo_recv or self.halo_send):
             return y_vec
-        ops = []
-        for g, lo, hi in self.halo_send:
-            ops.append(dist.P2POp(dist.isend, y_vec[lo:hi], g, group=self.group))
-        for g, lo, hi in self.halo_recv:
-            ops.append(dist.P2POp(dist.irecv, y_vec[lo:hi], g, group=self.group))
-        for w in dist.batch_isend_irecv(ops):
+        # the P2P descriptors only depend on the buffer: built once per y_vec, reused every step
+        cache = getattr(self, "_halo_ops", None)
+        if cache is None or cache[0] != (y_vec.data_ptr(), y_vec.numel()):
+            ops = []
+            for g, lo, hi in self.halo_send:
+                ops.append(dist.P2POp(dist.isend, y_vec[lo:hi], g, group=self.group))
+            for g, lo, hi in self.halo_recv:
+                ops.append(dist.P2POp(dist.irecv, y_vec[lo:hi], g, group=self.group))
+            self._halo_ops = cache = ((y_vec.data_ptr(), y_vec.numel()), ops)
+        for w in dist.batch_isend_irecv(cache[1]):
             w.wait()
         return y_vec
 
