@@ -349,3 +349,51 @@ def test_single_process_multi_gpu_context(oracle):
     if sp.device_count() == 1:
         with pytest.raises(sp.Panic):
             sp.MultiGpuCsr(a, 2)
+
+
+def _patchwork(rng, dtype):
+    """A matrix stitched from row sections of very different character (empty,
+    sparse, 14/row banded, 60/row, a few rows of hundreds or thousands of entries,
+    narrow / wide / full-width column windows), so that one launch mixes every
+    super-tile mode the planner has."""
+    ncols = int(rng.integers(2_000, 120_000))
+    rows_c, rows_v = [], []
+    for _ in range(int(rng.integers(2, 9))):
+        nr = int(rng.integers(1, 6_000))
+        kind = rng.integers(0, 7)
+        per = [0, int(rng.integers(1, 4)), 14, int(rng.integers(20, 70)), int(rng.integers(150, 400)),
+               int(rng.integers(1, 30)), 14][kind]
+        span = [1, ncols, 4096, 2048, ncols, 20_000, ncols][kind]
+        span = min(max(span, per + 1), ncols)
+        if kind == 4:
+            nr = int(rng.integers(1, 12))
+        for r in range(nr):
+            k = per if kind != 5 else int(rng.integers(0, per + 1))
+            if kind == 4 and r == 0 and ncols > 3_000:
+                k = int(rng.integers(1_100, 3_000))          # a row longer than a whole stream tile
+            lo = int(rng.integers(0, ncols - span + 1))
+            cols = lo + np.sort(rng.choice(span, min(k, span), replace=False))
+            rows_c.append(cols.astype(np.uint64))
+            rows_v.append(rng.uniform(-1, 1, cols.size).astype(dtype))
+    lens = np.array([c.size for c in rows_c])
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    ci = np.concatenate(rows_c) if lens.sum() else np.zeros(0, np.uint64)
+    va = np.concatenate(rows_v) if lens.sum() else np.zeros(0, dtype)
+    return rp, ci, va, ncols
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_patchwork_matrices_all_planner_modes(oracle, dtype):
+    """30 seeded patchwork matrices, each through the automatic plan, the forced
+    stream kernel (plain and persistent) and the forced vector kernel."""
+    rng = np.random.default_rng(2024)
+    kernels = set()
+    for _ in range(30):
+        rp, ci, va, ncols = _patchwork(rng, dtype)
+        x = rng.uniform(-1, 1, ncols).astype(dtype)
+        dev = check(oracle, rp, ci, va, x, ncols)
+        kernels.add(dev.describe()["kernel"])
+        check(oracle, rp, ci, va, x, ncols, kernel=2)
+        check(oracle, rp, ci, va, x, ncols, kernel=2, persistent=1, stream_global=0)
+        check(oracle, rp, ci, va, x, ncols, kernel=1)
+    assert "stream" in kernels
