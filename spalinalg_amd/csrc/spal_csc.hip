@@ -369,11 +369,11 @@ int csc_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, 
         a->d_colptr = nullptr; a->d_rowind = nullptr; a->d_values = nullptr;  // stay with the caller
         (void)dev_free(a->d_meta); (void)dev_free(a->d_desc);
         (void)dev_free(a->d_windows); (void)dev_free(a->d_chunk_ptr); (void)dev_free(a->d_chunk_blk);
-        if (a->stream) (void)hipStreamDestroy(a->stream);
+        stream_release(a->stream);
         delete a;
         return st;
     };
-    hipError_t e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
+    hipError_t e = stream_acquire(&a->stream);
     if (e != hipSuccess) return bail(fail(SPAL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)));
     int st = csc_plan_build(a);
     if (st == SPAL_OK && a->kernel == 2) st = csc_ensure_csr(a);  // setup work, not the first product's
@@ -398,7 +398,7 @@ static void csc_free(spal_csc *a) {
     (void)dev_free(a->d_chunk_blk);
     (void)dev_free(a->d_x);
     (void)dev_free(a->d_y);
-    if (a->stream) (void)hipStreamDestroy(a->stream);
+    stream_release(a->stream);
     delete a;
 }
 
@@ -439,7 +439,7 @@ static int csc_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t
     if (e == hipSuccess) e = hipMemcpy(a->d_colptr, cp32.data(), (ncols + 1) * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && nnz) e = hipMemcpy(a->d_rowind, ri32.data(), nnz * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && nnz) e = hipMemcpy(a->d_values, values, nnz * sizeof(T), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = stream_acquire(&a->stream);
     if (e != hipSuccess) {
         csc_free(a);
         return fail(e == hipErrorOutOfMemory ? SPAL_ERR_OUT_OF_MEMORY : SPAL_ERR_HIP,

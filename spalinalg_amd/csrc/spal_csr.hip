@@ -27,7 +27,12 @@ DeviceGuard::~DeviceGuard() {
     if (prev >= 0) (void)hipSetDevice(prev);
 }
 
-// ---- caching allocator for large device blocks -----------------------------------
+// ---- caching allocator for device blocks ------------------------------------------
+// hipMalloc / hipFree cost tens of microseconds (hipFree synchronises the device)
+// and, for the 600 MB blocks of an assembly, milliseconds on some hosts.  Blocks
+// are handed back to a per-process cache instead: large ones (>= 1 MiB) are
+// reused for requests up to 25 % smaller, small ones are rounded up to a power of
+// two (>= 256 B) and reused for the same class.
 namespace {
 struct DevCache {
     std::mutex mu;
@@ -42,8 +47,51 @@ struct DevCache {
     ~DevCache() {}  // the process is going away; the driver reclaims device memory
 };
 DevCache &dev_cache() { static DevCache c; return c; }
-constexpr size_t kCacheMinBytes = 1u << 20;
+constexpr size_t kCacheLargeBytes = 1u << 20;
+size_t size_class(size_t bytes) {  // what is actually allocated for a request
+    if (bytes >= kCacheLargeBytes) return bytes;
+    size_t c = 256;
+    while (c < bytes) c <<= 1;
+    return c;
+}
+
+struct StreamPool {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> idle;   // (device, stream)
+};
+StreamPool &stream_pool() { static StreamPool p; return p; }
 }  // namespace
+
+// Non-blocking streams are pooled: creating one costs ~100 us, and every handle
+// (including each assembled CSR result) owns one.
+hipError_t stream_acquire(hipStream_t *out) {
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    {
+        StreamPool &p = stream_pool();
+        std::lock_guard<std::mutex> lock(p.mu);
+        for (size_t i = 0; i < p.idle.size(); ++i)
+            if (p.idle[i].first == device) {
+                *out = p.idle[i].second;
+                p.idle.erase(p.idle.begin() + i);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+void stream_release(hipStream_t s) {
+    if (!s) return;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        (void)hipStreamDestroy(s);
+        return;
+    }
+    StreamPool &p = stream_pool();
+    std::lock_guard<std::mutex> lock(p.mu);
+    if (p.idle.size() < 64) p.idle.emplace_back(device, s);
+    else (void)hipStreamDestroy(s);
+}
 
 hipError_t dev_alloc(void **ptr, size_t bytes) {
     *ptr = nullptr;
@@ -52,13 +100,15 @@ hipError_t dev_alloc(void **ptr, size_t bytes) {
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
     DevCache &c = dev_cache();
-    if (bytes >= kCacheMinBytes) {
+    const size_t want = size_class(bytes);
+    {
         std::lock_guard<std::mutex> lock(c.mu);
         size_t best = (size_t)-1;
         for (size_t i = 0; i < c.free_blocks.size(); ++i) {
             const auto &b = c.free_blocks[i];
-            if (b.device == device && b.bytes >= bytes && b.bytes <= bytes + bytes / 4 &&
-                (best == (size_t)-1 || b.bytes < c.free_blocks[best].bytes))
+            const bool fits = want >= kCacheLargeBytes ? (b.bytes >= want && b.bytes <= want + want / 4)
+                                                       : b.bytes == want;
+            if (b.device == device && fits && (best == (size_t)-1 || b.bytes < c.free_blocks[best].bytes))
                 best = i;
         }
         if (best != (size_t)-1) {
@@ -70,15 +120,15 @@ hipError_t dev_alloc(void **ptr, size_t bytes) {
             return hipSuccess;
         }
     }
-    e = hipMalloc(ptr, bytes);
+    e = hipMalloc(ptr, want);
     if (e == hipErrorOutOfMemory) {  // give the cache back and retry once
         (void)hipGetLastError();
         dev_cache_trim();
-        e = hipMalloc(ptr, bytes);
+        e = hipMalloc(ptr, want);
     }
-    if (e == hipSuccess && bytes >= kCacheMinBytes) {
+    if (e == hipSuccess) {
         std::lock_guard<std::mutex> lock(c.mu);
-        c.live.push_back({*ptr, bytes, device});
+        c.live.push_back({*ptr, want, device});
     }
     return e;
 }
@@ -92,7 +142,7 @@ hipError_t dev_free(void *ptr) {
         for (size_t i = 0; i < c.live.size(); ++i)
             if (c.live[i].p == ptr) { b = c.live[i]; c.live.erase(c.live.begin() + i); break; }
     }
-    if (!b.p) return hipFree(ptr);  // small block (or not ours): straight back
+    if (!b.p) return hipFree(ptr);  // not ours: straight back
     hipError_t e = hipDeviceSynchronize();  // what hipFree would have done: no user of the block is still running
     std::lock_guard<std::mutex> lock(c.mu);
     if (e == hipSuccess && c.cached_bytes + b.bytes <= c.limit) {
@@ -563,7 +613,7 @@ static void csr_free(spal_csr *a) {
     (void)dev_free(a->d_col16);
     (void)dev_free(a->d_x);
     (void)dev_free(a->d_y);
-    if (a->stream) (void)hipStreamDestroy(a->stream);
+    stream_release(a->stream);
     delete a;
 }
 
@@ -584,7 +634,7 @@ int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, 
         csr_free(a);
         return st;
     };
-    hipError_t e = hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking);
+    hipError_t e = stream_acquire(&a->stream);
     if (e != hipSuccess) return bail(fail(SPAL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)));
     // the stream kernel reads whole 128-entry steps: keep kStreamPad spare entries
     const uint64_t need = nnz + kStreamPad;

@@ -57,10 +57,12 @@ struct DeviceGuard {
 // cache of large freed blocks (exact-fit-ish reuse, bounded by
 // SPAL_CACHE_BYTES, default 8 GiB).  dev_free synchronises the device first,
 // like hipFree does, so a cached block is never handed out while work that used
-// it is still in flight.  Small blocks go straight to hipMalloc / hipFree.
+// it is still in flight.  Small blocks are rounded up to a power of two.
 hipError_t dev_alloc(void **ptr, size_t bytes);   // on the current device
 hipError_t dev_free(void *ptr);                   // on the current device; NULL is fine
 void dev_cache_trim();                            // releases every cached block
+hipError_t stream_acquire(hipStream_t *out);      // a non-blocking stream of the current device (pooled)
+void stream_release(hipStream_t s);               // synchronises it and returns it to the pool
 
 // ---- host helpers ------------------------------------------------------------
 unsigned host_threads();
