@@ -507,7 +507,8 @@ __global__ __launch_bounds__(256) void coo_group_sort(const uint32_t *__restrict
                                                       const uint32_t *__restrict__ sorted_row,
                                                       uint32_t *__restrict__ cols, T *__restrict__ vals,
                                                       uint32_t nrows, uint32_t gbits,
-                                                      uint32_t *__restrict__ kept) {
+                                                      uint32_t *__restrict__ kept,
+                                                      uint2 *__restrict__ gwin) {
     constexpr int K = CAP / 256;  // rounds per wave = sorted positions per thread
     __shared__ T s_v2[CAP];
     __shared__ uint32_t s_c1[CAP];
@@ -516,6 +517,7 @@ __global__ __launch_bounds__(256) void coo_group_sort(const uint32_t *__restrict
     __shared__ uint32_t s_rk[256];
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_wc[K * 4];
+    __shared__ uint32_t s_cmin, s_cmax;   // columns of the survivors (the CSR planner's window input)
     __shared__ uint8_t s_r2[CAP];
     // volatile: lanes of a wave hand counts to each other through this array
     // between two rounds; the compiler must re-read it every round
@@ -528,6 +530,7 @@ __global__ __launch_bounds__(256) void coo_group_sort(const uint32_t *__restrict
     const uint32_t e0 = gstart[grp], n = gstart[grp + 1] - e0;  // n <= CAP (checked by the host)
     if (n == 0) {  // block-uniform
         if (t < nr) kept[r0 + t] = 0;
+        if (t == 0) gwin[grp] = make_uint2(0xffffffffu, 0u);
         return;
     }
     // 0. loads (clamped lanes re-read the last entry) and counter reset
@@ -543,6 +546,7 @@ __global__ __launch_bounds__(256) void coo_group_sort(const uint32_t *__restrict
     }
     for (uint32_t i = t; i < 4 * 256; i += 256) s_cnt[i >> 8][i & 255] = 0;
     s_rk[t] = 0;
+    if (t == 0) { s_cmin = 0xffffffffu; s_cmax = 0u; }
     __syncthreads();
     // 1. stable counting sort by row inside the group
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -658,18 +662,29 @@ __global__ __launch_bounds__(256) void coo_group_sort(const uint32_t *__restrict
         if (t < (uint32_t)(K * 4)) s_wc[t] = inc - c;
     }
     __syncthreads();
+    uint32_t cmin = 0xffffffffu, cmax = 0u;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (256u * k >= n) continue;
         if ((keepm[k] >> lane) & 1ull) {
             const uint32_t p = 256u * k + t;
             const uint32_t o = e0 + s_wc[k * 4 + w] + (uint32_t)__popcll(keepm[k] & lt);
-            cols[o] = s_c2[p];
+            const uint32_t cp = s_c2[p];
+            cols[o] = cp;
             vals[o] = acc[k];
             atomicAdd(&s_rk[s_r2[p]], 1u);
+            cmin = min(cmin, cp);
+            cmax = max(cmax, cp + 1u);
         }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cmin = min(cmin, (uint32_t)__shfl_xor((int)cmin, o, 64));
+        cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, o, 64));
+    }
+    if (lane == 0) { atomicMin(&s_cmin, cmin); atomicMax(&s_cmax, cmax); }
     __syncthreads();
+    if (t == 0) gwin[grp] = make_uint2(s_cmin, s_cmax);
     if (t < nr) kept[r0 + t] = s_rk[t];
 }
 
@@ -758,7 +773,7 @@ struct DevView {
 struct CooWorkspace {
     size_t bytes = 0;
     size_t off_key[2], off_aux[2], off_val[2], off_counts, off_sums, off_start, off_kept, off_flag,
-        off_total;
+        off_total, off_gwin;
 };
 static CooWorkspace coo_workspace_layout(uint64_t len, uint64_t nrows, size_t elem) {
     CooWorkspace w;
@@ -778,6 +793,7 @@ static CooWorkspace coo_workspace_layout(uint64_t len, uint64_t nrows, size_t el
     w.off_kept = take((nrows + 1) * 4);
     w.off_flag = take(16 + (size_t)kCheckBlocks * 16);  // maxima + per-workgroup partial maxima
     w.off_total = take(4);
+    w.off_gwin = take((nrows + 1) * 8);   // one uint2 per group of rows (at most one per row)
     w.bytes = o;
     return w;
 }
@@ -790,6 +806,9 @@ struct Assembled {
     uint32_t *ptr = nullptr, *ind = nullptr;
     void *val = nullptr;
     uint64_t nnz = 0, cap = 0;
+    // {first, one past last} minor index of every 256 majors of the result, when the local
+    // sort produced it on the way (saves the CSR planner its own pass over the matrix)
+    std::vector<uint2> win256;
 };
 
 template <typename T>
@@ -872,13 +891,25 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
                       : group_cap == 1536 ? coo_group_sort<T, 1536> : coo_group_sort<T, kGroupCap>;
         auto k_pack = group_cap == 512 ? coo_group_pack<T, 512> : group_cap == 1024 ? coo_group_pack<T, 1024>
                       : group_cap == 1536 ? coo_group_pack<T, 1536> : coo_group_pack<T, kGroupCap>;
+        uint2 *d_gwin = reinterpret_cast<uint2 *>(wb + ws.off_gwin);
         hipLaunchKernelGGL(k_sort, dim3(ngroups), dim3(256), 0, st, start.as<uint32_t>(), sb.key[cur],
-                           sb.aux[cur], sb.val[cur], nrows, gbits, kept.as<uint32_t>());
+                           sb.aux[cur], sb.val[cur], nrows, gbits, kept.as<uint32_t>(), d_gwin);
+        std::vector<uint2> gwin(ngroups);
         // ---- 4. rowptr = scan of the kept counts; pack
         SPAL_HIP_TRY(exclusive_scan_u32(kept.as<uint32_t>(), rowptr.as<uint32_t>(), nrows,
                                         sums.as<uint32_t>(), total.as<uint32_t>(), st, true));
         SPAL_HIP_TRY(hipMemcpyAsync(&nnz, total.p, 4, hipMemcpyDeviceToHost, st));
+        SPAL_HIP_TRY(hipMemcpyAsync(gwin.data(), d_gwin, (size_t)ngroups * sizeof(uint2), hipMemcpyDeviceToHost, st));
         SPAL_HIP_TRY(hipStreamSynchronize(st));  // the one data-dependent size
+        {   // fold the groups (2^gbits <= 256 rows each) into windows of 256 rows
+            const uint32_t per = 256u >> gbits;
+            res.win256.assign(((size_t)nrows + 255) / 256, make_uint2(0xffffffffu, 0u));
+            for (uint32_t g = 0; g < ngroups; ++g) {
+                uint2 &w = res.win256[g / per];
+                w.x = std::min(w.x, gwin[g].x);
+                w.y = std::max(w.y, gwin[g].y);
+            }
+        }
         const uint64_t cap = (uint64_t)nnz + 256;  // the stream kernel's over-read margin
         SPAL_HIP_TRY(ocol.alloc(cap * 4));
         SPAL_HIP_TRY(oval.alloc(cap * sizeof(T)));
@@ -1124,7 +1155,7 @@ int spal_coo_assemble_csr(spal_coo_t c, void *stream, spal_csr_t *out) {
     Assembled r;
     SPAL_TRY(coo_assemble(c, false, (hipStream_t)stream, r));
     int st = csr_adopt_device(c->device, c->elem_size, c->nrows, c->ncols, r.nnz, r.cap, r.ptr, r.ind,
-                              r.val, out);
+                              r.val, out, r.win256.empty() ? nullptr : &r.win256);
     if (st != SPAL_OK) { (void)dev_free(r.ptr); (void)dev_free(r.ind); (void)dev_free(r.val); }
     return st;
 }

@@ -619,8 +619,9 @@ static void csr_free(spal_csr *a) {
 
 int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, uint64_t nnz,
                      uint64_t cap_entries, uint32_t *d_rowptr, uint32_t *d_colind, void *d_values,
-                     spal_csr **out) {
+                     spal_csr **out, const std::vector<uint2> *win256) {
     spal_csr *a = new spal_csr;
+    if (win256 && win256->size() == (nrows + kWinBase - 1) / kWinBase) a->win_base = *win256;
     a->device = device;
     a->elem_size = elem_size;
     a->nrows = nrows; a->ncols = ncols; a->nnz = nnz;

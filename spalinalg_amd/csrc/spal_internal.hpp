@@ -185,7 +185,9 @@ int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream);
 // assembly, which produces CSR directly on the device)
 // (cap_entries = allocated entries of d_colind / d_values; re-allocated with
 // padding when smaller than nnz + the kernels' over-read margin)
+// (win256: optional {first column, one past the last} of every 256 rows, if the caller has it)
 int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols,
                      uint64_t nnz, uint64_t cap_entries, uint32_t *d_rowptr,
-                     uint32_t *d_colind, void *d_values, spal_csr **out);
+                     uint32_t *d_colind, void *d_values, spal_csr **out,
+                     const std::vector<uint2> *win256 = nullptr);
 }  // namespace spal

@@ -316,3 +316,29 @@ def test_coo_local_sort_geometries(oracle, dtype):
     assert ("general", 0, 0) in seen
     assert len({g[1] for g in seen}) >= 5, seen                  # 256, 128, 64, 32, ... rows per group
     assert {g[2] for g in seen} >= {512, 1024, 1536, 2048}, seen
+
+
+def test_assembled_handle_plans_like_an_uploaded_one(oracle):
+    """The assembly hands the CSR planner the column windows it saw on the way;
+    the resulting plan (LDS windows, stream fractions) must be the plan the same
+    matrix gets when it is uploaded from the host, and multiply bit-identically."""
+    rng = np.random.default_rng(91)
+    for n, per_row, window in [(40_000, 14, 2048), (100_000, 5, 600), (3_000, 40, 3_000), (70_001, 9, 70_001)]:
+        rp, ci, va = sp.synth.banded_csr(n, n, per_row, window, 17)
+        rows = np.repeat(np.arange(n, dtype=np.uint64), np.diff(rp).astype(np.int64))
+        perm = rng.permutation(rows.size)                       # insertion order: shuffled
+        coo = sp.CooMatrix.with_triplets(n, n, rows[perm], ci[perm], va[perm])
+        dcoo = coo.upload()
+        got = dcoo.assemble_csr()
+        assert dcoo.describe()["last_route"] == "local_sort"
+        ref = sp.CsrMatrix(n, n, rp, ci, va).device()
+        dg, dr = got.describe(), ref.describe()
+        for k in ("kernel", "rows_per_tile", "blocks", "lds_x", "lds_window_bytes", "lds_row_fraction",
+                  "stream_row_fraction", "index_bits"):
+            assert dg[k] == dr[k], (k, dg, dr)
+        gp, gi, gv = got.download()
+        assert np.array_equal(gp, rp) and np.array_equal(gi, ci) and np.array_equal(gv, va)
+        x = sp.synth.vector(n)
+        assert np.array_equal(got.spmv(x), ref.spmv(x))
+        got.close()
+        dcoo.close()
