@@ -156,7 +156,7 @@ def bench_csc(args):
             yh = oracle.csc_spmv(n, cp, ri, cv, xh)
             passes += 1
             el = time.perf_counter() - t0
-            if el >= args.cpu_seconds or passes >= 50:
+            if el >= args.cpu_seconds or passes >= 2000:
                 break
         out["cpu_baseline"] = {"value": round(sp.synth.spmv_flops(nnz) * passes / el / 1e9, 4), "unit": "GFLOP/s",
                                "cores": 1, "kind": "port",
@@ -551,7 +551,7 @@ def main():
             oracle.csr_spmv_idx32(rp32, ci32, va, xh, yh)
             passes += 1
             el = time.perf_counter() - t0
-            if el >= args.cpu_seconds or passes >= 50:
+            if el >= args.cpu_seconds or passes >= 1000:
                 break
         out["cpu_baseline"] = {
             "value": round(sp.synth.spmv_flops(nnz) * passes / el / 1e9, 4),
@@ -564,6 +564,28 @@ def main():
             "gpu_agrees_with_cpu": bool(np.allclose(y.cpu().numpy(), yh, rtol=1e-10 if esz == 8 else 1e-4,
                                                     atol=1e-12 if esz == 8 else 1e-5)),
         }
+        # for information: the same loop row-parallel on the host cores this box gives us
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+            threads = max(1, min(16, len(os.sched_getaffinity(0))))
+            y_mt = np.empty(nrows, dtype=np_dt)
+            with ThreadPoolExecutor(max_workers=threads) as pool:
+                oracle.csr_spmv_idx32_threads(rp32, ci32, va, xh, y_mt, threads, pool)   # warm
+                passes, t0 = 0, time.perf_counter()
+                while True:
+                    oracle.csr_spmv_idx32_threads(rp32, ci32, va, xh, y_mt, threads, pool)
+                    passes += 1
+                    el = time.perf_counter() - t0
+                    if el >= min(args.cpu_seconds, 4.0) or passes >= 50:
+                        break
+            out["cpu_baseline_all_cores"] = {
+                "value": round(sp.synth.spmv_flops(nnz) * passes / el / 1e9, 4), "unit": "GFLOP/s",
+                "cores": threads, "kind": "port",
+                "sample": f"{passes} full passes in {el:.1f} s, {threads} threads, one row range each "
+                          f"(informational: the reference has no threads)",
+                "same_result_as_1_thread": bool(np.array_equal(y_mt, yh))}
+        except Exception as exc:  # noqa: BLE001  (informational only)
+            out["cpu_baseline_all_cores"] = {"error": str(exc)}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -123,6 +123,33 @@ def csr_spmv_idx32(rowptr32, colind32, values, x, y=None) -> np.ndarray:
     return y
 
 
+def csr_spmv_idx32_threads(rowptr32, colind32, values, x, y, threads: int, pool=None) -> np.ndarray:
+    """The idx32 loop, one contiguous row range per thread (ctypes releases the
+    GIL); bench.py's informational all-cores figure.  Same results as the
+    sequential call: rows are independent."""
+    from concurrent.futures import ThreadPoolExecutor
+    values = np.ascontiguousarray(values)
+    fn = getattr(lib(), f"orc_csr_spmv_idx32_rows_{_sfx(values.dtype)}")
+    fn.restype = None
+    nrows = rowptr32.size - 1
+    # ranges balanced by stored entries
+    cuts = np.searchsorted(rowptr32, np.linspace(0, int(rowptr32[-1]), threads + 1)[1:-1]).tolist()
+    bounds = [0] + [int(c) for c in cuts] + [nrows]
+    args = (_p(rowptr32), _p(colind32), _p(values), _p(x), _p(y))
+
+    def run(i):
+        fn(C.c_uint64(bounds[i]), C.c_uint64(bounds[i + 1]), *args)
+
+    own = pool is None
+    pool = pool or ThreadPoolExecutor(max_workers=threads)
+    try:
+        list(pool.map(run, range(threads)))
+    finally:
+        if own:
+            pool.shutdown()
+    return y
+
+
 def csc_spmv(nrows, colptr, rowind, values, x) -> np.ndarray:
     values = np.ascontiguousarray(values)
     sfx = _sfx(values.dtype)

@@ -110,6 +110,27 @@ void NAME(usize nrows, const uint32_t *rowptr, const uint32_t *colind,        \
 DEF_CSR_SPMV32(orc_csr_spmv_idx32_f64, double)
 DEF_CSR_SPMV32(orc_csr_spmv_idx32_f32, float)
 
+/* The same loop over the rows [row_begin, row_end) only: rows are independent,
+ * so bench.py's informational all-cores figure runs one range per thread
+ * (results identical to the sequential call). */
+#define DEF_CSR_SPMV32_ROWS(NAME, T)                                          \
+void NAME(usize row_begin, usize row_end, const uint32_t *rowptr,             \
+          const uint32_t *colind, const T *values, const T *x, T *y)          \
+{                                                                             \
+    for (usize row = row_begin; row < row_end; ++row) {                       \
+        uint32_t p = rowptr[row], e = rowptr[row + 1];                        \
+        if (p == e) { y[row] = (T)0; continue; }                              \
+        T acc = values[p] * x[colind[p]];                                     \
+        for (++p; p < e; ++p) {                                               \
+            T prod = values[p] * x[colind[p]];                                \
+            acc += prod;                                                      \
+        }                                                                     \
+        y[row] = acc;                                                         \
+    }                                                                         \
+}
+DEF_CSR_SPMV32_ROWS(orc_csr_spmv_idx32_rows_f64, double)
+DEF_CSR_SPMV32_ROWS(orc_csr_spmv_idx32_rows_f32, float)
+
 /* ------------------------------------------------------------------------
  * y = A * x for CSC, dense x.
  * Derived from `impl Mul for &CscMatrix<T>` src/csc/ops/mul.rs:26-46 with
