@@ -306,6 +306,54 @@ def test_device_path_with_torch_stream(oracle):
     assert torch.equal(yd, yd2)        # deterministic run to run
 
 
+def test_concurrent_callers_on_one_handle(oracle):
+    """`&CsrMatrix` is Sync in the reference; the handle's device entry point may be
+    called from several threads at once (each on its own stream), the host-vector
+    call serialises internally.  Also: many create / assemble / destroy cycles
+    (pooled streams, cached device blocks) keep giving the same results."""
+    torch = pytest.importorskip("torch")
+    import threading
+    n = 120_000
+    rp, ci, va = sp.synth.banded_csr(n, n, 14, 2048, 77)
+    x = sp.synth.vector(n)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    xd = torch.from_numpy(x).cuda()
+    results, errors = {}, []
+
+    def worker(k):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(40):
+                    yd = dev.spmv_torch(xd)
+            s.synchronize()
+            results[k] = yd.cpu().numpy()
+            for _ in range(5):
+                results[("host", k)] = dev.spmv(x)          # host-vector convenience call
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k, y in results.items():
+        assert np.array_equal(y, y_ref), k                    # stream kernel: bit-identical
+    # handle churn
+    r, c, v = sp.synth.coo(5_000, 5_000, 60_000, 9)
+    p0, i0, w0 = oracle.coo_to_csr(5_000, 5_000, r, c, v)
+    for _ in range(60):
+        d = sp.CooMatrix.with_triplets(5_000, 5_000, r, c, v).upload()
+        got = d.assemble_csr()
+        gp, gi, gw = got.download()
+        assert np.array_equal(gp, p0) and np.array_equal(gi, i0) and np.array_equal(gw.view(np.uint64), w0.view(np.uint64))
+        got.close()
+        d.close()
+
+
 def test_full_size_config3_properties():
     """BASELINE config 3 (10M x 10M, 140M nnz) at full size: checked through
     size-independent properties (the oracle comparison lives in the smaller
