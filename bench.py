@@ -6,14 +6,14 @@
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the hot path over the whole matrix with every input
-already resident in HBM: each rank runs the HIP kernel on its row range; with
-N > 1 the ranks then exchange what the next product needs (--exchange: by
-default the halo of y each rank's rows reference, point-to-point; or an
-all-gather of the whole y).  x is broadcast ONCE from rank 0 before the timed
-region (x_bcast_ms) and, in halo mode, the y slices are all-gathered once at
-the end of the timed region.  The matrix is fixed as N grows ("scaling":
-"strong").  value = 2*nnz / time per step, whole job; compute_only and
-allgather_every_step give the other two readings of the same run.
+already resident in HBM: each rank runs the HIP kernel on its row range.  With
+N > 1 the timed region is, as north_star words it, {x broadcast once from rank
+0 over RCCL -> K rank-local SpMVs -> the per-GPU y slices all-gathered once at
+the end}; every rank then checks rows of its own shard in the gathered y.
+--exchange allgather / halo / auto measure ITERATIVE use instead (something
+moves after every step).  The matrix is fixed as N grows ("scaling":
+"strong").  value = 2*nnz / (timed region / K), whole job; compute_only is the
+max-over-ranks kernel time alone.
 
 Rank 0 prints ONE JSON line.  `roofline` is computed from the ALGORITHMIC
 bytes of the rank-local launch (SURVEY.md section 8d:
@@ -58,13 +58,18 @@ def parse():
                     help="single-GPU configs 2 and 4: rotate the launches over this many independent copies of "
                          "(matrix, x, y) so that the 188 MB working set is not served from the 256 MB Infinity "
                          "Cache (SURVEY 8d).  Default 0 = 3 copies for configs 2 and 4, 1 for config 3 (1.9 GB)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "allgather", "halo"],
-                    help="N > 1 only: what moves between the GPUs.  halo: per step every rank receives only the "
-                         "entries of y its rows reference as columns (point-to-point over xGMI; banded shards: "
-                         "+-W/2 from the neighbours), and the y slices are all-gathered ONCE at the end of the "
-                         "timed region (north_star: 'x broadcast once ... y slices gathered at the end').  "
-                         "allgather: the whole y is all-gathered after every step.  auto (default): halo when the "
-                         "halo is at most a quarter of a slice and its plan succeeded on every rank, else allgather")
+    ap.add_argument("--exchange", default="end", choices=["end", "auto", "allgather", "halo"],
+                    help="N > 1 only: what moves between the GPUs inside the timed region.  end (default) = "
+                         "north_star literally: x broadcast once over RCCL, K rank-local SpMVs, the per-GPU y "
+                         "slices all-gathered once at the end.  The others model ITERATIVE use (y of one step "
+                         "is the x of the next, so something must move every step): allgather = the whole y "
+                         "after every step; halo = per step every rank receives only the entries of y its rows "
+                         "reference as columns (point-to-point; banded shards: +-W/2 from the neighbours), y "
+                         "slices all-gathered once at the end; auto = halo when the halo is at most a quarter "
+                         "of a slice and its plan succeeded on every rank, else allgather")
+    ap.add_argument("--extras", action="store_true",
+                    help="N > 1, --exchange end: also time K steps with an all-gather after every step and "
+                         "report it beside the headline (extra collectives; off by default)")
     return ap.parse_args()
 
 
@@ -382,6 +387,8 @@ def main():
     def step():
         if world == 1:
             single_step()
+        elif exchange == "end":
+            op.local_only(x)        # the rank's rows into its slice buffer; nothing moves
         elif exchange == "halo":
             op.spmv_halo(x, y)
         else:
@@ -396,9 +403,11 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t_wall0 = time.perf_counter()
     e0.record()
+    if exchange == "end":
+        op.broadcast_x(x)       # "x broadcast once via RCCL": inside the timed region
     for _ in range(args.steps):
         step()
-    if exchange == "halo":
+    if exchange in ("halo", "end"):
         op.gather_y(y)          # "per-GPU y slices gathered at the end": once, inside the timed region
     e1.record()
     torch.cuda.synchronize()
@@ -415,7 +424,7 @@ def main():
 
     # ---- for transparency: the same K steps with an all-gather of y after EVERY step
     allgather_ms = None
-    if exchange == "halo":
+    if exchange == "halo" or (exchange == "end" and args.extras):
         for _ in range(min(args.warmup, 5)):
             op.spmv(x, y)
         torch.cuda.synchronize()
@@ -459,19 +468,28 @@ def main():
     peak = sp.synth.HBM_PEAK_BYTES_PER_S / 1e9
     gflops = sp.synth.spmv_flops(nnz) / (ms_per_step * 1e-3) / 1e9
 
+    # ---- a spot check so a wrong kernel / exchange cannot post a number: every rank evaluates
+    # the first and last two rows of ITS shard in numpy and looks them up in the gathered y
+    xh = sp.synth.vector(ncols, dtype=np_dt)
+    bad = 0
+    nloc = r1 - r0
+    for r in sorted({0, 1, max(nloc - 2, 0), nloc - 1}):
+        lo, hi = int(rp[r]), int(rp[r + 1])
+        ref = float(np.dot(va[lo:hi].astype(np.float64), xh[ci[lo:hi].astype(np.int64)].astype(np.float64)))
+        got = float(y[r0 + r].item())
+        if abs(got - ref) > (1e-10 if esz == 8 else 1e-4) * max(1.0, abs(ref)):
+            print(f"[rank {rank}] spot check failed at row {r0 + r}: {got} vs {ref}", file=sys.stderr)
+            bad = 1
+    flag = torch.tensor([bad], dtype=torch.int32, device=device)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        sys.exit("spot check failed (see stderr)")
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-
-    # ---- a spot check so a wrong kernel cannot post a number (rows evaluated directly in numpy)
-    ycpu = y[r0:r0 + 4].cpu().numpy() if world == 1 else y[:4].cpu().numpy()
-    xh = sp.synth.vector(ncols, dtype=np_dt)
-    for r in range(4):
-        lo, hi = int(rp[r]), int(rp[r + 1])
-        ref = float(np.dot(va[lo:hi].astype(np.float64), xh[ci[lo:hi].astype(np.int64)].astype(np.float64)))
-        if abs(float(ycpu[r]) - ref) > (1e-10 if esz == 8 else 1e-4) * max(1.0, abs(ref)):
-            sys.exit(f"spot check failed at row {r}: {ycpu[r]} vs {ref}")
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -509,6 +527,8 @@ def main():
                            if world == 1 else
                            f"rows partitioned over {world} GPUs, x bcast once (RCCL), "
                            + ("y all-gather after every step (RCCL)" if exchange == "allgather" else
+                              "y slices all-gathered once at the end; the bcast, the K local SpMVs and the gather "
+                              "are all inside the timed region" if exchange == "end" else
                               f"per step a halo exchange (RCCL send/recv, {getattr(op, 'halo_bytes', 0)} B received "
                               f"per rank), y slices all-gathered once at the end of the timed region")),
             "nrows": nrows, "ncols": ncols, "nnz": nnz, "algorithmic_index_bits": 32,

@@ -37,8 +37,10 @@ for s in "$@"; do
     align)  step 600 lab_align.log python tools/lab_align.py ${ALIGN_ARGS:-} ;;
     ab)     step 600 lab_ab.log python tools/lab_ab.py $AB_ARGS ;;
     bench)  step 400 bench.log python bench.py ;;
-    rehearse2) step 600 rehearse2.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29631 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --same-device --config 2 ;;
+    rehearse2) step 600 rehearse2.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29631 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --same-device --config 2 --exchange allgather ;;
     rehearse2h) step 600 rehearse2h.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29632 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --same-device --config 2 --exchange auto ;;
+    rehearse2e) step 600 rehearse2e.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29634 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --same-device --config 2 --extras ;;
+    rehearse4e) step 600 rehearse4e.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29635 bench.py --gpus 4 --steps 5 --warmup 2 --backend gloo --same-device --config 2 ;;
     rehearse1) step 600 rehearse1.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29633 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline ;;
     bench4) step 400 bench4.log python bench.py --config 4 ;;
     bench5) step 600 bench5.log python bench.py --config 5 ;;
