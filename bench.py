@@ -67,6 +67,9 @@ def parse():
                          "reference as columns (point-to-point; banded shards: +-W/2 from the neighbours), y "
                          "slices all-gathered once at the end; auto = halo when the halo is at most a quarter "
                          "of a slice and its plan succeeded on every rank, else allgather")
+    ap.add_argument("--plain-collectives", action="store_true",
+                    help="N > 1, --exchange end: use broadcast / all-gather even when every rank reads only a "
+                         "window of x (default: rank 0 scatters the windows and gathers the y slices)")
     ap.add_argument("--extras", action="store_true",
                     help="N > 1, --exchange end: also time K steps with an all-gather after every step and "
                          "report it beside the headline (extra collectives; off by default)")
@@ -364,6 +367,38 @@ def main():
             if args.exchange == "halo":
                 sys.exit("--exchange halo: the halo exchange failed (see stderr)")
             exchange = "allgather"
+    # --exchange end: "x broadcast once ... y slices gathered at the end".  When every rank reads only
+    # a window of x (banded shards: its slice +- W/2) rank 0 scatters the windows instead of
+    # broadcasting the whole vector, and the slices are gathered on rank 0 instead of all-gathered:
+    # 1/N of the bytes per link either way.  One verified dry run; any rank failing -> plain collectives.
+    x_mode, y_mode, x_needs = "broadcast", "allgather", None
+    if world > 1 and exchange == "end" and not args.plain_collectives:
+        ok = 1
+        try:
+            x_needs = op.plan_x_windows(int(ci.min()), int(ci.max()) + 1)
+            if op.xw_len * 4 > ncols * 3 or not op.equal:
+                raise ValueError("windows too wide / unequal slices: plain collectives")
+            probe = x if rank == 0 else torch.full_like(x, float("nan"))
+            a0, a1 = op.distribute_x(probe, ncols, x_needs)
+            torch.cuda.synchronize()
+            if not (a0 <= int(ci.min()) and int(ci.max()) < a1 and torch.equal(probe[a0:a1], x[a0:a1])):
+                raise RuntimeError("scattered x window differs from the broadcast vector")
+            del probe
+            op.local_only(x)
+            y_ag = torch.empty_like(y)
+            op.gather_y(y_ag)
+            op.gather_y_root(y)
+            torch.cuda.synchronize()
+            if rank == 0 and not torch.equal(y, y_ag):
+                raise RuntimeError("gather on rank 0 differs from the all-gather")
+            del y_ag
+        except Exception as exc:  # noqa: BLE001  (every rank must still reach the agreement below)
+            ok = 0
+            print(f"[rank {rank}] scatter/gather plan not used: {exc}", file=sys.stderr)
+        agree = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree[0]):
+            x_mode, y_mode = "scatter_windows", "gather_root"
     # setup: let the library pick between its kernel variants on this device (results are identical)
     plan = dev.autotune(x, op.y_local[: r1 - r0], iters=30)
     # config 2 on one GPU: 188 MB would be served from the 256 MB Infinity Cache, so the
@@ -403,12 +438,17 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t_wall0 = time.perf_counter()
     e0.record()
-    if exchange == "end":
-        op.broadcast_x(x)       # "x broadcast once via RCCL": inside the timed region
+    if exchange == "end":       # "x broadcast once via RCCL": inside the timed region
+        if x_mode == "scatter_windows":
+            op.distribute_x(x, ncols, x_needs)
+        else:
+            op.broadcast_x(x)
     for _ in range(args.steps):
         step()
-    if exchange in ("halo", "end"):
-        op.gather_y(y)          # "per-GPU y slices gathered at the end": once, inside the timed region
+    if exchange == "end" and y_mode == "gather_root":
+        op.gather_y_root(y)     # "per-GPU y slices gathered at the end": once, inside the timed region
+    elif exchange in ("halo", "end"):
+        op.gather_y(y)
     e1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -468,18 +508,31 @@ def main():
     peak = sp.synth.HBM_PEAK_BYTES_PER_S / 1e9
     gflops = sp.synth.spmv_flops(nnz) / (ms_per_step * 1e-3) / 1e9
 
-    # ---- a spot check so a wrong kernel / exchange cannot post a number: every rank evaluates
-    # the first and last two rows of ITS shard in numpy and looks them up in the gathered y
+    # ---- a spot check so a wrong kernel / exchange cannot post a number: every rank evaluates the
+    # first and last two rows of ITS shard in numpy against its slice; rank 0 also regenerates the
+    # first and last row of EVERY shard and looks them up in the gathered y
     xh = sp.synth.vector(ncols, dtype=np_dt)
+    tol = 1e-10 if esz == 8 else 1e-4
     bad = 0
     nloc = r1 - r0
+    y_own = op.y_local[:nloc] if world > 1 else y
     for r in sorted({0, 1, max(nloc - 2, 0), nloc - 1}):
         lo, hi = int(rp[r]), int(rp[r + 1])
         ref = float(np.dot(va[lo:hi].astype(np.float64), xh[ci[lo:hi].astype(np.int64)].astype(np.float64)))
-        got = float(y[r0 + r].item())
-        if abs(got - ref) > (1e-10 if esz == 8 else 1e-4) * max(1.0, abs(ref)):
+        got = float(y_own[r].item())
+        if abs(got - ref) > tol * max(1.0, abs(ref)):
             print(f"[rank {rank}] spot check failed at row {r0 + r}: {got} vs {ref}", file=sys.stderr)
             bad = 1
+    if rank == 0 and world > 1:
+        for g in range(world):
+            for r in (int(bounds[g]), int(bounds[g + 1]) - 1):
+                _, c1, v1 = sp.synth.banded_csr(nrows, ncols, per_row, window, sp.synth.matrix_seed(args.config),
+                                                dtype=np_dt, rows=(r, r + 1))
+                ref = float(np.dot(v1.astype(np.float64), xh[c1.astype(np.int64)].astype(np.float64)))
+                got = float(y[r].item())
+                if abs(got - ref) > tol * max(1.0, abs(ref)):
+                    print(f"[rank 0] gathered y wrong at row {r} (shard {g}): {got} vs {ref}", file=sys.stderr)
+                    bad = 1
     flag = torch.tensor([bad], dtype=torch.int32, device=device)
     if world > 1:
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
@@ -525,15 +578,20 @@ def main():
                         + ((f"single GPU" + (f"; launches rotate over {copies} independent copies of (A, x, y), "
                                              f"together larger than the 256 MB Infinity Cache" if copies > 1 else ""))
                            if world == 1 else
-                           f"rows partitioned over {world} GPUs, x bcast once (RCCL), "
+                           f"rows partitioned over {world} GPUs, x distributed once from rank 0 (RCCL), "
                            + ("y all-gather after every step (RCCL)" if exchange == "allgather" else
-                              "y slices all-gathered once at the end; the bcast, the K local SpMVs and the gather "
-                              "are all inside the timed region" if exchange == "end" else
+                              ("x windows scattered from rank 0 and y slices gathered on rank 0 (each GPU receives "
+                               "only the columns its rows read)" if x_mode == "scatter_windows" else
+                               "y slices all-gathered once at the end") +
+                              "; the x distribution, the K local SpMVs and the gather are all inside the timed "
+                              "region" if exchange == "end" else
                               f"per step a halo exchange (RCCL send/recv, {getattr(op, 'halo_bytes', 0)} B received "
                               f"per rank), y slices all-gathered once at the end of the timed region")),
             "nrows": nrows, "ncols": ncols, "nnz": nnz, "algorithmic_index_bits": 32,
             "partition": "none" if world == 1 else f"rows/{world}",
             "exchange": exchange,
+            "x_distribution": x_mode if world > 1 else "none",
+            "y_collection": y_mode if world > 1 else "none",
             "plan": plan,
         },
         "achieved_hbm_pct": round(100.0 * whole_bytes / (ms_per_step * 1e-3) / (world * sp.synth.HBM_PEAK_BYTES_PER_S), 2),

@@ -81,7 +81,60 @@ class RowPartitionedSpmv:
 
     def local_only(self, x):
         self.local_spmv(x, self.y_local)
+        self._y_in = None
         return self.y_local[: self.r1 - self.r0]
+
+    # ---- "x broadcast once ... y slices gathered at the end", without the excess ---------
+    # A rank's rows reference only the columns [need_lo, need_hi): for banded shards its own
+    # slice plus W/2 either side.  Rank 0 therefore SCATTERS x -- every rank receives the
+    # window it reads (equal lengths, clamped into the vector), 1/N of a broadcast's bytes per
+    # link -- and the y slices are GATHERED on rank 0 (1/N of an all-gather's bytes per rank).
+    def plan_x_windows(self, need_lo: int, need_hi: int):
+        """Collective: agree on one window length and every rank's window start."""
+        torch, dist = self.torch, self.torch.distributed
+        dev = self.y_local.device
+        mine = torch.tensor([need_lo, need_hi], dtype=torch.int64, device=dev)
+        allneeds = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        if self.world > 1:
+            dist.all_gather(allneeds, mine, group=self.group)
+        else:
+            allneeds = [mine]
+        needs = [(int(t[0]), int(t[1])) for t in allneeds]
+        self.xw_len = max(hi - lo for lo, hi in needs)
+        return needs
+
+    def distribute_x(self, x, ncols: int, needs):
+        """x (full length on every rank; rank 0 holds the content): every rank's window
+        [start, start + xw_len) is filled from rank 0.  Returns this rank's (start, stop)."""
+        dist = self.torch.distributed
+        L = min(self.xw_len, ncols)
+        starts = [max(0, min(lo, ncols - L)) for lo, _ in needs]
+        me = starts[self.rank]
+        if self.world > 1:
+            if self.rank == 0:
+                if getattr(self, "_x_self", None) is None or self._x_self.numel() != L:
+                    self._x_self = self.torch.empty(L, dtype=x.dtype, device=x.device)
+                dist.scatter(self._x_self, [x[s:s + L] for s in starts], src=0, group=self.group)
+            else:
+                dist.scatter(x[me:me + L], None, src=0, group=self.group)
+        return me, me + L
+
+    def gather_y_root(self, y_full):
+        """The slices of the last product (self.y_local) land in y_full on rank 0 only.
+        Needs equal slices (else: gather_y)."""
+        dist = self.torch.distributed
+        if not self.equal:
+            raise ValueError("gather_y_root needs equal row slices")
+        n = self.r1 - self.r0
+        if self.world == 1:
+            y_full[:n].copy_(self.y_local[:n])
+            return y_full
+        if self.rank == 0:
+            views = [y_full[int(self.bounds[g]):int(self.bounds[g + 1])] for g in range(self.world)]
+            dist.gather(self.y_local[:n], views, dst=0, group=self.group)
+        else:
+            dist.gather(self.y_local[:n], None, dst=0, group=self.group)
+        return y_full
 
     # ---- halo exchange (SURVEY.md section 8f-4) -------------------------------------
     # For a square matrix used iteratively (y is the next x) a rank does not need

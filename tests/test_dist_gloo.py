@@ -45,12 +45,27 @@ def _worker(rank, world, port, equal, q):
         y = torch.empty(n, dtype=torch.float64)
         op.spmv(x, y)
         y_ref = oracle.csr_spmv(rp, ci, va, sp.synth.vector(n))
-        q.put((rank, bool(np.array_equal(y.numpy(), y_ref)), op.equal, bounds.tolist()))
+        ok = bool(np.array_equal(y.numpy(), y_ref))
+        if equal:
+            # scatter of the x windows + gather of the y slices on rank 0 ("end" mode of bench.py)
+            lo, hi = int(shard.colind().min()), int(shard.colind().max()) + 1
+            needs = op.plan_x_windows(lo, hi)
+            x2 = torch.from_numpy(sp.synth.vector(n)) if rank == 0 else torch.full((n,), np.nan, dtype=torch.float64)
+            a0, a1 = op.distribute_x(x2, n, needs)
+            ok = ok and a0 <= lo and hi <= a1
+            ok = ok and bool(np.array_equal(x2.numpy()[a0:a1], sp.synth.vector(n)[a0:a1]))
+            xs = torch.nan_to_num(x2, nan=0.0)          # columns outside the window are never read
+            op.local_only(xs)
+            y2 = torch.full((n,), np.nan, dtype=torch.float64)
+            op.gather_y_root(y2)
+            if rank == 0:
+                ok = ok and bool(np.array_equal(y2.numpy(), y_ref))
+        q.put((rank, ok, op.equal, bounds.tolist()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,equal", [(2, True), (2, False), (3, False)])
+@pytest.mark.parametrize("world,equal", [(2, True), (2, False), (3, False), (3, True), (4, True)])
 def test_row_partitioned_spmv_gloo(world, equal):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
