@@ -342,3 +342,47 @@ def test_assembled_handle_plans_like_an_uploaded_one(oracle):
         assert np.array_equal(got.spmv(x), ref.spmv(x))
         got.close()
         dcoo.close()
+
+
+def test_full_size_config5_properties():
+    """BASELINE config 5 at full size (50M triplets into 5M x 5M), checked through
+    size-independent properties (the bit-exact oracle comparison lives in the
+    smaller tests): CSR invariants, nothing stored that is zero, idempotence
+    (assembling the result's own triplets reproduces it exactly), the product on
+    the result equals the product summed straight from the triplets, and two
+    assemblies give identical arrays."""
+    torch = pytest.importorskip("torch")
+    cfg = sp.synth.CONFIGS[5]
+    nr, length = cfg["nrows"], cfg["length"]
+    r, c, v = sp.synth.coo(nr, nr, length, sp.synth.matrix_seed(5), cfg["dup_permille"], cfg["cancel_permille"])
+    dcoo = sp.CooMatrix.with_triplets(nr, nr, r, c, v).upload()
+    a = dcoo.assemble_csr()
+    assert dcoo.describe()["last_route"] == "local_sort"
+    rp, ci, va = a.download()
+    nnz = int(rp[-1])
+    assert rp[0] == 0 and nnz == ci.size == va.size and nnz < length       # duplicates merged / cancelled
+    lens = np.diff(rp.astype(np.int64))
+    assert lens.min() >= 0
+    # columns strictly increasing inside every row (src/csr.rs:152-156)
+    d = np.diff(ci.astype(np.int64))
+    row_start = np.zeros(nnz, dtype=bool)
+    row_start[rp[:-1][lens > 0].astype(np.int64)] = True
+    assert np.all((d > 0) | row_start[1:])
+    assert ci.max() < nr and not np.any(va == 0.0)                          # coo.rs:64
+    # the product: straight from the triplets (float64 index_add, another order) vs the kernel
+    x = torch.from_numpy(sp.synth.vector(nr)).cuda()
+    y = a.spmv_torch(x)
+    rt, ct, vt = (torch.from_numpy(t.astype(np.int64) if t.dtype != np.float64 else t).cuda() for t in (r, c, v))
+    y_direct = torch.zeros(nr, dtype=torch.float64, device="cuda").index_add_(0, rt, vt * x[ct])
+    bound = torch.zeros(nr, dtype=torch.float64, device="cuda").index_add_(0, rt, (vt * x[ct]).abs())
+    assert bool(torch.all((y - y_direct).abs() <= 1e-10 * bound + 1e-300))
+    del rt, ct, vt, y_direct, bound
+    # idempotence and determinism
+    rows = np.repeat(np.arange(nr, dtype=np.uint64), lens)
+    d2 = sp.CooMatrix.with_triplets(nr, nr, rows, ci, va).upload()
+    b = d2.assemble_csr()
+    rp2, ci2, va2 = b.download()
+    assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(va2.view(np.uint64), va.view(np.uint64))
+    a2 = dcoo.assemble_csr()
+    rp3, ci3, va3 = a2.download()
+    assert np.array_equal(rp3, rp) and np.array_equal(ci3, ci) and np.array_equal(va3.view(np.uint64), va.view(np.uint64))
