@@ -441,7 +441,7 @@ def test_patchwork_matrices_all_planner_modes(oracle, dtype):
         x = rng.uniform(-1, 1, ncols).astype(dtype)
         dev = check(oracle, rp, ci, va, x, ncols)
         kernels.add(dev.describe()["kernel"])
-        check(oracle, rp, ci, va, x, ncols, kernel=2)
+        check(oracle, rp, ci, va, x, ncols, kernel=2, persistent=0)
         check(oracle, rp, ci, va, x, ncols, kernel=2, persistent=1, stream_global=0)
         check(oracle, rp, ci, va, x, ncols, kernel=1)
     assert "stream" in kernels
