@@ -115,6 +115,66 @@ __device__ __forceinline__ void stage_window(T *xw, const T *__restrict__ x, uin
     }
 }
 
+// The stream kernel's x "window" is a set of PAGES of kPageCols consecutive columns
+// (2 KB of f64): the pages the super-tile's rows touch, in ascending order, staged
+// back to back in LDS.  A band is a run of consecutive pages; a stencil matrix
+// touches a few short runs far apart (the span may be millions of columns while
+// only a few thousand distinct ones are read).  col16 = slot * kPageCols + column
+// inside the page, so the hot loop does not know the difference.
+//   contiguous: page ids are first, first + 1, ...      (no table needed)
+//   else      : page ids from pages[first ... first + npages), at most 64
+constexpr uint32_t kPageShift = 8;
+constexpr uint32_t kPageCols = 1u << kPageShift;
+template <typename T, int BLOCK>
+__device__ __forceinline__ void stage_pages(T *xw, const T *__restrict__ x,
+                                            const uint32_t *__restrict__ pages, uint32_t first,
+                                            uint32_t npages, bool contiguous, uint32_t ncols) {
+    static_assert(BLOCK == 256, "one page of 256 columns per pass of the scalar path");
+    constexpr uint32_t V = 16 / sizeof(T);      // elements per 16-byte load
+    constexpr uint32_t VP = kPageCols / V;      // 16-byte vectors per page: 128 (f64) / 64 (f32)
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t pid_lane = first + lane;           // contiguous run
+    if (!contiguous) pid_lane = pages[first + min(lane, npages - 1u)];   // npages >= 1 here
+    if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0 && ncols >= V) {
+        using vec_t = __attribute__((ext_vector_type(4))) uint32_t;
+        const uint32_t total = npages * VP;     // a multiple of 64: whole waves are in or out
+        const uint32_t last_full = ((ncols - V) / V) * V;   // first column of the last whole vector of x
+        vec_t *d4 = reinterpret_cast<vec_t *>(xw);
+        constexpr uint32_t K = 4;
+        for (uint32_t i0 = threadIdx.x; i0 < total; i0 += K * BLOCK) {
+            vec_t t[K];
+            uint32_t e[K];
+            // all loads unconditional (clamped, in bounds) so that they leave together
+#pragma unroll
+            for (uint32_t k = 0; k < K; ++k) {
+                const uint32_t ic = min(i0 + k * BLOCK, total - 1u);
+                // the 64 vectors of a wave lie inside one page: its id comes from a lane, not from memory
+                const uint32_t slot = __builtin_amdgcn_readfirstlane(ic / VP);
+                const uint32_t pid = __builtin_amdgcn_readlane(pid_lane, slot);
+                e[k] = pid * kPageCols + (ic % VP) * V;     // first column of this vector
+                t[k] = *reinterpret_cast<const vec_t *>(x + min(e[k], last_full));
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < K; ++k) {
+                const uint32_t i = i0 + k * BLOCK;
+                if (i < total) {
+                    d4[i] = t[k];
+                    if (e[k] > last_full) {   // at / past the end of x (last page only): columns one by one
+#pragma unroll
+                        for (uint32_t q = 0; q < V; ++q) xw[i * V + q] = e[k] + q < ncols ? x[e[k] + q] : T(0);
+                    }
+                }
+            }
+        }
+    } else {   // x not 16-byte aligned: element by element, one page per pass of the workgroup
+        for (uint32_t s0 = 0; s0 < npages; ++s0) {
+            const uint32_t pid = __builtin_amdgcn_readlane(pid_lane, s0);
+            const uint32_t e = pid * kPageCols + threadIdx.x;
+            xw[s0 * kPageCols + threadIdx.x] = e < ncols ? x[e] : T(0);
+        }
+    }
+}
+
 // ---- the "vector" kernel: L lanes per row ------------------------------------
 // One workgroup owns R consecutive rows.  Each wave walks its rows G = 64/L at
 // a time, U such groups ("a step" = G*U rows) per iteration.  Rows longer
@@ -535,13 +595,14 @@ __device__ __forceinline__ void stream_global_super_tile(const uint32_t *__restr
     }
 }
 
-// desc[b] = {window base column, window length, mode, 0}
+// desc[b] = Stream: {first page id or offset into pages[], number of pages, mode, 1 if the pages are a
+// contiguous run}; VectorLds: {window base column, window length, mode, 0}
 template <typename T, int L, int U, bool USE_DPP, int TPW, int RPT>
 __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
     const uint16_t *__restrict__ col16, const T *__restrict__ vals, const T *__restrict__ x,
-    T *__restrict__ y, const uint4 *__restrict__ desc, uint32_t nrows, uint32_t ncols, uint32_t nnz,
-    uint32_t nblocks, uint32_t per_xcd, uint32_t flags) {
+    T *__restrict__ y, const uint4 *__restrict__ desc, const uint32_t *__restrict__ pages, uint32_t nrows,
+    uint32_t ncols, uint32_t nnz, uint32_t nblocks, uint32_t per_xcd, uint32_t flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
     const bool nt_store = flags & 1u;
     // [ products: 4 waves x kStreamTileNnz ][ x window ]
@@ -570,10 +631,10 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
         StreamTile<T> cur, nxt;
         const bool has0 = wrow < row1;  // wave-uniform
         if (has0) stream_load<T, RPT>(cur, rowptr, col16, vals, wrow, row1, tb[0], tb[1], lane);  // overlaps the staging
-        stage_window<T, kStreamBlock>(xw, x, d.x, d.y);
+        stage_pages<T, kStreamBlock>(xw, x, pages, d.x, d.y, d.w != 0u, ncols);   // d = {first, npages, mode, contiguous}
         __syncthreads();
         if (!has0) return;
-        const uint32_t wmax = d.y - 1;
+        const uint32_t wmax = d.y * kPageCols - 1u;
 #pragma unroll
         for (int k = 0; k < TPW; ++k) {
             const uint32_t r0 = wrow + k * (uint32_t)RPT;
@@ -618,8 +679,8 @@ template <typename T, int L, int U, bool USE_DPP, int TPW, int RPT>
 __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
     const uint16_t *__restrict__ col16, const T *__restrict__ vals, const T *__restrict__ x,
-    T *__restrict__ y, const uint4 *__restrict__ desc, uint32_t nrows, uint32_t ncols, uint32_t nnz,
-    uint32_t nblocks, uint32_t per_xcd, uint32_t chunk, uint32_t flags) {
+    T *__restrict__ y, const uint4 *__restrict__ desc, const uint32_t *__restrict__ pages, uint32_t nrows,
+    uint32_t ncols, uint32_t nnz, uint32_t nblocks, uint32_t per_xcd, uint32_t chunk, uint32_t flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
     const bool nt_store = flags & 1u;
     T *prod_all = reinterpret_cast<T *>(spal_smem);
@@ -664,9 +725,9 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
             const bool has0 = wrow < row1;  // wave-uniform
             if (has0 && !cur_valid) stream_load<T, RPT>(cur, rowptr, col16, vals, wrow, row1, tb[0], tb[1], lane);
             __syncthreads();  // every wave is done with the previous window
-            stage_window<T, kStreamBlock>(xw, x, d.x, d.y);
+            stage_pages<T, kStreamBlock>(xw, x, pages, d.x, d.y, d.w != 0u, ncols);
             __syncthreads();
-            const uint32_t wmax = d.y - 1;
+            const uint32_t wmax = d.y * kPageCols - 1u;
             bool fetched_next = false;
             if (has0) {
 #pragma unroll

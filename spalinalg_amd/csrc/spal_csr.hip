@@ -222,17 +222,138 @@ __global__ __launch_bounds__(256) void csr_stream_check(const uint32_t *__restri
     ok[b] = good;
 }
 
-// One workgroup per super-tile: 16-bit columns relative to the window base.
+// ---- the pages a super-tile's rows touch ----------------------------------------------
+// One workgroup per super-tile of R rows.  info[b] = {first column, one past the last
+// column, number of pages or kNotPageable, 1 if the pages are the contiguous run that
+// starts at page (first column >> kPageShift)}.  When the span holds at most `cap` pages
+// the run is taken whole (a band); otherwise the columns are marked in an LDS bitmap
+// (spans up to 16.7M columns), first for a sample of 2048 entries -- scattered columns
+// are recognised and dropped there -- then for all of them, and the pages are listed in
+// ascending order at pages[b * cap ...].
+constexpr uint32_t kNotPageable = 0xffffffffu;
+constexpr uint32_t kPageBitmapWords = 2048;   // 65536 pages
+__global__ __launch_bounds__(256) void csr_block_pages(
+    const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind, uint32_t nrows,
+    uint32_t R, uint32_t cap, uint4 *__restrict__ info, uint32_t *__restrict__ pages) {
+    __shared__ uint32_t s_bits[kPageBitmapWords];
+    __shared__ uint32_t s_min, s_max, s_count, s_wsum[4];
+    const uint32_t t = threadIdx.x, b = blockIdx.x;
+    if (t == 0) { s_min = 0xffffffffu; s_max = 0u; s_count = 0u; }
+    __syncthreads();
+    const uint32_t row0 = b * R, row1 = min(row0 + R, nrows);
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (uint32_t r = row0 + t; r < row1; r += 256) {
+        const uint32_t a0 = rowptr[r], a1 = rowptr[r + 1];
+        if (a0 < a1) {   // columns ascend inside a row: its first and last entry bound it
+            lo = min(lo, colind[a0]);
+            hi = max(hi, colind[a1 - 1] + 1u);
+        }
+    }
+    atomicMin(&s_min, lo);
+    atomicMax(&s_max, hi);
+    __syncthreads();
+    const uint32_t cmin = s_min, cmax = s_max;
+    if (cmax == 0) {   // nothing stored
+        if (t == 0) info[b] = make_uint4(0xffffffffu, 0u, 0u, 1u);
+        return;
+    }
+    const uint32_t pmin = cmin >> kPageShift, span = ((cmax - 1u) >> kPageShift) - pmin + 1u;
+    if (span <= cap) {
+        if (t == 0) info[b] = make_uint4(cmin, cmax, span, 1u);
+        return;
+    }
+    if (span > kPageBitmapWords * 32u) {
+        if (t == 0) info[b] = make_uint4(cmin, cmax, kNotPageable, 0u);
+        return;
+    }
+    const uint32_t words = (span + 31u) / 32u;
+    for (uint32_t i = t; i < words; i += 256) s_bits[i] = 0u;
+    __syncthreads();
+    const uint32_t e0 = rowptr[row0], e1 = rowptr[row1];
+    const uint32_t es = min(e0 + 2048u, e1);
+    for (int pass = 0; pass < 2; ++pass) {
+        const uint32_t a0 = pass ? es : e0, a1 = pass ? e1 : es;
+        for (uint32_t e = a0 + t; e < a1; e += 256) {
+            const uint32_t pg = (colind[e] >> kPageShift) - pmin;
+            atomicOr(&s_bits[pg >> 5], 1u << (pg & 31u));
+        }
+        __syncthreads();
+        uint32_t c = 0;
+        for (uint32_t i = t; i < words; i += 256) c += (uint32_t)__popc(s_bits[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o, 64);
+        if ((t & 63u) == 0) s_wsum[t >> 6] = c;
+        __syncthreads();
+        const uint32_t count = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        __syncthreads();
+        if (count > cap) {   // block-uniform
+            if (t == 0) info[b] = make_uint4(cmin, cmax, kNotPageable, 0u);
+            return;
+        }
+        if (pass == 1 && t == 0) s_count = count;
+    }
+    // ascending page list: thread t owns the words [8t, 8t + 8)
+    constexpr uint32_t kPer = kPageBitmapWords / 256;
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) {
+        const uint32_t w = t * kPer + q;
+        if (w < words) mine += (uint32_t)__popc(s_bits[w]);
+    }
+    uint32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, o, 64);
+        if ((t & 63u) >= (uint32_t)o) inc += v;
+    }
+    if ((t & 63u) == 63u) s_wsum[t >> 6] = inc;
+    __syncthreads();
+    uint32_t rank = inc - mine;
+    for (uint32_t i = 0; i < (t >> 6); ++i) rank += s_wsum[i];
+#pragma unroll
+    for (uint32_t q = 0; q < kPer; ++q) {
+        const uint32_t w = t * kPer + q;
+        if (w < words) {
+            uint32_t bits = s_bits[w];
+            while (bits) {
+                const uint32_t bit = (uint32_t)__ffs((int)bits) - 1u;
+                bits &= bits - 1u;
+                pages[(size_t)b * cap + rank++] = pmin + w * 32u + bit;
+            }
+        }
+    }
+    if (t == 0) info[b] = make_uint4(cmin, cmax, s_count, 0u);
+}
+
+// One workgroup per super-tile: col16 = slot of the column's page * kPageCols + column
+// inside the page (the slot by binary search in the super-tile's ascending page list).
 __global__ __launch_bounds__(256) void csr_encode_col16(const uint32_t *__restrict__ rowptr,
                                                         const uint32_t *__restrict__ colind,
                                                         const uint4 *__restrict__ desc,
+                                                        const uint32_t *__restrict__ pages,
                                                         uint16_t *__restrict__ col16,
                                                         uint32_t nrows, uint32_t R) {
-    const uint4 d = desc[blockIdx.x];
+    __shared__ uint32_t s_pg[64];
+    const uint4 d = desc[blockIdx.x];   // Stream: {first page / offset, npages, mode, contiguous}
     if (d.z != kModeStream) return;
     const uint32_t row0 = blockIdx.x * R, row1 = min(row0 + R, nrows);
     const uint32_t p0 = rowptr[row0], p1 = rowptr[row1];
-    for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256) col16[p] = (uint16_t)(colind[p] - d.x);
+    if (d.w) {   // contiguous run of pages starting at page d.x
+        const uint32_t base = d.x << kPageShift;
+        for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256) col16[p] = (uint16_t)(colind[p] - base);
+        return;
+    }
+    if (threadIdx.x < 64) s_pg[threadIdx.x] = threadIdx.x < d.y ? pages[d.x + threadIdx.x] : 0xffffffffu;
+    __syncthreads();
+    for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256) {
+        const uint32_t c = colind[p], pg = c >> kPageShift;
+        uint32_t lo = 0, hi = d.y;   // the page is in the list: first slot with s_pg[slot] >= pg
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_pg[mid] < pg) lo = mid + 1; else hi = mid;
+        }
+        col16[p] = (uint16_t)(lo * kPageCols + (c & (kPageCols - 1u)));
+    }
 }
 
 static int pick_lanes(double mean_row) {
@@ -306,7 +427,7 @@ static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, h
     hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
-                       a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc,
+                       a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc, a->d_pages,
                        (uint32_t)a->nrows, (uint32_t)a->ncols, (uint32_t)a->nnz, p.nblocks, per_xcd,
                        (uint32_t)(p.nt_store ? 1 : 0));
     return hipGetLastError();
@@ -327,7 +448,7 @@ static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, voi
     hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(used * 8), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
-                       a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc,
+                       a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc, a->d_pages,
                        (uint32_t)a->nrows, (uint32_t)a->ncols, (uint32_t)a->nnz, p.nblocks, per_xcd, chunk,
                        (uint32_t)(p.nt_store ? 1 : 0));
     return hipGetLastError();
@@ -419,18 +540,29 @@ static int block_windows(spal_csr *a, uint32_t R, std::vector<uint2> &win) {
 // Stream plan: super-tiles of R rows; returns the fraction of rows
 // that can be streamed and fills `desc`.
 static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4> &desc, uint32_t &cap,
-                       double &frac) {
+                       double &frac, uint32_t **out_pages) {
+    *out_pages = nullptr;
     const uint32_t nb = (uint32_t)((a->nrows + R - 1) / R);
-    std::vector<uint2> win;
-    SPAL_TRY(block_windows(a, R, win));
-    uint32_t *d_ok = nullptr;
+    // pages of 256 columns that fit the LDS budget: 24 (f64) / 48 (f32)
+    const uint32_t page_cap = kStreamWindowBytes / (kPageCols * (uint32_t)a->elem_size);
+    uint32_t *d_ok = nullptr, *d_pages = nullptr;
+    uint4 *d_info = nullptr;
     SPAL_HIP_TRY(dev_alloc((void **)&d_ok, (size_t)nb * 4));
+    SPAL_HIP_TRY(dev_alloc((void **)&d_info, (size_t)nb * sizeof(uint4)));
+    SPAL_HIP_TRY(dev_alloc((void **)&d_pages, (size_t)nb * page_cap * 4));
     hipLaunchKernelGGL(csr_stream_check, dim3((nb + 255) / 256), dim3(256), 0, a->stream, a->d_rowptr,
                        (uint32_t)a->nrows, nb, R, rpt, d_ok);
+    hipLaunchKernelGGL(csr_block_pages, dim3(nb), dim3(256), 0, a->stream, a->d_rowptr, a->d_colind,
+                       (uint32_t)a->nrows, R, page_cap, d_info, d_pages);
     std::vector<uint32_t> ok(nb);
+    std::vector<uint4> info(nb);
     hipError_t e = hipMemcpyAsync(ok.data(), d_ok, (size_t)nb * 4, hipMemcpyDeviceToHost, a->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(info.data(), d_info, (size_t)nb * sizeof(uint4), hipMemcpyDeviceToHost, a->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
     (void)dev_free(d_ok);
+    (void)dev_free(d_info);
+    if (e != hipSuccess) { (void)dev_free(d_pages); }
     SPAL_HIP_TRY(e);
     const uint32_t budget = kStreamWindowBytes / (uint32_t)a->elem_size;
     const uint32_t valign = 16u / (uint32_t)a->elem_size;
@@ -439,31 +571,34 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
     cap = 0;
     for (uint32_t b = 0; b < nb; ++b) {
         const uint64_t rows = std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
-        uint2 w = win[b];
-        if (w.y == 0) {  // nothing stored: stream mode with a 1-element window writes the zeros
-            desc[b] = make_uint4(0, valign, kModeStream, 0);
-            cap = std::max(cap, valign);
+        const uint4 w = info[b];   // {first column, one past the last, pages or kNotPageable, contiguous}
+        if (w.y == 0) {  // nothing stored: stream mode with one (arbitrary) page writes the zeros
+            desc[b] = make_uint4(0, 1, kModeStream, 1);
+            cap = std::max(cap, kPageCols);
             rows_stream += rows;
             continue;
         }
+        if (ok[b] && w.z != kNotPageable) {   // the pages its rows touch fit LDS
+            desc[b] = make_uint4(w.w ? (w.x >> kPageShift) : b * page_cap, w.z, kModeStream, w.w);
+            cap = std::max(cap, w.z * kPageCols);
+            rows_stream += rows;
+            continue;
+        }
+        if (ok[b] && a->plan.stream_global) {   // tiles fit, columns too scattered for LDS: x through L2
+            desc[b] = make_uint4(0, 0, kModeStreamGlobal, 0);
+            rows_stream += rows;
+            continue;
+        }
+        // a tile of more than 1024 entries: vector rows, x window in LDS when the span fits
         const uint32_t cb = w.x & ~(valign - 1);
         const uint32_t len = w.y - cb;
-        if (len > budget) {  // window too wide for LDS: x through L2
-            if (ok[b] && a->plan.stream_global) {
-                desc[b] = make_uint4(0, 0, kModeStreamGlobal, 0);
-                rows_stream += rows;
-            }
-            continue;        // (else: vector kernel, x from global)
-        }
-        cap = std::max(cap, len);
-        if (ok[b] && len <= 65536u) {
-            desc[b] = make_uint4(cb, len, kModeStream, 0);
-            rows_stream += rows;
-        } else {
+        if (len <= budget) {
             desc[b] = make_uint4(cb, len, kModeVectorLds, 0);
+            cap = std::max(cap, len);
         }
     }
     frac = a->nrows ? (double)rows_stream / (double)a->nrows : 0.0;
+    *out_pages = d_pages;
     return SPAL_OK;
 }
 
@@ -506,15 +641,25 @@ int csr_plan_build(spal_csr *a) {
         uint32_t cap = 0, best_cap = 0;
         double frac = 0.0, best_frac = -1.0;
         int best_rpt = rpts[0];
+        uint32_t *best_pages = nullptr;
+        if (a->d_pages) { SPAL_HIP_TRY(dev_free(a->d_pages)); a->d_pages = nullptr; }
         for (int rpt : rpts) {
             const uint32_t R = (uint32_t)stream_rows(p.tiles_per_wave, rpt);
-            SPAL_TRY(stream_plan(a, R, (uint32_t)rpt, desc, cap, frac));
+            uint32_t *pg = nullptr;
+            int st = stream_plan(a, R, (uint32_t)rpt, desc, cap, frac, &pg);
+            if (st != SPAL_OK) { (void)dev_free(best_pages); return st; }
             if (frac > best_frac + 0.05) {  // a narrower tile must buy real coverage
                 best_frac = frac; best_rpt = rpt; best_cap = cap; best_desc.swap(desc);
+                (void)dev_free(best_pages);
+                best_pages = pg;
+            } else {
+                (void)dev_free(pg);
             }
             if (best_frac >= 0.95) break;
         }
+        if (!(p.user_kernel == 2 || best_frac >= 0.5)) (void)dev_free(best_pages);
         if (p.user_kernel == 2 || best_frac >= 0.5) {
+            a->d_pages = best_pages;
             const uint32_t R = (uint32_t)stream_rows(p.tiles_per_wave, best_rpt);
             p.kernel = 2;
             p.rows_per_tile = best_rpt;
@@ -537,7 +682,7 @@ int csr_plan_build(spal_csr *a) {
                 SPAL_HIP_TRY(hipMemsetAsync(a->d_col16, 0, (size_t)a->cap_entries * sizeof(uint16_t), a->stream));
             }
             hipLaunchKernelGGL(csr_encode_col16, dim3(p.nblocks), dim3(256), 0, a->stream, a->d_rowptr,
-                               a->d_colind, a->d_desc, a->d_col16, (uint32_t)a->nrows, R);
+                               a->d_colind, a->d_desc, a->d_pages, a->d_col16, (uint32_t)a->nrows, R);
             SPAL_HIP_TRY(hipGetLastError());
             SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
             return SPAL_OK;
@@ -611,6 +756,7 @@ static void csr_free(spal_csr *a) {
     (void)dev_free(a->d_values);
     (void)dev_free(a->d_desc);
     (void)dev_free(a->d_col16);
+    (void)dev_free(a->d_pages);
     (void)dev_free(a->d_x);
     (void)dev_free(a->d_y);
     stream_release(a->stream);

@@ -123,7 +123,8 @@ struct spal_csr {
     uint32_t *d_rowptr = nullptr;  // nrows + 1
     uint32_t *d_colind = nullptr;  // nnz
     void *d_values = nullptr;      // nnz * elem_size
-    uint16_t *d_col16 = nullptr;   // nnz (+pad): window-relative columns of streamable super-tiles
+    uint16_t *d_col16 = nullptr;   // nnz (+pad): page slot * 256 + column inside the page, streamable super-tiles
+    uint32_t *d_pages = nullptr;   // blocks * page budget: ascending page ids of super-tiles whose pages are not one run
     uint4 *d_desc = nullptr;       // per row block {window base column, window length or 0, mode, 0}
     uint64_t cap_entries = 0;      // allocated entries of d_colind / d_values (>= nnz + pad)
     // autotune: microseconds per launch of {plain, persistent} x {plain, non-temporal y stores}

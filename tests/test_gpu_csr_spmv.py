@@ -445,3 +445,75 @@ def test_patchwork_matrices_all_planner_modes(oracle, dtype):
         check(oracle, rp, ci, va, x, ncols, kernel=2, persistent=1, stream_global=0)
         check(oracle, rp, ci, va, x, ncols, kernel=1)
     assert "stream" in kernels
+
+
+def _stencil(m, points, dtype, rng):
+    """m^3 grid, 7- or 27-point stencil, row-major numbering: the columns of a row sit in a few
+    narrow clusters far apart (offsets +-1, +-m, +-m^2)."""
+    n = m ** 3
+    idx = np.arange(n, dtype=np.int64)
+    i, j, k = idx // (m * m), (idx // m) % m, idx % m
+    offs = [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1)
+            if points == 27 or abs(a) + abs(b) + abs(c) <= 1]
+    cols = np.stack([idx + a * m * m + b * m + c for a, b, c in offs], 1)
+    valid = np.stack([(i + a >= 0) & (i + a < m) & (j + b >= 0) & (j + b < m) & (k + c >= 0) & (k + c < m)
+                      for a, b, c in offs], 1)
+    rp = np.concatenate([[0], np.cumsum(valid.sum(1))]).astype(np.uint64)
+    ci = cols[valid].astype(np.uint64)
+    return n, rp, ci, rng.uniform(-1, 1, ci.size).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_paged_x_window_stencils_bit_identical(oracle, dtype):
+    """The LDS x window is a set of 256-column pages, not one interval: stencil matrices
+    (column span of a super-tile = 2 m^2, far beyond LDS; distinct pages: a dozen) stream out
+    of LDS like a band does, in every form, bit-identical to the reference order.  Also: a
+    vector x that is not 16-byte aligned, and a column count that ends inside a page."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(31)
+    for m, points in ((61, 7), (47, 27)):
+        n, rp, ci, va = _stencil(m, points, dtype, rng)
+        x = rng.uniform(-1, 1, n).astype(dtype)
+        dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+        d = dev.describe()
+        assert d["kernel"] == "stream" and d["stream_row_fraction"] == 1.0 and d["lds_row_fraction"] == 1.0, d
+        assert d["lds_window_bytes"] <= 48 * 1024
+        y_ref = oracle.csr_spmv(rp, ci, va, x)
+        assert np.array_equal(dev.spmv(x), y_ref)
+        for persistent, nt in ((1, 0), (1, 1), (0, 1)):
+            dev.set_option("persistent", persistent)
+            dev.set_option("nt_store", nt)
+            assert np.array_equal(dev.spmv(x), y_ref)
+        # x at an odd element offset: not 16-byte aligned, the element-wise staging path
+        big = torch.zeros(n + 3, dtype=torch.float64 if dtype == np.float64 else torch.float32, device="cuda")
+        big[1:n + 1].copy_(torch.from_numpy(x))
+        yd = dev.spmv_torch(big[1:n + 1])
+        assert np.array_equal(yd.cpu().numpy(), y_ref)
+    # columns too scattered for 24 / 48 pages: the stream kernel gathers through L2 instead
+    n = 150_000
+    rp, ci, va = sp.synth.banded_csr(n, n, 14, n, 5, dtype=dtype)
+    dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    d = dev.describe()
+    assert d["kernel"] == "stream" and d["lds_row_fraction"] == 0.0, d
+    x = sp.synth.vector(n, dtype=dtype)
+    assert np.array_equal(dev.spmv(x), oracle.csr_spmv(rp, ci, va, x))
+    # two bands far apart + a last page that x ends inside of (ncols = 5 * 256 + 3 beyond the band)
+    nr, nc = 30_000, 900_003
+    lens = rng.integers(0, 20, nr)
+    rows_c = []
+    for r in range(nr):
+        k = int(lens[r])
+        left = np.sort(rng.choice(800, k // 2, replace=False)) + r
+        right = np.sort(rng.choice(500, k - k // 2, replace=False)) + (nc - 500 if r % 3 == 0 else 600_000 + r)
+        rows_c.append(np.concatenate([left, right]).astype(np.uint64))
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    ci = np.concatenate(rows_c)
+    va = rng.uniform(-1, 1, ci.size).astype(dtype)
+    x = rng.uniform(-1, 1, nc).astype(dtype)
+    dev = sp.CsrMatrix(nr, nc, rp, ci, va).device()
+    d = dev.describe()
+    assert d["kernel"] == "stream" and d["lds_row_fraction"] > 0.9, d
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    assert np.array_equal(dev.spmv(x), y_ref)
+    dev.set_option("persistent", 1)
+    assert np.array_equal(dev.spmv(x), y_ref)

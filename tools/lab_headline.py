@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Config 3 f64, plain and persistent form, for A/B runs of differently built libraries
+(SPAL_HIP_LIB); development tool."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import spalinalg_amd as sp  # noqa: E402
+
+
+def timeit(fn, iters):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+n = 10_000_000
+rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, sp.synth.matrix_seed(3))
+dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
+x = torch.from_numpy(sp.synth.vector(n)).cuda()
+y = torch.empty_like(x)
+for _ in range(150):
+    dev.spmv_torch(x, out=y)
+out = []
+for rnd in range(3):
+    for pers in (0, 1):
+        dev.set_option("persistent", pers)
+        timeit(lambda: dev.spmv_torch(x, out=y), 20)
+        out.append(f"{'pers' if pers else 'plain'} {timeit(lambda: dev.spmv_torch(x, out=y), 150):6.1f}")
+print(os.environ.get("SPAL_HIP_LIB", "main").split("/")[-2] if os.environ.get("SPAL_HIP_LIB") else "main", " | ".join(out), flush=True)
