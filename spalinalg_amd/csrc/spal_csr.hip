@@ -234,23 +234,28 @@ constexpr uint32_t kNotPageable = 0xffffffffu;
 constexpr uint32_t kPageBitmapWords = 2048;   // 65536 pages
 __global__ __launch_bounds__(256) void csr_block_pages(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind, uint32_t nrows,
-    uint32_t R, uint32_t cap, uint4 *__restrict__ info, uint32_t *__restrict__ pages) {
+    uint32_t R, uint32_t cap, const uint2 *__restrict__ known_win, uint4 *__restrict__ info,
+    uint32_t *__restrict__ pages) {
     __shared__ uint32_t s_bits[kPageBitmapWords];
     __shared__ uint32_t s_min, s_max, s_count, s_wsum[4];
     const uint32_t t = threadIdx.x, b = blockIdx.x;
     if (t == 0) { s_min = 0xffffffffu; s_max = 0u; s_count = 0u; }
     __syncthreads();
     const uint32_t row0 = b * R, row1 = min(row0 + R, nrows);
-    uint32_t lo = 0xffffffffu, hi = 0u;
-    for (uint32_t r = row0 + t; r < row1; r += 256) {
-        const uint32_t a0 = rowptr[r], a1 = rowptr[r + 1];
-        if (a0 < a1) {   // columns ascend inside a row: its first and last entry bound it
-            lo = min(lo, colind[a0]);
-            hi = max(hi, colind[a1 - 1] + 1u);
+    if (known_win) {   // the caller already knows {first column, one past the last} of this super-tile
+        if (t == 0) { s_min = known_win[b].x; s_max = known_win[b].y; }
+    } else {
+        uint32_t lo = 0xffffffffu, hi = 0u;
+        for (uint32_t r = row0 + t; r < row1; r += 256) {
+            const uint32_t a0 = rowptr[r], a1 = rowptr[r + 1];
+            if (a0 < a1) {   // columns ascend inside a row: its first and last entry bound it
+                lo = min(lo, colind[a0]);
+                hi = max(hi, colind[a1 - 1] + 1u);
+            }
         }
+        atomicMin(&s_min, lo);
+        atomicMax(&s_max, hi);
     }
-    atomicMin(&s_min, lo);
-    atomicMax(&s_max, hi);
     __syncthreads();
     const uint32_t cmin = s_min, cmax = s_max;
     if (cmax == 0) {   // nothing stored
@@ -552,8 +557,17 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
     SPAL_HIP_TRY(dev_alloc((void **)&d_pages, (size_t)nb * page_cap * 4));
     hipLaunchKernelGGL(csr_stream_check, dim3((nb + 255) / 256), dim3(256), 0, a->stream, a->d_rowptr,
                        (uint32_t)a->nrows, nb, R, rpt, d_ok);
+    // column windows already known per 256 rows (e.g. handed over by the assembly): fold and pass them
+    uint2 *d_win = nullptr;
+    if (!a->win_base.empty() && R % kWinBase == 0) {
+        std::vector<uint2> win;
+        SPAL_TRY(block_windows(a, R, win));
+        SPAL_HIP_TRY(dev_alloc((void **)&d_win, (size_t)nb * sizeof(uint2)));
+        SPAL_HIP_TRY(hipMemcpyAsync(d_win, win.data(), (size_t)nb * sizeof(uint2), hipMemcpyHostToDevice, a->stream));
+        SPAL_HIP_TRY(hipStreamSynchronize(a->stream));   // `win` goes out of scope
+    }
     hipLaunchKernelGGL(csr_block_pages, dim3(nb), dim3(256), 0, a->stream, a->d_rowptr, a->d_colind,
-                       (uint32_t)a->nrows, R, page_cap, d_info, d_pages);
+                       (uint32_t)a->nrows, R, page_cap, d_win, d_info, d_pages);
     std::vector<uint32_t> ok(nb);
     std::vector<uint4> info(nb);
     hipError_t e = hipMemcpyAsync(ok.data(), d_ok, (size_t)nb * 4, hipMemcpyDeviceToHost, a->stream);
@@ -562,6 +576,7 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
     if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
     (void)dev_free(d_ok);
     (void)dev_free(d_info);
+    (void)dev_free(d_win);
     if (e != hipSuccess) { (void)dev_free(d_pages); }
     SPAL_HIP_TRY(e);
     const uint32_t budget = kStreamWindowBytes / (uint32_t)a->elem_size;
