@@ -444,10 +444,17 @@ static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, voi
     constexpr int L = 16;
     const CsrPlan &p = a->plan;
     const uint32_t per_xcd = (p.nblocks + 7) / 8;
-    const uint32_t slots = (uint32_t)std::max(1, p.persistent_blocks / 8);   // workgroups per XCD
+    const size_t lds = ((size_t)kStreamWaves * kStreamTileNnz + p.lds_entries) * sizeof(T);
+    // grid: as many workgroups as the device holds at once -- 160 KiB of LDS per CU decide
+    // (f64 band: 2 per CU = 512; f32, whose strips and window are half the size: 4 per CU)
+    int grid = p.persistent_blocks;
+    if (grid <= 0) {
+        const int per_cu = (int)std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / (lds + 1024)));
+        grid = 256 * per_cu;
+    }
+    const uint32_t slots = (uint32_t)std::max(1, grid / 8);                   // workgroups per XCD
     const uint32_t chunk = (per_xcd + slots - 1) / slots;
     const uint32_t used = (per_xcd + chunk - 1) / chunk;                      // non-empty slots
-    const size_t lds = ((size_t)kStreamWaves * kStreamTileNnz + p.lds_entries) * sizeof(T);
     auto kern = csr_spmv_stream_persistent<T, L, 2, true, 4, RPT>;
     static std::atomic<uint64_t> configured{0};
     hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
@@ -1103,8 +1110,8 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "persistent must be 0 or 1");
         p.persistent = (int)value;
     } else if (!strcmp(key, "persistent_blocks")) {
-        if (value < 8 || value > 4096 || (value % 8))
-            return fail(SPAL_ERR_INVALID_ARGUMENT, "persistent_blocks must be a multiple of 8 in [8, 4096]");
+        if (value != 0 && (value < 8 || value > 4096 || (value % 8)))
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "persistent_blocks must be 0 (auto) or a multiple of 8 in [8, 4096]");
         p.persistent_blocks = (int)value;
     } else if (!strcmp(key, "rows_per_tile")) {
         if (value == 0) p.user_rows_per_tile = false;

@@ -92,7 +92,7 @@ struct CsrPlan {
     int persistent = 0;      // stream kernel: fixed grid walking chunks of super-tiles
     int nt_store = 0;        // stream kernel: non-temporal stores of y
     int stream_global = 1;   // stream kernel: tiles whose window exceeds LDS gather x from global
-    int persistent_blocks = 512;  // its grid (2 workgroups per CU on 256 CUs)
+    int persistent_blocks = 0;    // its grid; 0 = what the device holds at once (LDS per workgroup decides: f64 band 512)
     int rows_per_block = 0;  // R
     int lds_x = 0;           // stage the block's x window in LDS
     uint32_t lds_entries = 0;  // LDS window capacity (elements) when lds_x

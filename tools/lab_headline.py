@@ -22,9 +22,10 @@ def timeit(fn, iters):
 
 
 n = 10_000_000
-rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, sp.synth.matrix_seed(3))
+dt = np.float32 if "f32" in sys.argv[1:] else np.float64
+rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, sp.synth.matrix_seed(3), dtype=dt)
 dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
-x = torch.from_numpy(sp.synth.vector(n)).cuda()
+x = torch.from_numpy(sp.synth.vector(n, dtype=dt)).cuda()
 y = torch.empty_like(x)
 for _ in range(150):
     dev.spmv_torch(x, out=y)
