@@ -30,9 +30,13 @@ y = torch.empty_like(x)
 for _ in range(150):
     dev.spmv_torch(x, out=y)
 out = []
+forms = [("plain", [("tiles_per_wave", 4), ("persistent", 0)]), ("pers", [("tiles_per_wave", 4), ("persistent", 1)])]
+if "tpw8" in sys.argv[1:]:
+    forms += [("plain8", [("tiles_per_wave", 8), ("persistent", 0)]), ("pers8", [("tiles_per_wave", 8), ("persistent", 1)])]
 for rnd in range(3):
-    for pers in (0, 1):
-        dev.set_option("persistent", pers)
+    for name, opts in forms:
+        for k, v in opts:
+            dev.set_option(k, v)
         timeit(lambda: dev.spmv_torch(x, out=y), 20)
-        out.append(f"{'pers' if pers else 'plain'} {timeit(lambda: dev.spmv_torch(x, out=y), 150):6.1f}")
+        out.append(f"{name} {timeit(lambda: dev.spmv_torch(x, out=y), 150):6.1f}")
 print(os.environ.get("SPAL_HIP_LIB", "main").split("/")[-2] if os.environ.get("SPAL_HIP_LIB") else "main", " | ".join(out), flush=True)
