@@ -366,7 +366,7 @@ __global__ __launch_bounds__(BLOCK, 8) void csr_spmv_vector(
 // A workgroup (4 waves) owns a SUPER-TILE of 256 * TPW rows (TPW = 4: 1024) and
 // stages its x window in LDS once.  Each wave owns TPW TILES of 64 consecutive
 // rows.  For a tile the wave
-//   1. loads the tile's values and 16-bit window-relative columns with wide,
+//   1. loads the tile's values and 16-bit columns (page slot * 256 + column inside the page) with wide,
 //      perfectly coalesced loads: lane l, step j holds entries
 //      start + (64 j + l) * 2 + {0, 1}   (tile k+1 is in flight while tile k
 //      is being processed),
@@ -402,7 +402,7 @@ template <> struct Pair<float> { using type = __attribute__((ext_vector_type(2))
 template <typename T>
 struct StreamTile {
     typename Pair<T>::type v[kStreamSteps];
-    uint32_t c[kStreamSteps];  // two 16-bit window-relative columns
+    uint32_t c[kStreamSteps];  // two 16-bit LDS-window positions (page slot * 256 + column inside the page)
     uint32_t rp0, rp1;         // rowptr[row], rowptr[row + 1] of this lane's row
     uint32_t start;            // first loaded entry (tile start rounded down to even); wave-uniform
     uint32_t steps;            // 128-entry steps that hold entries of the tile; wave-uniform

@@ -80,7 +80,7 @@ const char *invariant_text(int reason, bool csr);
 struct CsrPlan {
     // kernel family: 1 = "vector" (L lanes per row, shuffle reduction, optional
     // LDS-staged x window); 2 = "stream" (lane per row, products through LDS,
-    // 16-bit window-relative columns; vector fallback per super-tile)
+    // 16-bit columns = position in the paged LDS x window; vector fallback per super-tile)
     int kernel = 0;          // 0 = not planned yet
     int user_kernel = 0;     // 0 = auto
     int lanes_per_row = 0;   // L in {2,4,8,16,32,64}
@@ -91,7 +91,7 @@ struct CsrPlan {
     int rows_per_tile = 64;  // stream kernel: rows of a wave-tile (64, 32 or 16)
     int persistent = 0;      // stream kernel: fixed grid walking chunks of super-tiles
     int nt_store = 0;        // stream kernel: non-temporal stores of y
-    int stream_global = 1;   // stream kernel: tiles whose window exceeds LDS gather x from global
+    int stream_global = 1;   // stream kernel: super-tiles whose pages exceed the LDS budget gather x from global
     int persistent_blocks = 0;    // its grid; 0 = what the device holds at once (LDS per workgroup decides: f64 band 512)
     int rows_per_block = 0;  // R
     int lds_x = 0;           // stage the block's x window in LDS
@@ -125,7 +125,8 @@ struct spal_csr {
     void *d_values = nullptr;      // nnz * elem_size
     uint16_t *d_col16 = nullptr;   // nnz (+pad): page slot * 256 + column inside the page, streamable super-tiles
     uint32_t *d_pages = nullptr;   // blocks * page budget: ascending page ids of super-tiles whose pages are not one run
-    uint4 *d_desc = nullptr;       // per row block {window base column, window length or 0, mode, 0}
+    uint4 *d_desc = nullptr;       // per row block: Stream {first page / offset into d_pages, pages, mode, contiguous};
+                                   // VectorLds {window base column, window length, mode, 0}
     uint64_t cap_entries = 0;      // allocated entries of d_colind / d_values (>= nnz + pad)
     // autotune: microseconds per launch of {plain, persistent} x {plain, non-temporal y stores}
     float tuned_us[4] = {0.f, 0.f, 0.f, 0.f};
