@@ -517,3 +517,32 @@ def test_paged_x_window_stencils_bit_identical(oracle, dtype):
     assert np.array_equal(dev.spmv(x), y_ref)
     dev.set_option("persistent", 1)
     assert np.array_equal(dev.spmv(x), y_ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_x_vector_ends_inside_a_page(oracle, dtype):
+    """column counts around the 16-byte vector and 256-column page boundaries, every row
+    touching the first and the last column; x both aligned and at an odd element offset."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(8)
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    for nc in (1, 2, 3, 4, 5, 7, 255, 256, 257, 511, 513, 1023, 1025):
+        nr = 300
+        rows = []
+        for r in range(nr):
+            inner = rng.choice(nc, min(nc, int(rng.integers(0, 6))), replace=False) if nc > 2 else np.empty(0, np.int64)
+            rows.append(np.unique(np.concatenate([[0, nc - 1], inner])).astype(np.uint64))
+        rp = np.concatenate([[0], np.cumsum([c.size for c in rows])]).astype(np.uint64)
+        ci = np.concatenate(rows)
+        va = rng.uniform(-1, 1, ci.size).astype(dtype)
+        x = rng.uniform(-1, 1, nc).astype(dtype)
+        dev = sp.CsrMatrix(nr, nc, rp, ci, va).device()
+        dev.set_option("kernel", 2)
+        assert dev.describe()["kernel"] == "stream"
+        y_ref = oracle.csr_spmv(rp, ci, va, x)
+        assert np.array_equal(dev.spmv(x), y_ref), nc
+        big = torch.full((nc + 2,), float("nan"), dtype=tdt, device="cuda")   # NaN guards either side
+        big[1:nc + 1].copy_(torch.from_numpy(x))
+        assert np.array_equal(dev.spmv_torch(big[1:nc + 1]).cpu().numpy(), y_ref), nc
+        dev.set_option("persistent", 1)
+        assert np.array_equal(dev.spmv(x), y_ref), nc
