@@ -204,6 +204,10 @@ static constexpr uint32_t kLdsBudgetBytes = 64 * 1024;
 // stream kernel: 4 product strips (kStreamTileNnz each, 32 KiB f64) + a window of
 // at most 48 KiB -> at most 80 KiB per workgroup, two workgroups per CU.
 static constexpr uint32_t kStreamWindowBytes = 48 * 1024;
+// ... or one workgroup per CU with a window of up to 120 KiB (+ 32 KiB of strips), for matrices whose
+// super-tiles touch more pages than 48 KiB hold: LDS gathers at half the occupancy still beat x through L2
+// (band of 8192 columns, f64: 463 / 392 us against 722 us)
+static constexpr uint32_t kStreamBigWindowBytes = 120 * 1024;
 
 // One thread per super-tile: every 64-row tile must fit the product strip.
 __global__ __launch_bounds__(256) void csr_stream_check(const uint32_t *__restrict__ rowptr,
@@ -373,7 +377,7 @@ static hipError_t raise_lds_cap(K kern, int device, size_t lds, std::atomic<uint
     const uint64_t bit = 1ull << (device & 63);
     if (configured.load(std::memory_order_relaxed) & bit) return hipSuccess;
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       128 * 1024);
+                                       160 * 1024);
     if (e == hipSuccess) configured.fetch_or(bit, std::memory_order_relaxed);
     return e;
 }
@@ -556,7 +560,10 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
     *out_pages = nullptr;
     const uint32_t nb = (uint32_t)((a->nrows + R - 1) / R);
     // pages of 256 columns that fit the LDS budget: 24 (f64) / 48 (f32)
-    const uint32_t page_cap = kStreamWindowBytes / (kPageCols * (uint32_t)a->elem_size);
+    // page budgets: `small` keeps two workgroups per CU, `page_cap` (<= 64: page ids travel in a wave's lanes) one
+    const uint32_t page_bytes = kPageCols * (uint32_t)a->elem_size;
+    const uint32_t page_cap = std::min<uint32_t>(64u, kStreamBigWindowBytes / page_bytes);
+    const uint32_t small_cap = std::min<uint32_t>(page_cap, a->elem_size == 4 ? 64u : kStreamWindowBytes / page_bytes);
     uint32_t *d_ok = nullptr, *d_pages = nullptr;
     uint4 *d_info = nullptr;
     SPAL_HIP_TRY(dev_alloc((void **)&d_ok, (size_t)nb * 4));
@@ -588,6 +595,24 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
     SPAL_HIP_TRY(e);
     const uint32_t budget = kStreamWindowBytes / (uint32_t)a->elem_size;
     const uint32_t valign = 16u / (uint32_t)a->elem_size;
+    // which page budget?  Rows weighted by what their mode costs per entry, from measurements on bands
+    // (f64): LDS window at two workgroups per CU 1.0, at one workgroup per CU 1.35, x through L2 2.3
+    uint32_t use_cap = small_cap;
+    if (a->plan.window_pages > 0) {
+        use_cap = std::min<uint32_t>(page_cap, (uint32_t)a->plan.window_pages);
+    } else if (page_cap > small_cap) {
+        double rows_small = 0, rows_big = 0, rows_ok = 0;
+        for (uint32_t b = 0; b < nb; ++b) {
+            if (!ok[b] || info[b].y == 0) continue;
+            const double rows = (double)std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
+            rows_ok += rows;
+            if (info[b].z != kNotPageable && info[b].z <= small_cap) rows_small += rows;
+            if (info[b].z != kNotPageable) rows_big += rows;
+        }
+        const double cost_small = rows_small * 1.0 + (rows_ok - rows_small) * 2.3;
+        const double cost_big = rows_big * 1.35 + (rows_ok - rows_big) * 2.3;
+        if (cost_big < 0.97 * cost_small) use_cap = page_cap;
+    }
     desc.assign(nb, make_uint4(0, 0, kModeVectorGlobal, 0));
     uint64_t rows_stream = 0;
     cap = 0;
@@ -600,7 +625,7 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
             rows_stream += rows;
             continue;
         }
-        if (ok[b] && w.z != kNotPageable) {   // the pages its rows touch fit LDS
+        if (ok[b] && w.z != kNotPageable && w.z <= use_cap) {   // the pages its rows touch fit the LDS budget
             desc[b] = make_uint4(w.w ? (w.x >> kPageShift) : b * page_cap, w.z, kModeStream, w.w);
             cap = std::max(cap, w.z * kPageCols);
             rows_stream += rows;
@@ -1103,6 +1128,11 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
     } else if (!strcmp(key, "stream_global")) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "stream_global must be 0 or 1");
         p.stream_global = (int)value;
+    } else if (!strcmp(key, "window_pages")) {
+        // stream kernel: LDS budget of a super-tile in 256-column pages; 0 = automatic (24 f64 pages
+        // at two workgroups per CU, or up to 60 at one when that is estimated to pay)
+        if (value < 0 || value > 64) return fail(SPAL_ERR_INVALID_ARGUMENT, "window_pages must be in [0, 64]");
+        p.window_pages = (int)value;
     } else if (!strcmp(key, "nt_store")) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "nt_store must be 0 or 1");
         p.nt_store = (int)value;

@@ -49,6 +49,8 @@ def main():
         csr_case("cfg3 uniform f64 (stress)", 10_000_000, None, np.float64, iters=10)
         csr_case("cfg3 W=65536 f64", 10_000_000, 65536, np.float64, iters=10)
         csr_case("cfg3 W=16384 f64", 10_000_000, 16384, np.float64, iters=10)
+        csr_case("cfg3 W=8192 f64", 10_000_000, 8192, np.float64, iters=10)
+        csr_case("cfg3 W=8192 f64 persistent", 10_000_000, 8192, np.float64, iters=10, opts=[("persistent", 1)])
         csr_case("cfg3 banded f64 vector kernel", 10_000_000, 4096, np.float64, opts=[("kernel", 1)])
         csr_case("cfg2 banded f64 (fits MALL)", 1_000_000, 4096, np.float64, iters=100)
     if "csc" in which:
