@@ -83,6 +83,7 @@ struct CsrPlan {
     // 16-bit columns = position in the paged LDS x window; vector fallback per super-tile)
     int kernel = 0;          // 0 = not planned yet
     int user_kernel = 0;     // 0 = auto
+    bool user_persistent = false;  // `persistent` was set by the caller or by the autotune
     int lanes_per_row = 0;   // L in {2,4,8,16,32,64}
     int unroll = 1;          // row groups in flight per wave iteration
     int long_rows = 0;       // vector kernel: batched rest-of-row loop (mean row length above 64)
