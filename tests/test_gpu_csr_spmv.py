@@ -565,3 +565,39 @@ def test_x_vector_ends_inside_a_page(oracle, dtype):
         assert np.array_equal(dev.spmv_torch(big[1:nc + 1]).cpu().numpy(), y_ref), nc
         dev.set_option("persistent", 1)
         assert np.array_equal(dev.spmv(x), y_ref), nc
+
+
+def test_device_entry_point_is_graph_capturable(oracle):
+    """`spal_csr_spmv_dev_*` only enqueues work on the caller's stream (no allocation, no
+    synchronisation), so a launch-bound loop of products can be captured in a HIP graph and
+    replayed: here y2 = A (A x) for a small matrix, 8 pairs per graph launch."""
+    torch = pytest.importorskip("torch")
+    n = 50_000
+    rp, ci, va = sp.synth.banded_csr(n, n, 14, 1024, 19)
+    dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    x = torch.from_numpy(sp.synth.vector(n)).cuda()
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        dev.spmv_torch(x, out=y1)          # warm-up outside the capture (module load, LDS attribute)
+        dev.spmv_torch(y1, out=y2)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(8):
+            dev.spmv_torch(x, out=y1)
+            dev.spmv_torch(y1, out=y2)
+    y1.zero_()
+    y2.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    xh = x.cpu().numpy()
+    r1 = oracle.csr_spmv(rp, ci, va, xh)
+    r2 = oracle.csr_spmv(rp, ci, va, r1)
+    assert np.array_equal(y1.cpu().numpy(), r1) and np.array_equal(y2.cpu().numpy(), r2)
+    x.mul_(2.0)                               # new input, same graph
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(y1.cpu().numpy(), oracle.csr_spmv(rp, ci, va, 2.0 * xh))
