@@ -116,9 +116,13 @@ int spal_csr_download_f64(spal_csr_t a, uint64_t *rowptr, uint64_t *colind,
                           double *values);
 int spal_csr_download_f32(spal_csr_t a, uint64_t *rowptr, uint64_t *colind,
                           float *values);
-/* Kernel plan knobs (tuning / tests).  Keys: "kernel" (0 = auto),
- * "rows_per_block", "lanes_per_row", "lds_x" (-1 auto/0/1), "unroll", "threads".  Unknown key or
- * a value the kernels are not instantiated for: SPAL_ERR_INVALID_ARGUMENT. */
+/* Kernel plan knobs (tuning / tests).  Keys: "kernel" (0 = auto, 1 = vector,
+ * 2 = stream), "rows_per_block", "lanes_per_row", "lds_x" (-1 auto/0/1),
+ * "unroll", "threads" (vector kernel); "rows_per_tile" (0 auto, 64, 32, 16),
+ * "tiles_per_wave", "persistent", "persistent_blocks" (0 = what the device
+ * holds at once), "nt_store", "stream_global", "window_pages" (0 auto; LDS x
+ * window budget in 256-column pages) (stream kernel).  Unknown key or a value
+ * the kernels are not instantiated for: SPAL_ERR_INVALID_ARGUMENT. */
 int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value);
 /* Setup-time autotune: runs the planned kernel's variants (today: the stream
  * kernel with one workgroup per super-tile vs. its persistent form, each with

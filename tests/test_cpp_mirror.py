@@ -53,3 +53,29 @@ def test_oracle_under_asan_ubsan():
                          env=dict(os.environ, UBSAN_OPTIONS="halt_on_error=1"))
     assert out.returncode == 0, out.stdout + out.stderr
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr
+
+
+C_EXE = os.path.join(ROOT, "tests", "c", "abi_demo")
+
+
+def build_c():
+    """include/spal.h is a C header: a C99 translation unit, -pedantic -Werror."""
+    src = os.path.join(ROOT, "tests", "c", "abi_demo.c")
+    lib = os.path.join(ROOT, "spalinalg_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I",
+                           os.path.join(ROOT, "include"), src, "-o", C_EXE, "-L", lib, "-lspal_hip",
+                           f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_plain_c_caller_host():
+    build_c()
+    out = subprocess.run([C_EXE], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "spalinalg_amd" in out.stdout and "devices:" in out.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_gpu():
+    build_c()
+    out = subprocess.run([C_EXE, "gpu"], capture_output=True, text=True)
+    assert out.returncode == 0 and "gpu ok" in out.stdout, out.stdout + out.stderr
