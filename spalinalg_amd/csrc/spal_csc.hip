@@ -20,6 +20,9 @@
 
 namespace spal {
 
+#ifndef SPAL_CSC_U
+#define SPAL_CSC_U 4
+#endif
 #ifndef SPAL_CSC_BLOCK
 #define SPAL_CSC_BLOCK 1024
 #endif
@@ -28,7 +31,10 @@ namespace spal {
 #endif
 constexpr int kCscBlock = SPAL_CSC_BLOCK;      // threads of the scatter kernel
 constexpr int kCscCols = SPAL_CSC_COLS;        // columns per super-tile
-constexpr uint32_t kCscWindowBytes = 48 * 1024;  // LDS y window budget (+ 8 KiB x tile)
+// LDS y window budget (+ 8 KiB x tile): two 1024-thread workgroups per CU either way; a band's
+// clamped edge needs more rows than its interior (config 4: 6717 against 5120), and ONE super-tile
+// left to the global-atomic path kept the whole launch busy (47 us -> 78 us)
+constexpr uint32_t kCscWindowBytes = 70 * 1024;
 constexpr uint32_t kCscModeGlobal = 0, kCscModeLds = 1;
 
 // ---- plan-time kernels ---------------------------------------------------------
@@ -91,32 +97,46 @@ __global__ __launch_bounds__(kCscBlock, kCscBlock >= 1024 ? 1 : 2) void csc_spmv
     const uint32_t b = xcd_contiguous_block(blockIdx.x, per_xcd);
     if (b >= nblocks) return;
     const uint32_t k0 = b * kCscCols, k1 = min(k0 + (uint32_t)kCscCols, ncols);
+    // desc and the two column pointers are independent loads: one round trip for the three
     const uint4 d = desc[b];  // block-uniform
+    const uint32_t p0 = colptr[k0], p1 = colptr[k1];  // uniform
 
     if (d.z == kCscModeLds) {
-        const uint32_t p0 = colptr[k0], p1 = colptr[k1];  // uniform
+        // entries in pairs from an even start; a batch = U pairs per thread.  The FIRST batch and this
+        // thread's element of the x tile are requested before the window is zeroed and before the
+        // barrier: zeroing and staging hide behind those loads.
+        constexpr uint32_t U = SPAL_CSC_U;
+        constexpr uint32_t kBatch = 2 * U * kCscBlock;
+        static_assert(kCscCols <= kCscBlock, "one x element per thread");
+        uint32_t batch0 = p0 & ~1u;   // uniform: first entry of the current batch
+        pair_t v[U];
+        u2_t m[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            // unconditional loads; a batch may reach past the super-tile's last entry: stay inside
+            // the allocation (last_pair = last even index of the padded arrays)
+            const uint32_t e = min(batch0 + threadIdx.x * 2 + u * (kCscBlock * 2), last_pair);
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const pair_t *>(vals + e));
+            m[u] = __builtin_nontemporal_load(reinterpret_cast<const u2_t *>(meta + e));
+        }
+        const T xk = x[min(k0 + threadIdx.x, k1 - 1u)];
         for (uint32_t i = threadIdx.x; i < d.y; i += kCscBlock) yw[i] = T(0);
-        for (uint32_t i = threadIdx.x; i < k1 - k0; i += kCscBlock) xt[i] = x[k0 + i];
+        if (threadIdx.x < k1 - k0) xt[threadIdx.x] = xk;
         __syncthreads();
-        // entries in pairs from an even start; each workgroup pass covers 512 entries
-        constexpr uint32_t U = 4;
-        const uint32_t pa = p0 & ~1u;
-        for (uint32_t base = pa + threadIdx.x * 2; base < p1; base += kCscBlock * 2 * U) {
-            pair_t v[U];
-            u2_t m[U];
+        while (true) {
 #pragma unroll
             for (uint32_t u = 0; u < U; ++u) {
-                // unconditional loads; a step may reach past the super-tile's last entry: stay
-                // inside the allocation (last_pair = last even index of the padded arrays)
-                const uint32_t e = min(base + u * (kCscBlock * 2), last_pair);
-                v[u] = __builtin_nontemporal_load(reinterpret_cast<const pair_t *>(vals + e));
-                m[u] = __builtin_nontemporal_load(reinterpret_cast<const u2_t *>(meta + e));
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < U; ++u) {
-                const uint32_t e = base + u * (kCscBlock * 2);
+                const uint32_t e = batch0 + threadIdx.x * 2 + u * (kCscBlock * 2);
                 if (e >= p0 && e < p1) lds_add(&yw[m[u].x & 0xffffu], v[u].x * xt[m[u].x >> 16]);
                 if (e + 1 >= p0 && e + 1 < p1) lds_add(&yw[m[u].y & 0xffffu], v[u].y * xt[m[u].y >> 16]);
+            }
+            batch0 += kBatch;
+            if (batch0 >= p1) break;   // uniform
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t e = min(batch0 + threadIdx.x * 2 + u * (kCscBlock * 2), last_pair);
+                v[u] = __builtin_nontemporal_load(reinterpret_cast<const pair_t *>(vals + e));
+                m[u] = __builtin_nontemporal_load(reinterpret_cast<const u2_t *>(meta + e));
             }
         }
         __syncthreads();
@@ -135,17 +155,40 @@ __global__ __launch_bounds__(kCscBlock, kCscBlock >= 1024 ? 1 : 2) void csc_spmv
         return;
     }
 
-    // global scatter: L lanes per column
-    constexpr uint32_t G = kCscBlock / L;
-    const uint32_t g = threadIdx.x / L, s = threadIdx.x % L;
-    for (uint32_t k = k0 + g; k < k1; k += G) {
-        const uint32_t a0 = colptr[k], a1 = colptr[k + 1];
-        if (a0 == a1) continue;
-        const T xk = x[k];
-        for (uint32_t p = a0 + s; p < a1; p += L) {
-            const uint32_t i = load_stream(rowind + p);
-            const T v = load_stream(vals + p);
-            atomicAdd(&y[i], v * xk);  // -munsafe-fp-atomics: global_atomic_add_f64 / _f32
+    // Super-tiles whose row window does not fit LDS (at a band's clamped edges, or scattered rows):
+    // one global atomic per entry, entry-parallel.  The tile's column pointers and x go to LDS;
+    // thread t takes entries p0 + t, p0 + t + 1024, ...: coalesced loads of (row, value), all of a
+    // batch in flight together, the entry's column by binary search in the LDS column pointers.
+    // (A lanes-per-column walk costs three dependent memory round trips per 64 columns; on config 4
+    // the two edge super-tiles alone kept the kernel busy for 75 us while all others took 47.)
+    {
+        uint32_t *cp = reinterpret_cast<uint32_t *>(yw);   // k1 - k0 + 1 column pointers
+        const uint32_t nk = k1 - k0;
+        for (uint32_t i = threadIdx.x; i <= nk; i += kCscBlock) cp[i] = colptr[k0 + i];
+        for (uint32_t i = threadIdx.x; i < nk; i += kCscBlock) xt[i] = x[k0 + i];
+        __syncthreads();
+        constexpr uint32_t U = 4;   // (p0 = cp[0], p1 = cp[nk])
+        for (uint32_t base = p0 + threadIdx.x; base < p1; base += kCscBlock * U) {
+            uint32_t row[U];
+            T val[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t e = min(base + u * kCscBlock, p1 - 1u);   // in bounds; the extra lanes re-read
+                row[u] = load_stream(rowind + e);
+                val[u] = load_stream(vals + e);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t e = base + u * kCscBlock;
+                if (e < p1) {
+                    uint32_t lo = 0, hi = nk;   // largest c with cp[c] <= e (empty columns share a pointer with their successor)
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (cp[mid] <= e) lo = mid; else hi = mid;
+                    }
+                    atomicAdd(&y[row[u]], val[u] * xt[lo]);  // -munsafe-fp-atomics: global_atomic_add_f64 / _f32
+                }
+            }
         }
     }
 }
@@ -194,7 +237,9 @@ static int pick_lanes_csc(double mean) {
 template <typename T, int L>
 static hipError_t csc_launch_l(const spal_csc *a, const void *x, void *y, hipStream_t st) {
     const uint32_t per_xcd = (a->nblocks + 7) / 8;
-    const size_t lds = ((size_t)kCscCols + a->lds_entries) * sizeof(T);
+    // x tile + the y window; global-mode super-tiles keep their column pointers where the window would be
+    const size_t lds = std::max(((size_t)kCscCols + a->lds_entries) * sizeof(T),
+                                (size_t)kCscCols * sizeof(T) + ((size_t)kCscCols + 2) * sizeof(uint32_t));
     auto kern = csc_spmv_scatter<T, L>;
     static std::atomic<uint64_t> configured{0};
     if (lds > 48 * 1024) {
