@@ -100,6 +100,14 @@ def rotating(fns):
     return call
 
 
+def traffic_entry(key):
+    """HBM bytes per launch measured with PMC passes (profiles/traffic.json), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def bench_csc(args):
     """BASELINE config 4: CscMatrix f64 SpMV (atomic scatter path), CSC of the config-2 matrix."""
     import torch
@@ -147,7 +155,8 @@ def bench_csc(args):
                       f"independent copies of (A, x, y) = {copies * B / 1e6:.0f} MB > the 256 MB Infinity Cache",
                       dev.describe())
     out["roofline"] = {"bound": "hbm", "achieved": round(B / (ms * 1e-3) / 1e9, 2), "peak": 8000.0,
-                       "unit": "GB/s", "frac": round(B / (ms * 1e-3) / 8e12, 4), "traffic": None,
+                       "unit": "GB/s", "frac": round(B / (ms * 1e-3) / 8e12, 4),
+                       "traffic": traffic_entry("config4_scatter_f64") if args.dtype == "f64" else None,
                        "kernel": "csc_spmv_scatter (+ y memset)", "kernel_ms": round(ms, 6),
                        "algorithmic_bytes_per_launch": B,
                        "note": "bound in practice by LDS / global float-atomic rates, not by HBM"}
@@ -218,7 +227,8 @@ def bench_coo(args):
                       f"cancelling pairs) into {nr}x{nr} -> {nnz} stored entries (BASELINE configs[4]), single GPU",
                       csr.describe())
     out["roofline"] = {"bound": "hbm", "achieved": round(lb / (ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
-                       "frac": round(lb / (ms * 1e-3) / 8e12, 4), "traffic": None,
+                       "frac": round(lb / (ms * 1e-3) / 8e12, 4),
+                       "traffic": traffic_entry("config5_assembly_f64") if args.dtype == "f64" else None,
                        "kernel": "radix_hist/scatter x2 + coo_group_sort + coo_group_pack + CSR planning (whole assembly call)",
                        "kernel_ms": round(ms, 6), "algorithmic_bytes_per_launch": lb,
                        "note": "algorithmic = lower bound 16*len + 12*nnz_out + 4*(nrows+1); a multi-pass sort "

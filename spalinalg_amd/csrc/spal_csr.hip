@@ -728,13 +728,19 @@ int csr_plan_build(spal_csr *a) {
             SPAL_HIP_TRY(dev_alloc((void **)&a->d_desc, (size_t)p.nblocks * sizeof(uint4)));
             SPAL_HIP_TRY(hipMemcpyAsync(a->d_desc, best_desc.data(), (size_t)p.nblocks * sizeof(uint4),
                                         hipMemcpyHostToDevice, a->stream));
-            if (!a->d_col16) {
-                SPAL_HIP_TRY(dev_alloc((void **)&a->d_col16, (size_t)a->cap_entries * sizeof(uint16_t)));
-                SPAL_HIP_TRY(hipMemsetAsync(a->d_col16, 0, (size_t)a->cap_entries * sizeof(uint16_t), a->stream));
+            // 16-bit columns only where some super-tile reads them (a matrix whose columns are scattered
+            // everywhere streams with the 32-bit ones: no 2 B/entry array to allocate and clear)
+            bool any_stream = false;
+            for (uint32_t b = 0; b < p.nblocks && !any_stream; ++b) any_stream = best_desc[b].z == kModeStream;
+            if (any_stream) {
+                if (!a->d_col16) {
+                    SPAL_HIP_TRY(dev_alloc((void **)&a->d_col16, (size_t)a->cap_entries * sizeof(uint16_t)));
+                    SPAL_HIP_TRY(hipMemsetAsync(a->d_col16, 0, (size_t)a->cap_entries * sizeof(uint16_t), a->stream));
+                }
+                hipLaunchKernelGGL(csr_encode_col16, dim3(p.nblocks), dim3(256), 0, a->stream, a->d_rowptr,
+                                   a->d_colind, a->d_desc, a->d_pages, a->d_col16, (uint32_t)a->nrows, R);
+                SPAL_HIP_TRY(hipGetLastError());
             }
-            hipLaunchKernelGGL(csr_encode_col16, dim3(p.nblocks), dim3(256), 0, a->stream, a->d_rowptr,
-                               a->d_colind, a->d_desc, a->d_pages, a->d_col16, (uint32_t)a->nrows, R);
-            SPAL_HIP_TRY(hipGetLastError());
             SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
             return SPAL_OK;
         }

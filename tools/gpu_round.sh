@@ -41,6 +41,12 @@ for s in "$@"; do
             step 400 pmc4a.log rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d gpurun_out/pmc4a -o p -- python3 bench.py --config 4 --steps 10 --warmup 3 --no-cpu-baseline --copies 1
             step 400 pmc4b.log rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/pmc4b -o p -- python3 bench.py --config 4 --steps 10 --warmup 3 --no-cpu-baseline --copies 1
             ;;
+    pmc45)  export TMPDIR=/tmp
+            step 400 pmc5f.log rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc5f -o p -- python3 bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline
+            step 400 pmc5w.log rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc5w -o p -- python3 bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline
+            step 400 pmc4f.log rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc4f -o p -- python3 bench.py --config 4 --steps 10 --warmup 3 --no-cpu-baseline --copies 1
+            step 400 pmc4w.log rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc4w -o p -- python3 bench.py --config 4 --steps 10 --warmup 3 --no-cpu-baseline --copies 1
+            ;;
     ab)     step 600 lab_ab.log python tools/lab_ab.py $AB_ARGS ;;
     bench)  step 400 bench.log python bench.py ;;
     rehearse2) step 600 rehearse2.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29631 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --same-device --config 2 --exchange allgather ;;
