@@ -1066,7 +1066,7 @@ static int coo_upload(int device, uint64_t nrows, uint64_t ncols, uint64_t len, 
     // CooMatrix::new asserts (src/coo.rs:105-106)
     if (!(nrows > 0)) return fail(SPAL_ERR_INVARIANT, "CooMatrix::new would panic: assertion failed: nrows > 0");
     if (!(ncols > 0)) return fail(SPAL_ERR_INVARIANT, "CooMatrix::new would panic: assertion failed: ncols > 0");
-    if (nrows >= 0xffffffffull || ncols > 0xffffffffull || len >= 0xffffffffull)
+    if (nrows >= 0xffffffffull || ncols > 0xffffffffull || len > kMaxEntries)
         return fail(SPAL_ERR_UNSUPPORTED, "COO shape does not fit 32-bit device indices");
     // every entry inside the matrix (push asserts, src/coo.rs:432-433)
     std::vector<uint32_t> r32(len), c32(len);

@@ -458,7 +458,7 @@ static int csc_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t
     int reason = 0;
     SPAL_TRY(spal_csc_validate(nrows, ncols, colptr, colptr_len, rowind, rowind_len, values_len, &reason));
     const uint64_t nnz = colptr[ncols];
-    if (ncols >= 0xffffffffull || nrows > 0xffffffffull || nnz > 0xffffffffull)
+    if (ncols >= 0xffffffffull || nrows > 0xffffffffull || nnz > kMaxEntries)
         return fail(SPAL_ERR_UNSUPPORTED,
                     "shape %llu x %llu with %llu entries does not fit 32-bit device indices",
                     (unsigned long long)nrows, (unsigned long long)ncols, (unsigned long long)nnz);

@@ -884,7 +884,7 @@ static int csr_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t
     int reason = 0;
     SPAL_TRY(spal_csr_validate(nrows, ncols, rowptr, rowptr_len, colind, colind_len, values_len, &reason));
     const uint64_t nnz = rowptr[nrows];
-    if (nrows >= 0xffffffffull || ncols > 0xffffffffull || nnz > 0xffffffffull)
+    if (nrows >= 0xffffffffull || ncols > 0xffffffffull || nnz > kMaxEntries)
         return fail(SPAL_ERR_UNSUPPORTED,
                     "shape %llu x %llu with %llu entries does not fit 32-bit device indices",
                     (unsigned long long)nrows, (unsigned long long)ncols, (unsigned long long)nnz);

@@ -58,6 +58,10 @@ struct DeviceGuard {
 // SPAL_CACHE_BYTES, default 8 GiB).  dev_free synchronises the device first,
 // like hipFree does, so a cached block is never handed out while work that used
 // it is still in flight.  Small blocks are rounded up to a power of two.
+// Stored entries a handle accepts: entry offsets are 32-bit on the device and the kernels compute
+// `offset + a batch` (at most a few thousand entries past the end, clamped afterwards) in 32 bits.
+constexpr uint64_t kMaxEntries = 0xffffffffull - 65536ull;
+
 hipError_t dev_alloc(void **ptr, size_t bytes);   // on the current device
 hipError_t dev_free(void *ptr);                   // on the current device; NULL is fine
 void dev_cache_trim();                            // releases every cached block
