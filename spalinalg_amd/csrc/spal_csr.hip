@@ -40,9 +40,13 @@ struct DevCache {
     std::vector<Block> free_blocks;
     std::vector<Block> live;      // blocks handed out by dev_alloc (for their size at free time)
     size_t cached_bytes = 0;
+    // default: a quarter of the device's memory (72 GB of 288), at least 8 GiB -- the 27 GB of output an
+    // assembly of 2.3e9 triplets allocates must be reusable or every call pays hipMalloc / hipFree again
     size_t limit = [] {
         if (const char *e = getenv("SPAL_CACHE_BYTES")) return (size_t)strtoull(e, nullptr, 10);
-        return (size_t)8 << 30;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = 0; }
+        return std::max((size_t)8 << 30, total_b / 4);
     }();
     ~DevCache() {}  // the process is going away; the driver reclaims device memory
 };

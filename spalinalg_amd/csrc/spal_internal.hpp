@@ -54,7 +54,7 @@ struct DeviceGuard {
 // hipMalloc / hipFree of hundreds of MB cost milliseconds (and on some hosts
 // tens of ms) each; a handle that is assembled, used and destroyed in a loop
 // would pay that every time.  dev_alloc / dev_free keep a small per-device
-// cache of large freed blocks (exact-fit-ish reuse, bounded by
+// cache of freed blocks (exact-fit-ish reuse, bounded by a quarter of the device memory or
 // SPAL_CACHE_BYTES, default 8 GiB).  dev_free synchronises the device first,
 // like hipFree does, so a cached block is never handed out while work that used
 // it is still in flight.  Small blocks are rounded up to a power of two.
