@@ -54,8 +54,8 @@ struct DeviceGuard {
 // hipMalloc / hipFree of hundreds of MB cost milliseconds (and on some hosts
 // tens of ms) each; a handle that is assembled, used and destroyed in a loop
 // would pay that every time.  dev_alloc / dev_free keep a small per-device
-// cache of freed blocks (exact-fit-ish reuse, bounded by a quarter of the device memory or
-// SPAL_CACHE_BYTES, default 8 GiB).  dev_free synchronises the device first,
+// cache of freed blocks (exact-fit-ish reuse, bounded by SPAL_CACHE_BYTES, default a quarter
+// of the device's memory, at least 8 GiB).  dev_free synchronises the device first,
 // like hipFree does, so a cached block is never handed out while work that used
 // it is still in flight.  Small blocks are rounded up to a power of two.
 // Stored entries a handle accepts: entry offsets are 32-bit on the device and the kernels compute
