@@ -34,6 +34,7 @@ for s in "$@"; do
             step 400 pmc2.log rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU --output-format csv -d gpurun_out/pmc2 -o p -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline
             step 400 pmc3.log rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc3 -o p -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline
             ;;
+    hugecsc) step 1000 lab_huge_csc.log python tools/lab_huge_csc.py ${HUGE_ARGS:-} ;;
     hugecoo) step 1000 lab_huge_coo.log python tools/lab_huge_coo.py ${HUGE_ARGS:-} ;;
     huge)   step 1000 lab_huge.log python tools/lab_huge.py ${HUGE_ARGS:-} ;;
     fem)    step 600 lab_fem.log python tools/lab_fem.py ;;
