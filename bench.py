@@ -41,9 +41,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
+    ap.add_argument("--config", type=int, default=3, choices=[1, 2, 3, 4, 5],
                     help="BASELINE config: 3 = CSR 10Mx10M/140M nnz (headline, the default line), "
-                         "2 = CSR 1Mx1M/14M nnz, 4 = CSC scatter 1Mx1M, 5 = COO->CSR assembly 50M entries")
+                         "2 = CSR 1Mx1M/14M nnz, 4 = CSC scatter 1Mx1M, 5 = COO->CSR assembly 50M entries, "
+                         "1 = the reference's CPU-sized case (10k x 10k, 100k triplets) end to end")
     ap.add_argument("--dist", default="banded", choices=["banded", "uniform"],
                     help="column distribution: banded W=4096 (headline) or uniform (stress row)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
@@ -183,6 +184,55 @@ def bench_csc(args):
     print(json.dumps(out))
 
 
+def bench_small(args):
+    """BASELINE config 1 (the reference's own CPU-runnable case): 10k x 10k, 100k random triplets ->
+    CsrMatrix on the device -> SpMV, checked in full against the oracle (assembly bit-exact)."""
+    import torch
+    import spalinalg_amd as sp
+    import oracle  # the checker and the CPU baseline of this tiny case
+    cfg = sp.synth.CONFIGS[1]
+    nr, nc, length = cfg["nrows"], cfg["ncols"], cfg["length"]
+    np_dt = np.float64 if args.dtype == "f64" else np.float32
+    r, c, v = sp.synth.coo(nr, nc, length, sp.synth.matrix_seed(1), dtype=np_dt)
+    d = sp.CooMatrix.with_triplets(nr, nc, r, c, v).upload()
+    csr = d.assemble_csr()
+    x = torch.from_numpy(sp.synth.vector(nc, dtype=np_dt)).cuda()
+    y = torch.empty(nr, dtype=x.dtype, device="cuda")
+    ms = timed(lambda: csr.spmv_torch(x, out=y), args.steps, args.warmup, torch)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        d.assemble_csr().close()
+    torch.cuda.synchronize()
+    asm_ms = (time.perf_counter() - t0) * 1e3 / 20
+    rp, ci, va = csr.download()
+    p, i, w = oracle.coo_to_csr(nr, nc, r, c, v)
+    bits = np.uint64 if np_dt == np.float64 else np.uint32
+    exact = bool(np.array_equal(rp, p) and np.array_equal(ci, i) and np.array_equal(va.view(bits), w.view(bits)))
+    xh = x.cpu().numpy()
+    t0, passes = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 2.0:
+        yh = oracle.csr_spmv(p, i, w, xh)
+        passes += 1
+    el = time.perf_counter() - t0
+    nnz = int(rp[-1])
+    B = sp.synth.spmv_bytes(nnz, nr, nr, nc, np.dtype(np_dt).itemsize)
+    out = base_record(args, f"CSR SpMV GFLOP/s ({args.dtype}, config 1)", sp.synth.spmv_flops(nnz) / (ms * 1e-3) / 1e9,
+                      "GFLOP/s", ms, f"CooMatrix {length} triplets -> CsrMatrix {nr}x{nc} ({nnz} stored) -> y=A*x "
+                      f"(BASELINE configs[0], the reference's CPU-sized case; launch-bound on a GPU), single GPU",
+                      csr.describe())
+    out["roofline"] = {"bound": "hbm", "achieved": round(B / (ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
+                       "frac": round(B / (ms * 1e-3) / 8e12, 5), "traffic": None, "kernel": "csr_spmv_" + csr.describe()["kernel"],
+                       "kernel_ms": round(ms, 6), "algorithmic_bytes_per_launch": B,
+                       "note": "1.4 MB of work: the launch itself is the cost"}
+    out["assembly_ms"] = round(asm_ms, 4)
+    out["assembly_bit_exact_vs_oracle"] = exact
+    out["cpu_baseline"] = {"value": round(sp.synth.spmv_flops(nnz) * passes / el / 1e9, 4), "unit": "GFLOP/s", "cores": 1,
+                           "kind": "port", "sample": f"{passes} passes of the same matrix in {el:.1f} s, 1 thread",
+                           "gpu_agrees_with_cpu": bool(np.allclose(y.cpu().numpy(), yh, rtol=1e-10 if np_dt == np.float64 else 1e-4,
+                                                                   atol=1e-12 if np_dt == np.float64 else 1e-5))}
+    print(json.dumps(out))
+
+
 def bench_coo(args):
     """BASELINE config 5: CooMatrix -> CsrMatrix on the device, 50M random triplets
     (+1 % duplicates, +0.1 % cancelling pairs) into 5M x 5M, then one SpMV on the result."""
@@ -260,14 +310,14 @@ def base_record(args, metric, value, unit, ms, workload, plan):
 
 def main():
     args = parse()
-    if args.config in (4, 5):
+    if args.config in (1, 4, 5):
         if args.gpus != 1 or int(os.environ.get("WORLD_SIZE", "1")) != 1:
-            sys.exit("configs 4 and 5 are single-GPU (BASELINE.json); only the CSR configs shard over GPUs")
+            sys.exit("configs 1, 4 and 5 are single-GPU (BASELINE.json); only the CSR configs shard over GPUs")
         import torch
         import spalinalg_amd as sp
         if not torch.cuda.is_available() or sp.device_count() < 1:
             sys.exit("bench.py needs a GPU: libspal_hip has no CPU fallback")
-        return bench_csc(args) if args.config == 4 else bench_coo(args)
+        return bench_small(args) if args.config == 1 else bench_csc(args) if args.config == 4 else bench_coo(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -57,6 +57,7 @@ for s in "$@"; do
     rehearse2e) step 600 rehearse2e.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29634 bench.py --gpus 2 --steps 5 --warmup 2 --backend gloo --same-device --config 2 --extras ;;
     rehearse4e) step 600 rehearse4e.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29635 bench.py --gpus 4 --steps 5 --warmup 2 --backend gloo --same-device --config 2 ;;
     rehearse1) step 600 rehearse1.log python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29633 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline ;;
+    bench1) step 400 bench1.log python bench.py --config 1 ;;
     bench4) step 400 bench4.log python bench.py --config 4 ;;
     bench5) step 600 bench5.log python bench.py --config 5 ;;
     bench2) step 400 bench2.log python bench.py --config 2 ;;
