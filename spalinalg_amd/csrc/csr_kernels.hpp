@@ -657,11 +657,11 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     if (d.z == kModeVectorLds) {
         stage_window<T, kStreamBlock>(xw, x, d.x, d.y);
         __syncthreads();
-        vector_rows<T, L, U, true, USE_DPP, kStreamBlock>(rowptr, colind, vals, x, xw, y, row0, row1,
+        vector_rows<T, L, U, true, USE_DPP, kStreamBlock, 4>(rowptr, colind, vals, x, xw, y, row0, row1,
                                                           d.x, last_nz);
         return;
     }
-    vector_rows<T, L, U, false, USE_DPP, kStreamBlock>(rowptr, colind, vals, x, nullptr, y, row0, row1,
+    vector_rows<T, L, U, false, USE_DPP, kStreamBlock, 4>(rowptr, colind, vals, x, nullptr, y, row0, row1,
                                                        0u, last_nz);
 }
 
@@ -765,10 +765,10 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
             if (d.z == kModeVectorLds) {
                 stage_window<T, kStreamBlock>(xw, x, d.x, d.y);
                 __syncthreads();
-                vector_rows<T, L, U, true, USE_DPP, kStreamBlock>(rowptr, colind, vals, x, xw, y, row0,
+                vector_rows<T, L, U, true, USE_DPP, kStreamBlock, 4>(rowptr, colind, vals, x, xw, y, row0,
                                                                   row1, d.x, last_nz);
             } else {
-                vector_rows<T, L, U, false, USE_DPP, kStreamBlock>(rowptr, colind, vals, x, nullptr, y,
+                vector_rows<T, L, U, false, USE_DPP, kStreamBlock, 4>(rowptr, colind, vals, x, nullptr, y,
                                                                    row0, row1, 0u, last_nz);
             }
         }

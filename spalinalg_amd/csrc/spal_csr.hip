@@ -431,11 +431,13 @@ static hipError_t launch_vec_unroll(const spal_csr *a, const void *x, void *y, h
 // stream kernel; its vector fallback for non-streamable super-tiles uses U = 2
 template <typename T, int TPW, int RPT>
 static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, hipStream_t st) {
-    constexpr int L = 16;  // lanes per row of the in-kernel vector fallback (any value is correct)
+    // the in-kernel vector fallback takes super-tiles with a tile of more than 1024 entries, i.e. with heavy
+    // rows: a wave per row, four (colind, value) pairs per lane in flight (any geometry is correct)
+    constexpr int L = 64;
     const CsrPlan &p = a->plan;
     const uint32_t per_xcd = (p.nblocks + 7) / 8;
     const size_t lds = ((size_t)kStreamWaves * kStreamTileNnz + p.lds_entries) * sizeof(T);
-    auto kern = csr_spmv_stream<T, L, 2, true, TPW, RPT>;
+    auto kern = csr_spmv_stream<T, L, 1, true, TPW, RPT>;
     static std::atomic<uint64_t> configured{0};
     hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
     if (e != hipSuccess) return e;
@@ -449,7 +451,7 @@ static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, h
 // persistent form: 2 workgroups per CU, contiguous chunks of each XCD's run
 template <typename T, int RPT>
 static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, void *y, hipStream_t st) {
-    constexpr int L = 16;
+    constexpr int L = 64;
     const CsrPlan &p = a->plan;
     const uint32_t per_xcd = (p.nblocks + 7) / 8;
     const size_t lds = ((size_t)kStreamWaves * kStreamTileNnz + p.lds_entries) * sizeof(T);
@@ -463,7 +465,7 @@ static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, voi
     const uint32_t slots = (uint32_t)std::max(1, grid / 8);                   // workgroups per XCD
     const uint32_t chunk = (per_xcd + slots - 1) / slots;
     const uint32_t used = (per_xcd + chunk - 1) / chunk;                      // non-empty slots
-    auto kern = csr_spmv_stream_persistent<T, L, 2, true, 4, RPT>;
+    auto kern = csr_spmv_stream_persistent<T, L, 1, true, 4, RPT>;
     static std::atomic<uint64_t> configured{0};
     hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
     if (e != hipSuccess) return e;
@@ -660,9 +662,12 @@ int csr_plan_build(spal_csr *a) {
     // vector kernel geometry, from measurements (tools/lab_ab.py): one lane per entry
     // up to 64 entries per row; longer rows loop in batches of 4 L entries per
     // lane group, which 16 lanes per row keep busiest (128/row: 65 %, L = 64: 38 %)
-    if (!p.user_lanes) p.lanes_per_row = mean > 64.0 ? 16 : pick_lanes(mean);
-    p.long_rows = mean > 64.0 ? 1 : 0;
-    if (!p.user_unroll) p.unroll = (mean > 64.0 && mean <= 160.0) ? 2 : 4;
+    // rows longer than a wave (tools/lab_longrows.py, 70 ... 1500 entries per row): a whole wave per row,
+    // one row group in flight, and few rows per workgroup (below) beat 16 lanes per row everywhere
+    // (100/row 56 % against 37 %, 400/row 67 % against 17 %, 1500/row 54 % against 23 %)
+    if (!p.user_lanes) p.lanes_per_row = mean > 85.0 ? 64 : mean > 64.0 ? 32 : pick_lanes(mean);
+    p.long_rows = mean > 64.0 ? 1 : 0;   // (only the 16-lane instantiation has the batched rest-of-row loop)
+    if (!p.user_unroll) p.unroll = mean > 64.0 ? 1 : 4;
     if (!p.user_threads) p.threads = 1024;
     if (a->d_desc) {
         SPAL_HIP_TRY(dev_free(a->d_desc));
@@ -757,8 +762,18 @@ int csr_plan_build(spal_csr *a) {
     const uint32_t budget = kLdsBudgetBytes / (uint32_t)a->elem_size;  // elements
     const uint32_t cand_all[] = {4096, 2048, 1024, 512};
     std::vector<uint32_t> cands;
-    if (p.user_rows_per_block) cands.push_back((uint32_t)p.rows_per_block);
-    else cands.assign(cand_all, cand_all + 4);
+    if (p.user_rows_per_block) {
+        cands.push_back((uint32_t)p.rows_per_block);
+    } else if (mean > 64.0) {
+        // long rows: about 100 000 entries per workgroup (1024 rows at 100/row ... 64 rows at 1500/row), so
+        // that there are workgroups enough for 256 CUs -- 4096 rows of 400 entries were 61 workgroups
+        uint32_t r0 = 1024;
+        while (r0 > 64 && (double)r0 * mean > 131072.0) r0 >>= 1;
+        cands.push_back(r0);
+        if (r0 > 64) cands.push_back(r0 >> 1);
+    } else {
+        cands.assign(cand_all, cand_all + 4);
+    }
 
     std::vector<uint4> best_desc;
     uint32_t best_R = 0, best_cap = 0;

@@ -37,6 +37,8 @@ for s in "$@"; do
     hugecsc) step 1000 lab_huge_csc.log python tools/lab_huge_csc.py ${HUGE_ARGS:-} ;;
     hugecoo) step 1000 lab_huge_coo.log python tools/lab_huge_coo.py ${HUGE_ARGS:-} ;;
     huge)   step 1000 lab_huge.log python tools/lab_huge.py ${HUGE_ARGS:-} ;;
+    longrows) step 900 lab_longrows.log python tools/lab_longrows.py ;;
+    zoo)    step 900 lab_zoo.log python tools/lab_zoo.py ;;
     fem)    step 600 lab_fem.log python tools/lab_fem.py ;;
     small)  step 600 lab_small.log python tools/lab_small.py ${SMALL_ARGS:-} ;;
     align)  step 600 lab_align.log python tools/lab_align.py ${ALIGN_ARGS:-} ;;

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Long rows (100 / 400 per row) through the vector kernel's knobs (development tool)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import spalinalg_amd as sp  # noqa: E402
+from tools.lab_zoo import from_lens, timeit  # noqa: E402
+
+
+def main():
+    rng = np.random.default_rng(5)
+    for per, n, W in ((70, 1_400_000, 2048), (100, 1_000_000, 2048), (200, 500_000, 4096), (400, 250_000, 4096), (1500, 64_000, 8192)):
+        rp, ci, va = from_lens(np.full(n, per, np.int64), lambda r, p, g: np.clip(r - W // 2 + g.integers(0, W, r.size), 0, n - 1), rng)
+        nnz = int(rp[-1])
+        B = sp.synth.spmv_bytes(nnz, n, n, n, 8)
+        dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+        x = torch.from_numpy(sp.synth.vector(n)).cuda()
+        y = torch.empty(n, dtype=torch.float64, device="cuda")
+        t = timeit(lambda: dev.spmv_torch(x, out=y))
+        d = dev.describe()
+        print(f"{per}/row n={n} nnz={nnz}: auto {t*1e3:8.1f} us = {100*B/(t*1e-3)/8e12:5.1f} %  [{d['kernel']} L={d['lanes_per_row']} U={d['unroll']} R={d['rows_per_block']} lds={d['lds_x']}]", flush=True)
+        for L in ():
+            for U in (1, 2, 4):
+                for R in (64, 128, 256, 512, 1024):
+                    try:
+                        dev.set_option("kernel", 1)
+                        dev.set_option("lanes_per_row", L)
+                        dev.set_option("unroll", U)
+                        dev.set_option("rows_per_block", R)
+                    except Exception as exc:  # noqa: BLE001
+                        print("   ", L, U, R, "refused:", exc)
+                        continue
+                    t = timeit(lambda: dev.spmv_torch(x, out=y), iters=10)
+                    print(f"    L={L:2d} U={U} R={R:4d}: {t*1e3:8.1f} us = {100*B/(t*1e-3)/8e12:5.1f} %", flush=True)
+
+
+if __name__ == "__main__":
+    main()
