@@ -14,6 +14,7 @@
 //    one L2;
 //  - enough independent loads in flight per wave (U row groups per iteration).
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -399,6 +400,27 @@ template <typename T> struct Pair;
 template <> struct Pair<double> { using type = __attribute__((ext_vector_type(2))) double; };
 template <> struct Pair<float> { using type = __attribute__((ext_vector_type(2))) float; };
 
+// A tile whose rows hold more than the strip's 1024 entries (a heavy row among light ones) is not
+// streamed: the stream kernels skip it and csr_spmv_overflow, launched right after them over the
+// plan's list of such tiles, computes its rows -- a wave per row.  The other tiles of the
+// super-tile stream as usual.  (Handing the whole super-tile to the vector path made it the
+// launch's straggler: one row of 3000 entries every 20 super-tiles cost +50 ... +130 %; running
+// the vector rows inside the stream kernels cost their hot loop 6 ... 10 % in registers.)
+// entries of the tile [b, e) as the strip sees them (from the even start)
+__device__ __forceinline__ bool stream_tile_overflows(uint32_t b, uint32_t e) {
+    return e - (b & ~1u) > (uint32_t)kStreamTileNnz;
+}
+// bit k set: the wave's tile k (rows wrow + k*RPT ...) exists and is oversized; wave-uniform.
+// Zero for almost every wave, which then runs the tile loop compiled without the test.
+template <int TPW, int RPT>
+__device__ __forceinline__ uint32_t stream_overflow_mask(const uint32_t (&tb)[TPW + 1], uint32_t wrow,
+                                                         uint32_t row1) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < TPW; ++k)
+        if (wrow + k * (uint32_t)RPT < row1 && stream_tile_overflows(tb[k], tb[k + 1])) m |= 1u << k;
+    return m;
+}
 template <typename T>
 struct StreamTile {
     typename Pair<T>::type v[kStreamSteps];
@@ -582,17 +604,24 @@ __device__ __forceinline__ void stream_global_super_tile(const uint32_t *__restr
     for (int k = 0; k <= TPW; ++k) tb[k] = __builtin_amdgcn_readlane(tb_lane, k);
     StreamTileG<T> cur, nxt;
     stream_load_g<T, RPT>(cur, rowptr, colind, vals, wrow, row1, tb[0], tb[1], lane);
+    const uint32_t ovmask = stream_overflow_mask<TPW, RPT>(tb, wrow, row1);
+    auto tiles = [&](auto ov) {
+        constexpr bool OV = decltype(ov)::value;
 #pragma unroll
-    for (int k = 0; k < TPW; ++k) {
-        const uint32_t r0 = wrow + k * (uint32_t)RPT;
-        if (r0 >= row1) break;  // wave-uniform
-        const uint32_t rn = r0 + (uint32_t)RPT;
-        const bool more = (k + 1 < TPW) && rn < row1;
-        if (more) stream_load_g<T, RPT>(nxt, rowptr, colind, vals, rn, row1, tb[k + 1],
-                                        tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
-        stream_compute_g<T, RPT>(cur, x, ncols - 1, prod, y, r0, row1, lane, nt_store);
-        if (more) cur = nxt;
-    }
+        for (int k = 0; k < TPW; ++k) {
+            const uint32_t r0 = wrow + k * (uint32_t)RPT;
+            if (r0 >= row1) break;  // wave-uniform
+            const uint32_t rn = r0 + (uint32_t)RPT;
+            const bool more = (k + 1 < TPW) && rn < row1;
+            if (more) stream_load_g<T, RPT>(nxt, rowptr, colind, vals, rn, row1, tb[k + 1],
+                                            tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
+            if (!OV || !((ovmask >> k) & 1u))  // oversized tiles: csr_spmv_overflow
+                stream_compute_g<T, RPT>(cur, x, ncols - 1, prod, y, r0, row1, lane, nt_store);
+            if (more) cur = nxt;
+        }
+    };
+    if (ovmask == 0u) tiles(std::false_type{});
+    else tiles(std::true_type{});
 }
 
 // desc[b] = Stream: {first page id or offset into pages[], number of pages, mode, 1 if the pages are a
@@ -635,16 +664,23 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
         __syncthreads();
         if (!has0) return;
         const uint32_t wmax = d.y * kPageCols - 1u;
+        const uint32_t ovmask = stream_overflow_mask<TPW, RPT>(tb, wrow, row1);
+        auto tiles = [&](auto ov) {
+            constexpr bool OV = decltype(ov)::value;
 #pragma unroll
-        for (int k = 0; k < TPW; ++k) {
-            const uint32_t r0 = wrow + k * (uint32_t)RPT;
-            if (r0 >= row1) break;  // wave-uniform
-            const uint32_t rn = r0 + (uint32_t)RPT;
-            const bool more = (k + 1 < TPW) && rn < row1;
-            if (more) stream_load<T, RPT>(nxt, rowptr, col16, vals, rn, row1, tb[k + 1], tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
-            stream_compute<T, RPT>(cur, xw, wmax, prod, y, r0, row1, lane, nt_store);
-            if (more) cur = nxt;
-        }
+            for (int k = 0; k < TPW; ++k) {
+                const uint32_t r0 = wrow + k * (uint32_t)RPT;
+                if (r0 >= row1) break;  // wave-uniform
+                const uint32_t rn = r0 + (uint32_t)RPT;
+                const bool more = (k + 1 < TPW) && rn < row1;
+                if (more) stream_load<T, RPT>(nxt, rowptr, col16, vals, rn, row1, tb[k + 1], tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
+                if (!OV || !((ovmask >> k) & 1u))  // oversized tiles: csr_spmv_overflow
+                    stream_compute<T, RPT>(cur, xw, wmax, prod, y, r0, row1, lane, nt_store);
+                if (more) cur = nxt;
+            }
+        };
+        if (ovmask == 0u) tiles(std::false_type{});
+        else tiles(std::true_type{});
         return;
     }
     if (d.z == kModeStreamGlobal) {
@@ -730,29 +766,36 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
             const uint32_t wmax = d.y * kPageCols - 1u;
             bool fetched_next = false;
             if (has0) {
+                const uint32_t ovmask = stream_overflow_mask<TPW, RPT>(tb, wrow, row1);
+                auto tiles = [&](auto ov) {
+                    constexpr bool OV = decltype(ov)::value;
 #pragma unroll
-                for (int k = 0; k < TPW; ++k) {
-                    const uint32_t r0 = wrow + k * (uint32_t)RPT;
-                    if (r0 >= row1) break;  // wave-uniform
-                    const uint32_t rn = r0 + (uint32_t)RPT;
-                    const bool more = (k + 1 < TPW) && rn < row1;
-                    if (more) {
-                        stream_load<T, RPT>(nxt, rowptr, col16, vals, rn, row1, tb[k + 1],
-                                       tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
-                    } else if (next_stream) {
-                        // last tile of this super-tile: start on the next one's first tile
-                        const uint32_t nrow0 = (s + 1) * kRows, nrow1 = min(nrow0 + kRows, nrows);
-                        const uint32_t nwrow = nrow0 + wave * (TPW * (uint32_t)RPT);
-                        if (nwrow < nrow1) {
-                            const uint32_t b0 = __builtin_amdgcn_readlane(tbl_next, 0);
-                            const uint32_t b1 = __builtin_amdgcn_readlane(tbl_next, 1);
-                            stream_load<T, RPT>(nxt, rowptr, col16, vals, nwrow, nrow1, b0, b1, lane);
-                            fetched_next = true;
+                    for (int k = 0; k < TPW; ++k) {
+                        const uint32_t r0 = wrow + k * (uint32_t)RPT;
+                        if (r0 >= row1) break;  // wave-uniform
+                        const uint32_t rn = r0 + (uint32_t)RPT;
+                        const bool more = (k + 1 < TPW) && rn < row1;
+                        if (more) {
+                            stream_load<T, RPT>(nxt, rowptr, col16, vals, rn, row1, tb[k + 1],
+                                           tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
+                        } else if (next_stream) {
+                            // last tile of this super-tile: start on the next one's first tile
+                            const uint32_t nrow0 = (s + 1) * kRows, nrow1 = min(nrow0 + kRows, nrows);
+                            const uint32_t nwrow = nrow0 + wave * (TPW * (uint32_t)RPT);
+                            if (nwrow < nrow1) {
+                                const uint32_t b0 = __builtin_amdgcn_readlane(tbl_next, 0);
+                                const uint32_t b1 = __builtin_amdgcn_readlane(tbl_next, 1);
+                                stream_load<T, RPT>(nxt, rowptr, col16, vals, nwrow, nrow1, b0, b1, lane);
+                                fetched_next = true;
+                            }
                         }
+                        if (!OV || !((ovmask >> k) & 1u))  // oversized tiles: csr_spmv_overflow
+                            stream_compute<T, RPT>(cur, xw, wmax, prod, y, r0, row1, lane, nt_store);
+                        if (more || fetched_next) cur = nxt;
                     }
-                    stream_compute<T, RPT>(cur, xw, wmax, prod, y, r0, row1, lane, nt_store);
-                    if (more || fetched_next) cur = nxt;
-                }
+                };
+                if (ovmask == 0u) tiles(std::false_type{});
+                else tiles(std::true_type{});
             }
             cur_valid = fetched_next;
         } else if (d.z == kModeStreamGlobal) {
@@ -773,6 +816,101 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
             }
         }
         tbl = tbl_next;
+    }
+}
+
+// ---- the oversized tiles of a stream plan ----------------------------------------------
+// tiles[i] = first row of a tile of rpt <= 64 rows that holds more than 1024 entries: typically one or
+// a few heavy rows among light ones.  A workgroup per tile; every wave reads the tile's row bounds
+// (a row per lane) and sorts the rows into three classes by length:
+//   light  (<= 128 entries): 8 lanes per row, 32 rows per trip;
+//   medium (<= 1024):        a wave per row, the four waves taking turns;
+//   heavy:                   the whole workgroup per row, partial sums of the four waves folded in LDS.
+// Each class keeps four (column, value) pairs per lane in flight; x is gathered from global memory.
+// (A wave per row for every row: 156 000 mostly idle waves cost 50 us for 2400 such tiles; 16 lanes per row:
+// a row of 3000 entries is 47 dependent trips.)
+constexpr uint32_t kOverflowLight = 128, kOverflowMedium = 1024;
+
+template <typename T, uint32_t S>   // partial sum of entries b + s, b + s + S, ... < e
+__device__ __forceinline__ T strided_row_sum(const uint32_t *__restrict__ colind, const T *__restrict__ vals,
+                                             const T *__restrict__ x, uint32_t b, uint32_t e, uint32_t s) {
+    T acc = T(0);
+    uint32_t k = b + s;
+    for (; k + 3 * S < e; k += 4 * S) {
+        const uint32_t c0 = __builtin_nontemporal_load(colind + k), c1 = __builtin_nontemporal_load(colind + k + S),
+                       c2 = __builtin_nontemporal_load(colind + k + 2 * S),
+                       c3 = __builtin_nontemporal_load(colind + k + 3 * S);
+        const T v0 = __builtin_nontemporal_load(vals + k), v1 = __builtin_nontemporal_load(vals + k + S),
+                v2 = __builtin_nontemporal_load(vals + k + 2 * S), v3 = __builtin_nontemporal_load(vals + k + 3 * S);
+        const T x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+        acc += v0 * x0;
+        acc += v1 * x1;
+        acc += v2 * x2;
+        acc += v3 * x3;
+    }
+    for (; k < e; k += S) acc += __builtin_nontemporal_load(vals + k) * x[__builtin_nontemporal_load(colind + k)];
+    return acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kStreamBlock) void csr_spmv_overflow(
+    const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind, const T *__restrict__ vals,
+    const T *__restrict__ x, T *__restrict__ y, const uint32_t *__restrict__ tiles, uint32_t ntiles,
+    uint32_t rpt, uint32_t nrows) {
+    __shared__ T part[kStreamWaves];
+    const uint32_t t = blockIdx.x;
+    if (t >= ntiles) return;
+    const uint32_t r0 = tiles[t];
+    const uint32_t r1 = min(r0 + rpt, nrows);
+    const uint32_t nrow = r1 - r0;                       // <= 64
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    // lane i: bounds of row r0 + i (lanes past the tile: an empty row)
+    const uint32_t b_l = rowptr[min(r0 + lane, r1)];
+    const uint32_t e_l = rowptr[min(r0 + lane + 1, r1)];
+    const uint32_t len_l = e_l - b_l;
+    const uint64_t medium = __ballot(len_l > kOverflowLight && len_l <= kOverflowMedium);
+    uint64_t heavy = __ballot(len_l > kOverflowMedium);
+
+    // light rows: 8 lanes per row
+    {
+        const uint32_t g = threadIdx.x >> 3, s = threadIdx.x & 7u;   // 32 row groups
+        for (uint32_t i = g; i < 64u; i += 32u) {
+            const uint32_t b = __shfl(b_l, (int)i), e = __shfl(e_l, (int)i);
+            T acc = T(0);
+            if (e - b <= kOverflowLight) acc = strided_row_sum<T, 8>(colind, vals, x, b, e, s);
+            acc += __shfl_xor(acc, 4);
+            acc += __shfl_xor(acc, 2);
+            acc += __shfl_xor(acc, 1);
+            if (s == 0 && i < nrow && e - b <= kOverflowLight) y[r0 + i] = acc;
+        }
+    }
+    // medium rows: a wave per row
+    {
+        uint64_t m = medium;
+        uint32_t turn = 0;
+        while (m) {   // wave-uniform
+            const uint32_t i = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            if ((turn++ & (kStreamWaves - 1)) != wave) continue;
+            const uint32_t b = __shfl(b_l, (int)i), e = __shfl(e_l, (int)i);
+            T acc = strided_row_sum<T, kWave>(colind, vals, x, b, e, lane);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0) y[r0 + i] = acc;
+        }
+    }
+    // heavy rows: the workgroup per row
+    while (heavy) {   // block-uniform
+        const uint32_t i = (uint32_t)__builtin_ctzll(heavy);
+        heavy &= heavy - 1;
+        const uint32_t b = __shfl(b_l, (int)i), e = __shfl(e_l, (int)i);
+        T acc = strided_row_sum<T, kStreamBlock>(colind, vals, x, b, e, threadIdx.x);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) part[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) y[r0 + i] = (part[0] + part[1]) + (part[2] + part[3]);
+        __syncthreads();
     }
 }
 

@@ -213,21 +213,39 @@ static constexpr uint32_t kStreamWindowBytes = 48 * 1024;
 // (band of 8192 columns, f64: 463 / 392 us against 722 us)
 static constexpr uint32_t kStreamBigWindowBytes = 120 * 1024;
 
-// One thread per super-tile: every 64-row tile must fit the product strip.
+// One thread per super-tile: over[b] = how many of its tiles hold more entries than the product strip
+// (those tiles are not streamed: csr_spmv_overflow computes their rows).
 __global__ __launch_bounds__(256) void csr_stream_check(const uint32_t *__restrict__ rowptr,
                                                         uint32_t nrows, uint32_t nblocks,
                                                         uint32_t R, uint32_t rpt,
-                                                        uint32_t *__restrict__ ok) {
+                                                        uint32_t *__restrict__ over) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nblocks) return;
     const uint32_t row0 = b * R, row1 = min(row0 + R, nrows);
-    uint32_t good = 1;
+    uint32_t bad = 0;
     for (uint32_t r0 = row0; r0 < row1; r0 += rpt) {
         const uint32_t rl = min(r0 + rpt, row1);
         const uint32_t n = rowptr[rl] - (rowptr[r0] & ~1u);
-        if (n > (uint32_t)kStreamTileNnz) good = 0;
+        if (n > (uint32_t)kStreamTileNnz) ++bad;
     }
-    ok[b] = good;
+    over[b] = bad;
+}
+
+// Plan time: the first rows of the oversized tiles of super-tiles in a stream mode, appended in any order.
+__global__ __launch_bounds__(256) void csr_overflow_tiles(const uint32_t *__restrict__ rowptr,
+                                                          const uint4 *__restrict__ desc, uint32_t nrows,
+                                                          uint32_t R, uint32_t rpt, uint32_t cap,
+                                                          uint32_t *__restrict__ count,
+                                                          uint32_t *__restrict__ tiles) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t r0 = i * rpt;
+    if (r0 >= nrows) return;
+    const uint32_t mode = desc[r0 / R].z;
+    if (mode != kModeStream && mode != kModeStreamGlobal) return;
+    const uint32_t r1 = (uint32_t)min((uint64_t)r0 + rpt, (uint64_t)min((r0 / R + 1) * R, (uint64_t)nrows));
+    if (!stream_tile_overflows(rowptr[r0], rowptr[r1])) return;
+    const uint32_t at = atomicAdd(count, 1u);
+    if (at < cap) tiles[at] = (uint32_t)r0;
 }
 
 // ---- the pages a super-tile's rows touch ----------------------------------------------
@@ -476,8 +494,27 @@ static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, voi
     return hipGetLastError();
 }
 
+// rows of the tiles the stream kernels skipped (more than 1024 entries in one tile)
+template <typename T>
+static hipError_t launch_overflow(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    hipLaunchKernelGGL(csr_spmv_overflow<T>, dim3(a->n_ovtiles), dim3(kStreamBlock), 0, st, a->d_rowptr,
+                       a->d_colind, (const T *)a->d_values, (const T *)x, (T *)y, a->d_ovtiles + 1,
+                       a->n_ovtiles, (uint32_t)a->plan.rows_per_tile, (uint32_t)a->nrows);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_stream_main(const spal_csr *a, const void *x, void *y, hipStream_t st);
+
 template <typename T>
 static hipError_t launch_stream(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    hipError_t e = launch_stream_main<T>(a, x, y, st);
+    if (e == hipSuccess && a->n_ovtiles) e = launch_overflow<T>(a, x, y, st);
+    return e;
+}
+
+template <typename T>
+static hipError_t launch_stream_main(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     const CsrPlan &p = a->plan;
     if (p.tiles_per_wave == 8) return launch_stream_tpw<T, 8, 64>(a, x, y, st);  // (64-row tiles only)
     switch (p.rows_per_tile) {
@@ -562,8 +599,9 @@ static int block_windows(spal_csr *a, uint32_t R, std::vector<uint2> &win) {
 // Stream plan: super-tiles of R rows; returns the fraction of rows
 // that can be streamed and fills `desc`.
 static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4> &desc, uint32_t &cap,
-                       double &frac, uint32_t **out_pages) {
+                       double &frac, uint32_t **out_pages, uint32_t &n_over) {
     *out_pages = nullptr;
+    n_over = 0;
     const uint32_t nb = (uint32_t)((a->nrows + R - 1) / R);
     // pages of 256 columns that fit the LDS budget: 24 (f64) / 48 (f32)
     // page budgets: `small` keeps two workgroups per CU, `page_cap` (<= 64: page ids travel in a wave's lanes) one
@@ -588,9 +626,9 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
     }
     hipLaunchKernelGGL(csr_block_pages, dim3(nb), dim3(256), 0, a->stream, a->d_rowptr, a->d_colind,
                        (uint32_t)a->nrows, R, page_cap, d_win, d_info, d_pages);
-    std::vector<uint32_t> ok(nb);
+    std::vector<uint32_t> over(nb);   // tiles per super-tile that do not fit the strip
     std::vector<uint4> info(nb);
-    hipError_t e = hipMemcpyAsync(ok.data(), d_ok, (size_t)nb * 4, hipMemcpyDeviceToHost, a->stream);
+    hipError_t e = hipMemcpyAsync(over.data(), d_ok, (size_t)nb * 4, hipMemcpyDeviceToHost, a->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(info.data(), d_info, (size_t)nb * sizeof(uint4), hipMemcpyDeviceToHost, a->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
@@ -609,7 +647,7 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
     } else if (page_cap > small_cap) {
         double rows_small = 0, rows_big = 0, rows_ok = 0;
         for (uint32_t b = 0; b < nb; ++b) {
-            if (!ok[b] || info[b].y == 0) continue;
+            if (info[b].y == 0) continue;
             const double rows = (double)std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
             rows_ok += rows;
             if (info[b].z != kNotPageable && info[b].z <= small_cap) rows_small += rows;
@@ -631,18 +669,18 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
             rows_stream += rows;
             continue;
         }
-        if (ok[b] && w.z != kNotPageable && w.z <= use_cap) {   // the pages its rows touch fit the LDS budget
+        if (w.z != kNotPageable && w.z <= use_cap) {   // the pages its rows touch fit the LDS budget
             desc[b] = make_uint4(w.w ? (w.x >> kPageShift) : b * page_cap, w.z, kModeStream, w.w);
             cap = std::max(cap, w.z * kPageCols);
             rows_stream += rows;
             continue;
         }
-        if (ok[b] && a->plan.stream_global) {   // tiles fit, columns too scattered for LDS: x through L2
+        if (a->plan.stream_global) {   // columns too scattered for LDS: x through L2
             desc[b] = make_uint4(0, 0, kModeStreamGlobal, 0);
             rows_stream += rows;
             continue;
         }
-        // a tile of more than 1024 entries: vector rows, x window in LDS when the span fits
+        // (stream_global switched off) vector rows, x window in LDS when the span fits
         const uint32_t cb = w.x & ~(valign - 1);
         const uint32_t len = w.y - cb;
         if (len <= budget) {
@@ -650,7 +688,19 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
             cap = std::max(cap, len);
         }
     }
-    frac = a->nrows ? (double)rows_stream / (double)a->nrows : 0.0;
+    // what the caller ranks tile heights by: the share of rows whose TILE streams (a super-tile in a stream
+    // mode still hands its oversized tiles to the vector rows)
+    {
+        uint64_t rows_tiles = 0;
+        for (uint32_t b = 0; b < nb; ++b) {
+            if (desc[b].z != kModeStream && desc[b].z != kModeStreamGlobal) continue;
+            const uint64_t rows = std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
+            rows_tiles += rows - std::min<uint64_t>(rows, (uint64_t)over[b] * rpt);
+            n_over += over[b];
+        }
+        frac = a->nrows ? (double)rows_tiles / (double)a->nrows : 0.0;
+    }
+    (void)rows_stream;
     *out_pages = d_pages;
     return SPAL_OK;
 }
@@ -698,14 +748,17 @@ int csr_plan_build(spal_csr *a) {
         double frac = 0.0, best_frac = -1.0;
         int best_rpt = rpts[0];
         uint32_t *best_pages = nullptr;
+        uint32_t n_over = 0, best_over = 0;
         if (a->d_pages) { SPAL_HIP_TRY(dev_free(a->d_pages)); a->d_pages = nullptr; }
+        if (a->d_ovtiles) { SPAL_HIP_TRY(dev_free(a->d_ovtiles)); a->d_ovtiles = nullptr; }
+        a->n_ovtiles = 0;
         for (int rpt : rpts) {
             const uint32_t R = (uint32_t)stream_rows(p.tiles_per_wave, rpt);
             uint32_t *pg = nullptr;
-            int st = stream_plan(a, R, (uint32_t)rpt, desc, cap, frac, &pg);
+            int st = stream_plan(a, R, (uint32_t)rpt, desc, cap, frac, &pg, n_over);
             if (st != SPAL_OK) { (void)dev_free(best_pages); return st; }
             if (frac > best_frac + 0.05) {  // a narrower tile must buy real coverage
-                best_frac = frac; best_rpt = rpt; best_cap = cap; best_desc.swap(desc);
+                best_frac = frac; best_rpt = rpt; best_cap = cap; best_over = n_over; best_desc.swap(desc);
                 (void)dev_free(best_pages);
                 best_pages = pg;
             } else {
@@ -749,6 +802,22 @@ int csr_plan_build(spal_csr *a) {
                 hipLaunchKernelGGL(csr_encode_col16, dim3(p.nblocks), dim3(256), 0, a->stream, a->d_rowptr,
                                    a->d_colind, a->d_desc, a->d_pages, a->d_col16, (uint32_t)a->nrows, R);
                 SPAL_HIP_TRY(hipGetLastError());
+            }
+            if (best_over) {   // the tiles the stream kernels skip: listed for csr_spmv_overflow
+                uint32_t *d_list = nullptr;   // [count][first rows]
+                SPAL_HIP_TRY(dev_alloc((void **)&d_list, ((size_t)best_over + 1) * 4));
+                a->d_ovtiles = d_list;
+                SPAL_HIP_TRY(hipMemsetAsync(d_list, 0, 4, a->stream));
+                const uint64_t ntile = (a->nrows + (uint64_t)best_rpt - 1) / (uint64_t)best_rpt;
+                hipLaunchKernelGGL(csr_overflow_tiles, dim3((uint32_t)((ntile + 255) / 256)), dim3(256), 0, a->stream,
+                                   a->d_rowptr, a->d_desc, (uint32_t)a->nrows, R, (uint32_t)best_rpt, best_over,
+                                   d_list, d_list + 1);
+                SPAL_HIP_TRY(hipGetLastError());
+                uint32_t listed = 0;
+                SPAL_HIP_TRY(hipMemcpyAsync(&listed, d_list, 4, hipMemcpyDeviceToHost, a->stream));
+                SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
+                if (listed != best_over) return SPAL_ERR_HIP;   // (cannot happen: both count the same tiles)
+                a->n_ovtiles = best_over;
             }
             SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
             return SPAL_OK;
@@ -833,6 +902,7 @@ static void csr_free(spal_csr *a) {
     (void)dev_free(a->d_desc);
     (void)dev_free(a->d_col16);
     (void)dev_free(a->d_pages);
+    (void)dev_free(a->d_ovtiles);
     (void)dev_free(a->d_x);
     (void)dev_free(a->d_y);
     stream_release(a->stream);
@@ -1210,13 +1280,14 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "\"index_bits\": %d, \"kernel\": \"%s\", \"lanes_per_row\": %d, \"unroll\": %d, "
              "\"rows_per_block\": %d, \"rows_per_tile\": %d, \"blocks\": %u, \"threads_per_block\": %d, \"lds_x\": %d, "
              "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f, "
-             "\"persistent\": %d, \"nt_store\": %d, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f]}",
+             "\"overflow_tiles\": %u, \"persistent\": %d, \"nt_store\": %d, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f]}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, p.kernel == 2 ? 16 : 32,
              p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
              p.rows_per_block, p.kernel == 2 ? p.rows_per_tile : 0, p.nblocks, p.threads, p.lds_x,
              (unsigned long long)p.lds_entries * (unsigned long long)a->elem_size, p.lds_row_fraction,
-             p.stream_row_fraction, (p.kernel == 2 && p.persistent && p.tiles_per_wave == 4) ? 1 : 0,
+             p.stream_row_fraction, p.kernel == 2 ? a->n_ovtiles : 0u,
+             (p.kernel == 2 && p.persistent && p.tiles_per_wave == 4) ? 1 : 0,
              (p.kernel == 2 && p.nt_store) ? 1 : 0, (double)a->tuned_us[0], (double)a->tuned_us[1],
              (double)a->tuned_us[2], (double)a->tuned_us[3]);
     return SPAL_OK;

@@ -130,6 +130,8 @@ struct spal_csr {
     uint32_t *d_colind = nullptr;  // nnz
     void *d_values = nullptr;      // nnz * elem_size
     uint16_t *d_col16 = nullptr;   // nnz (+pad): page slot * 256 + column inside the page, streamable super-tiles
+    uint32_t *d_ovtiles = nullptr; // [count][first rows of the n_ovtiles tiles the stream kernels skip (csr_spmv_overflow)]
+    uint32_t n_ovtiles = 0;
     uint32_t *d_pages = nullptr;   // blocks * page budget: ascending page ids of super-tiles whose pages are not one run
     uint4 *d_desc = nullptr;       // per row block: Stream {first page / offset into d_pages, pages, mode, contiguous};
                                    // VectorLds {window base column, window length, mode, 0}

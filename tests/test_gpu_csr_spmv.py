@@ -165,8 +165,8 @@ def test_long_rows_go_to_the_vector_kernel(oracle):
 
 
 def test_stream_kernel_mixed_supertiles(oracle):
-    """a few heavy rows make single super-tiles fall back to the vector path
-    inside the same launch; one wide row forces the global-gather mode."""
+    """a few heavy rows take their tiles out of the stream path (overflow kernel); one wide row forces
+    the global-gather mode."""
     rng = np.random.default_rng(4)
     n = 20_000
     rp, ci, va = sp.synth.banded_csr(n, n, 14, 2048, 13)
@@ -181,10 +181,47 @@ def test_stream_kernel_mixed_supertiles(oracle):
     x = sp.synth.vector(n)
     dev = check(oracle, rp, ci, va, x, n, kernel=2)
     d = dev.describe()
-    assert d["kernel"] == "stream" and 0.5 < d["stream_row_fraction"] < 1.0
+    assert d["kernel"] == "stream" and 0.5 < d["stream_row_fraction"] < 1.0 and d["overflow_tiles"] >= 3
     check(oracle, rp, ci, va, x, n, kernel=2, persistent=1)
     check(oracle, rp, ci, va, x, n, kernel=2, persistent=1, persistent_blocks=8)
     check(oracle, rp, ci, va, x, n, kernel=1)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("rpt", [64, 32, 16])
+def test_oversized_tiles_go_to_the_overflow_kernel(oracle, dtype, rpt):
+    """heavy rows among light ones: only their TILE leaves the stream path (a second kernel computes its
+    rows); every other row keeps the reference's summation order bit for bit."""
+    rng = np.random.default_rng(77 + rpt)
+    n = 20_011                                   # ragged last super-tile and last tile
+    rp, ci, va = sp.synth.banded_csr(n, n, 14, 2048, 21, dtype=dtype)
+    rp = rp.astype(np.int64)
+    ci, va = list(np.split(ci, rp[1:-1])), list(np.split(va, rp[1:-1]))
+    heavy = [(0, 1200), (63, 1500), (64, 1100), (700, 600), (701, 600), (4096, 3000), (4097 + rpt, 2500),
+             (9000, 5000), (n - 1, 1300)]
+    for r, k in heavy:
+        span = max(4000, 2 * k)
+        lo = max(0, min(r - span // 2, n - span))
+        ci[r] = (lo + np.sort(rng.choice(span, k, replace=False))).astype(np.uint64)
+        va[r] = rng.uniform(-1, 1, k).astype(dtype)
+    lens = np.array([c.size for c in ci])
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    ci, va = np.concatenate(ci), np.concatenate(va)
+    x = sp.synth.vector(n, dtype=dtype)
+    starts = np.arange(0, n, rpt)
+    ends = np.minimum(starts + rpt, n)
+    big = (rp[ends] - (rp[starts] & ~np.uint64(1))) > 1024
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    light = np.ones(n, dtype=bool)
+    for s0, e0 in zip(starts[big], ends[big]):
+        light[s0:e0] = False
+    for pers in (0, 1):
+        dev = check(oracle, rp, ci, va, x, n, kernel=2, rows_per_tile=rpt, persistent=pers)
+        d = dev.describe()
+        assert d["kernel"] == "stream" and d["rows_per_tile"] == rpt
+        assert d["overflow_tiles"] == int(big.sum()) > 0
+        y = dev.spmv(x)
+        assert np.array_equal(y[light], y_ref[light])
 
 
 @pytest.mark.parametrize("lanes", [2, 4, 8, 16, 32, 64])
