@@ -410,17 +410,18 @@ template <> struct Pair<float> { using type = __attribute__((ext_vector_type(2))
 __device__ __forceinline__ bool stream_tile_overflows(uint32_t b, uint32_t e) {
     return e - (b & ~1u) > (uint32_t)kStreamTileNnz;
 }
-// bit k set: the wave's tile k (rows wrow + k*RPT ...) exists and is oversized; wave-uniform.
-// Zero for almost every wave, which then runs the tile loop compiled without the test.
-template <int TPW, int RPT>
-__device__ __forceinline__ uint32_t stream_overflow_mask(const uint32_t (&tb)[TPW + 1], uint32_t wrow,
-                                                         uint32_t row1) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int k = 0; k < TPW; ++k)
-        if (wrow + k * (uint32_t)RPT < row1 && stream_tile_overflows(tb[k], tb[k + 1])) m |= 1u << k;
-    return m;
+// Which tiles those are is the plan's decision (more than 1024 entries, or a row so long that its lane
+// would keep the other 63 waiting): a bit per tile of the super-tile, packed into the descriptor --
+// desc.w = contiguous | bits 0..15 << 16, desc.z = mode | bits 16..31 << 16.
+__device__ __forceinline__ uint32_t desc_mode(const uint4 &d) { return d.z & 0xffffu; }
+__device__ __forceinline__ uint32_t desc_skip_bits(const uint4 &d) { return (d.w >> 16) | (d.z & 0xffff0000u); }
+// the bits of one wave's TPW tiles; zero for almost every wave, which then runs the tile loop compiled
+// without the test
+template <int TPW>
+__device__ __forceinline__ uint32_t wave_skip_mask(uint32_t bits, uint32_t wave) {
+    return (bits >> (wave * TPW)) & ((1u << TPW) - 1u);
 }
+
 template <typename T>
 struct StreamTile {
     typename Pair<T>::type v[kStreamSteps];
@@ -593,7 +594,7 @@ __device__ __forceinline__ void stream_global_super_tile(const uint32_t *__restr
                                                          const T *__restrict__ vals,
                                                          const T *__restrict__ x, T *__restrict__ y,
                                                          T *prod, uint32_t row0, uint32_t row1,
-                                                         uint32_t ncols, bool nt_store) {
+                                                         uint32_t ncols, bool nt_store, uint32_t skip_bits) {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = threadIdx.x / kWave;
     const uint32_t wrow = row0 + wave * (TPW * (uint32_t)RPT);
@@ -604,7 +605,7 @@ __device__ __forceinline__ void stream_global_super_tile(const uint32_t *__restr
     for (int k = 0; k <= TPW; ++k) tb[k] = __builtin_amdgcn_readlane(tb_lane, k);
     StreamTileG<T> cur, nxt;
     stream_load_g<T, RPT>(cur, rowptr, colind, vals, wrow, row1, tb[0], tb[1], lane);
-    const uint32_t ovmask = stream_overflow_mask<TPW, RPT>(tb, wrow, row1);
+    const uint32_t ovmask = wave_skip_mask<TPW>(skip_bits, wave);
     auto tiles = [&](auto ov) {
         constexpr bool OV = decltype(ov)::value;
 #pragma unroll
@@ -643,7 +644,10 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     constexpr uint32_t kRows = stream_rows(TPW, RPT);
     const uint32_t row0 = b * kRows;
     const uint32_t row1 = min(row0 + kRows, nrows);
-    const uint4 d = desc[b];  // block-uniform
+    uint4 d = desc[b];  // block-uniform
+    const uint32_t skip_bits = desc_skip_bits(d);
+    d.z = desc_mode(d);
+    d.w &= 1u;
 
     if (d.z == kModeStream) {
         const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -664,7 +668,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
         __syncthreads();
         if (!has0) return;
         const uint32_t wmax = d.y * kPageCols - 1u;
-        const uint32_t ovmask = stream_overflow_mask<TPW, RPT>(tb, wrow, row1);
+        const uint32_t ovmask = wave_skip_mask<TPW>(skip_bits, wave);
         auto tiles = [&](auto ov) {
             constexpr bool OV = decltype(ov)::value;
 #pragma unroll
@@ -686,7 +690,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     if (d.z == kModeStreamGlobal) {
         stream_global_super_tile<T, TPW, RPT>(rowptr, colind, vals, x, y,
                                               prod_all + (threadIdx.x / kWave) * kStreamTileNnz, row0,
-                                              row1, ncols, nt_store);
+                                              row1, ncols, nt_store, skip_bits);
         return;
     }
     const uint32_t last_nz = nnz - 1;
@@ -748,9 +752,12 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
 
     for (uint32_t s = s_begin; s < s_end; ++s) {
         const uint32_t row0 = s * kRows, row1 = min(row0 + kRows, nrows);
-        const uint4 d = desc[s];  // block-uniform
+        uint4 d = desc[s];  // block-uniform
+        const uint32_t skip_bits = desc_skip_bits(d);
+        d.z = desc_mode(d);
+        d.w &= 1u;
         // the next super-tile's boundaries: asked for now, needed at this one's last tile
-        const bool next_stream = (s + 1 < s_end) && desc[s + 1].z == kModeStream;
+        const bool next_stream = (s + 1 < s_end) && desc_mode(desc[s + 1]) == kModeStream;
         const uint32_t tbl_next = (s + 1 < s_end) ? bounds_lane(s + 1) : 0u;
 
         if (d.z == kModeStream) {
@@ -766,7 +773,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
             const uint32_t wmax = d.y * kPageCols - 1u;
             bool fetched_next = false;
             if (has0) {
-                const uint32_t ovmask = stream_overflow_mask<TPW, RPT>(tb, wrow, row1);
+                const uint32_t ovmask = wave_skip_mask<TPW>(skip_bits, wave);
                 auto tiles = [&](auto ov) {
                     constexpr bool OV = decltype(ov)::value;
 #pragma unroll
@@ -801,7 +808,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
         } else if (d.z == kModeStreamGlobal) {
             cur_valid = false;   // (no window involved: no barrier needed)
             stream_global_super_tile<T, TPW, RPT>(rowptr, colind, vals, x, y, prod, row0, row1, ncols,
-                                                  nt_store);
+                                                  nt_store, skip_bits);
         } else {
             cur_valid = false;
             __syncthreads();

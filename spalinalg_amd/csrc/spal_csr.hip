@@ -213,37 +213,57 @@ static constexpr uint32_t kStreamWindowBytes = 48 * 1024;
 // (band of 8192 columns, f64: 463 / 392 us against 722 us)
 static constexpr uint32_t kStreamBigWindowBytes = 120 * 1024;
 
-// One thread per super-tile: over[b] = how many of its tiles hold more entries than the product strip
-// (those tiles are not streamed: csr_spmv_overflow computes their rows).
+// One workgroup per super-tile: chk[b] = {skip bits, cost, entries, 0}.
+//  - skip: a bit per tile that the stream kernels must leave to csr_spmv_overflow -- it holds more entries
+//    than the product strip, or a row of more than row_max entries (the stream kernels sum a row per lane:
+//    such a row keeps 63 lanes waiting, 25 cycles per entry);
+//  - cost: what the super-tile's tiles cost at this tile height, in entries: a streamed tile as much as a
+//    half-full one at least (its fixed work: 160 entries per 16-row tile ran 2.1 x slower than 400 per 64-row tile),
+//    a skipped tile 1.5 per entry + 1000 (its own workgroup in the overflow kernel).  The planner takes the
+//    tile height with the smallest sum (power-law rows, 10 per row on average: 64 / 32 / 16 rows per tile
+//    predicted 1 : 1.37 : 2.1, measured 196 : 270 : 380 us).
+constexpr uint32_t kTileFloorEntries = 512, kOverflowTileFixed = 1000;
 __global__ __launch_bounds__(256) void csr_stream_check(const uint32_t *__restrict__ rowptr,
-                                                        uint32_t nrows, uint32_t nblocks,
-                                                        uint32_t R, uint32_t rpt,
-                                                        uint32_t *__restrict__ over) {
-    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= nblocks) return;
+                                                        uint32_t nrows, uint32_t R, uint32_t rpt,
+                                                        uint32_t row_max, uint4 *__restrict__ chk) {
+    __shared__ uint32_t s_long[32];
+    const uint32_t t = threadIdx.x, b = blockIdx.x;
     const uint32_t row0 = b * R, row1 = min(row0 + R, nrows);
-    uint32_t bad = 0;
-    for (uint32_t r0 = row0; r0 < row1; r0 += rpt) {
-        const uint32_t rl = min(r0 + rpt, row1);
-        const uint32_t n = rowptr[rl] - (rowptr[r0] & ~1u);
-        if (n > (uint32_t)kStreamTileNnz) ++bad;
+    if (t < 32) s_long[t] = 0u;
+    __syncthreads();
+    for (uint32_t r = row0 + t; r < row1; r += 256)
+        if (rowptr[r + 1] - rowptr[r] > row_max) s_long[(r - row0) / rpt] = 1u;   // (same value from every writer)
+    __syncthreads();
+    if (t < 64) {   // R / rpt <= 32 tiles
+        const uint32_t r0 = row0 + t * rpt;
+        bool bad = false;
+        uint32_t cost = 0;
+        if (t < R / rpt && r0 < row1) {
+            const uint32_t rl = min(r0 + rpt, row1);
+            const uint32_t e0 = rowptr[r0], e1 = rowptr[rl];
+            bad = stream_tile_overflows(e0, e1) || s_long[t] != 0u;
+            const uint32_t n = e1 - e0;
+            cost = bad ? n + n / 2 + kOverflowTileFixed : max(n, kTileFloorEntries);
+        }
+        const uint64_t m = __ballot(bad);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cost += (uint32_t)__shfl_xor((int)cost, o, 64);
+        if (t == 0) chk[b] = make_uint4((uint32_t)m, cost, rowptr[row1] - rowptr[row0], 0u);
     }
-    over[b] = bad;
 }
 
-// Plan time: the first rows of the oversized tiles of super-tiles in a stream mode, appended in any order.
-__global__ __launch_bounds__(256) void csr_overflow_tiles(const uint32_t *__restrict__ rowptr,
-                                                          const uint4 *__restrict__ desc, uint32_t nrows,
+// Plan time: the first rows of the tiles the descriptors mark, appended in any order.
+__global__ __launch_bounds__(256) void csr_overflow_tiles(const uint4 *__restrict__ desc, uint32_t nrows,
                                                           uint32_t R, uint32_t rpt, uint32_t cap,
                                                           uint32_t *__restrict__ count,
                                                           uint32_t *__restrict__ tiles) {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t r0 = i * rpt;
     if (r0 >= nrows) return;
-    const uint32_t mode = desc[r0 / R].z;
+    const uint4 d = desc[r0 / R];
+    const uint32_t mode = desc_mode(d);
     if (mode != kModeStream && mode != kModeStreamGlobal) return;
-    const uint32_t r1 = (uint32_t)min((uint64_t)r0 + rpt, (uint64_t)min((r0 / R + 1) * R, (uint64_t)nrows));
-    if (!stream_tile_overflows(rowptr[r0], rowptr[r1])) return;
+    if (!((desc_skip_bits(d) >> (uint32_t)((r0 % R) / rpt)) & 1u)) return;
     const uint32_t at = atomicAdd(count, 1u);
     if (at < cap) tiles[at] = (uint32_t)r0;
 }
@@ -251,7 +271,7 @@ __global__ __launch_bounds__(256) void csr_overflow_tiles(const uint32_t *__rest
 // ---- the pages a super-tile's rows touch ----------------------------------------------
 // One workgroup per super-tile of R rows.  info[b] = {first column, one past the last
 // column, number of pages or kNotPageable, 1 if the pages are the contiguous run that
-// starts at page (first column >> kPageShift)}.  When the span holds at most `cap` pages
+// starts at page (first column >> kPageShift)}.  When the span holds at most `run_cap` pages
 // the run is taken whole (a band); otherwise the columns are marked in an LDS bitmap
 // (spans up to 16.7M columns), first for a sample of 2048 entries -- scattered columns
 // are recognised and dropped there -- then for all of them, and the pages are listed in
@@ -260,8 +280,8 @@ constexpr uint32_t kNotPageable = 0xffffffffu;
 constexpr uint32_t kPageBitmapWords = 2048;   // 65536 pages
 __global__ __launch_bounds__(256) void csr_block_pages(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind, uint32_t nrows,
-    uint32_t R, uint32_t cap, const uint2 *__restrict__ known_win, uint4 *__restrict__ info,
-    uint32_t *__restrict__ pages) {
+    uint32_t R, uint32_t cap, uint32_t run_cap, const uint2 *__restrict__ known_win,
+    uint4 *__restrict__ info, uint32_t *__restrict__ pages) {
     __shared__ uint32_t s_bits[kPageBitmapWords];
     __shared__ uint32_t s_min, s_max, s_count, s_wsum[4];
     const uint32_t t = threadIdx.x, b = blockIdx.x;
@@ -289,7 +309,7 @@ __global__ __launch_bounds__(256) void csr_block_pages(
         return;
     }
     const uint32_t pmin = cmin >> kPageShift, span = ((cmax - 1u) >> kPageShift) - pmin + 1u;
-    if (span <= cap) {
+    if (span <= run_cap) {   // (run_cap <= cap: the budget that keeps two workgroups per CU)
         if (t == 0) info[b] = make_uint4(cmin, cmax, span, 1u);
         return;
     }
@@ -353,7 +373,7 @@ __global__ __launch_bounds__(256) void csr_block_pages(
             }
         }
     }
-    if (t == 0) info[b] = make_uint4(cmin, cmax, s_count, 0u);
+    if (t == 0) info[b] = make_uint4(cmin, cmax, s_count, s_count == span ? 1u : 0u);   // (every page of the span: a run after all)
 }
 
 // One workgroup per super-tile: col16 = slot of the column's page * kPageCols + column
@@ -366,10 +386,10 @@ __global__ __launch_bounds__(256) void csr_encode_col16(const uint32_t *__restri
                                                         uint32_t nrows, uint32_t R) {
     __shared__ uint32_t s_pg[64];
     const uint4 d = desc[blockIdx.x];   // Stream: {first page / offset, npages, mode, contiguous}
-    if (d.z != kModeStream) return;
+    if (desc_mode(d) != kModeStream) return;
     const uint32_t row0 = blockIdx.x * R, row1 = min(row0 + R, nrows);
     const uint32_t p0 = rowptr[row0], p1 = rowptr[row1];
-    if (d.w) {   // contiguous run of pages starting at page d.x
+    if (d.w & 1u) {   // contiguous run of pages starting at page d.x
         const uint32_t base = d.x << kPageShift;
         for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256) col16[p] = (uint16_t)(colind[p] - base);
         return;
@@ -599,7 +619,8 @@ static int block_windows(spal_csr *a, uint32_t R, std::vector<uint2> &win) {
 // Stream plan: super-tiles of R rows; returns the fraction of rows
 // that can be streamed and fills `desc`.
 static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4> &desc, uint32_t &cap,
-                       double &frac, uint32_t **out_pages, uint32_t &n_over) {
+                       double &frac, uint32_t **out_pages, uint32_t &n_over, std::vector<uint32_t> &skip,
+                       double &cost) {
     *out_pages = nullptr;
     n_over = 0;
     const uint32_t nb = (uint32_t)((a->nrows + R - 1) / R);
@@ -608,13 +629,13 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
     const uint32_t page_bytes = kPageCols * (uint32_t)a->elem_size;
     const uint32_t page_cap = std::min<uint32_t>(64u, kStreamBigWindowBytes / page_bytes);
     const uint32_t small_cap = std::min<uint32_t>(page_cap, a->elem_size == 4 ? 64u : kStreamWindowBytes / page_bytes);
-    uint32_t *d_ok = nullptr, *d_pages = nullptr;
-    uint4 *d_info = nullptr;
-    SPAL_HIP_TRY(dev_alloc((void **)&d_ok, (size_t)nb * 4));
+    uint32_t *d_pages = nullptr;
+    uint4 *d_info = nullptr, *d_ok = nullptr;
+    SPAL_HIP_TRY(dev_alloc((void **)&d_ok, (size_t)nb * sizeof(uint4)));
     SPAL_HIP_TRY(dev_alloc((void **)&d_info, (size_t)nb * sizeof(uint4)));
     SPAL_HIP_TRY(dev_alloc((void **)&d_pages, (size_t)nb * page_cap * 4));
-    hipLaunchKernelGGL(csr_stream_check, dim3((nb + 255) / 256), dim3(256), 0, a->stream, a->d_rowptr,
-                       (uint32_t)a->nrows, nb, R, rpt, d_ok);
+    hipLaunchKernelGGL(csr_stream_check, dim3(nb), dim3(256), 0, a->stream, a->d_rowptr, (uint32_t)a->nrows, R,
+                       rpt, (uint32_t)a->plan.stream_row_max, d_ok);
     // column windows already known per 256 rows (e.g. handed over by the assembly): fold and pass them
     uint2 *d_win = nullptr;
     if (!a->win_base.empty() && R % kWinBase == 0) {
@@ -625,10 +646,12 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
         SPAL_HIP_TRY(hipStreamSynchronize(a->stream));   // `win` goes out of scope
     }
     hipLaunchKernelGGL(csr_block_pages, dim3(nb), dim3(256), 0, a->stream, a->d_rowptr, a->d_colind,
-                       (uint32_t)a->nrows, R, page_cap, d_win, d_info, d_pages);
-    std::vector<uint32_t> over(nb);   // tiles per super-tile that do not fit the strip
+                       (uint32_t)a->nrows, R, page_cap,
+                       a->plan.window_pages > 0 ? std::min<uint32_t>(page_cap, (uint32_t)a->plan.window_pages) : small_cap,
+                       d_win, d_info, d_pages);
+    std::vector<uint4> chk(nb);   // {a bit per tile that does not stream, cost of the tiles, entries, -}
     std::vector<uint4> info(nb);
-    hipError_t e = hipMemcpyAsync(over.data(), d_ok, (size_t)nb * 4, hipMemcpyDeviceToHost, a->stream);
+    hipError_t e = hipMemcpyAsync(chk.data(), d_ok, (size_t)nb * sizeof(uint4), hipMemcpyDeviceToHost, a->stream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(info.data(), d_info, (size_t)nb * sizeof(uint4), hipMemcpyDeviceToHost, a->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
@@ -645,16 +668,19 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
     if (a->plan.window_pages > 0) {
         use_cap = std::min<uint32_t>(page_cap, (uint32_t)a->plan.window_pages);
     } else if (page_cap > small_cap) {
-        double rows_small = 0, rows_big = 0, rows_ok = 0;
+        // per super-tile, in bytes: its entries' stream (10 B each) plus the window's pages (staged through L2,
+        // weighted 0.7); the 1.35 and 2.3 are measured on bands.  (A window as large as the entries it serves
+        // does not pay: 256-row super-tiles of 10-entry rows spread over 10 000 columns ran 380 us with the
+        // large window, 227 us with x through L2.)
+        double cost_small = 0, cost_big = 0;
         for (uint32_t b = 0; b < nb; ++b) {
             if (info[b].y == 0) continue;
-            const double rows = (double)std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
-            rows_ok += rows;
-            if (info[b].z != kNotPageable && info[b].z <= small_cap) rows_small += rows;
-            if (info[b].z != kNotPageable) rows_big += rows;
+            const double stream = 10.0 * (double)chk[b].z, gather = 2.3 * stream;
+            const double window = 0.7 * (double)page_bytes * (double)info[b].z;
+            const bool pageable = info[b].z != kNotPageable;
+            cost_small += pageable && info[b].z <= small_cap ? stream + window : gather;
+            cost_big += pageable ? 1.35 * (stream + window) : gather;
         }
-        const double cost_small = rows_small * 1.0 + (rows_ok - rows_small) * 2.3;
-        const double cost_big = rows_big * 1.35 + (rows_ok - rows_big) * 2.3;
         if (cost_big < 0.97 * cost_small) use_cap = page_cap;
     }
     desc.assign(nb, make_uint4(0, 0, kModeVectorGlobal, 0));
@@ -688,15 +714,23 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
             cap = std::max(cap, len);
         }
     }
-    // what the caller ranks tile heights by: the share of rows whose TILE streams (a super-tile in a stream
-    // mode still hands its oversized tiles to the vector rows)
+    // what the caller ranks tile heights by: the share of rows whose TILE streams (the marked tiles of a
+    // super-tile in a stream mode are left to csr_spmv_overflow)
     {
         uint64_t rows_tiles = 0;
+        skip.assign(nb, 0u);
+        cost = 0.0;
         for (uint32_t b = 0; b < nb; ++b) {
-            if (desc[b].z != kModeStream && desc[b].z != kModeStreamGlobal) continue;
+            if (desc[b].z != kModeStream && desc[b].z != kModeStreamGlobal) {
+                cost += 2.0 * (double)chk[b].z;   // (vector rows inside the stream kernel)
+                continue;
+            }
+            skip[b] = chk[b].x;
+            cost += (double)chk[b].y;
             const uint64_t rows = std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
-            rows_tiles += rows - std::min<uint64_t>(rows, (uint64_t)over[b] * rpt);
-            n_over += over[b];
+            const uint32_t over = (uint32_t)__builtin_popcount(skip[b]);
+            rows_tiles += rows - std::min<uint64_t>(rows, (uint64_t)over * rpt);
+            n_over += over;
         }
         frac = a->nrows ? (double)rows_tiles / (double)a->nrows : 0.0;
     }
@@ -745,26 +779,29 @@ int csr_plan_build(spal_csr *a) {
         else rpts.assign(rpt_all, rpt_all + 3);
         std::vector<uint4> desc, best_desc;
         uint32_t cap = 0, best_cap = 0;
-        double frac = 0.0, best_frac = -1.0;
+        double frac = 0.0, best_frac = -1.0, best_cost = -1.0;
         int best_rpt = rpts[0];
         uint32_t *best_pages = nullptr;
         uint32_t n_over = 0, best_over = 0;
+        std::vector<uint32_t> skip, best_skip;
         if (a->d_pages) { SPAL_HIP_TRY(dev_free(a->d_pages)); a->d_pages = nullptr; }
         if (a->d_ovtiles) { SPAL_HIP_TRY(dev_free(a->d_ovtiles)); a->d_ovtiles = nullptr; }
         a->n_ovtiles = 0;
         for (int rpt : rpts) {
             const uint32_t R = (uint32_t)stream_rows(p.tiles_per_wave, rpt);
             uint32_t *pg = nullptr;
-            int st = stream_plan(a, R, (uint32_t)rpt, desc, cap, frac, &pg, n_over);
+            double cost = 0.0;
+            int st = stream_plan(a, R, (uint32_t)rpt, desc, cap, frac, &pg, n_over, skip, cost);
             if (st != SPAL_OK) { (void)dev_free(best_pages); return st; }
-            if (frac > best_frac + 0.05) {  // a narrower tile must buy real coverage
-                best_frac = frac; best_rpt = rpt; best_cap = cap; best_over = n_over; best_desc.swap(desc);
+            if (best_cost < 0.0 || cost < 0.95 * best_cost) {  // a narrower tile must be estimated cheaper (see csr_stream_check)
+                best_cost = cost;
+                best_frac = frac; best_rpt = rpt; best_cap = cap; best_over = n_over; best_desc.swap(desc); best_skip.swap(skip);
                 (void)dev_free(best_pages);
                 best_pages = pg;
             } else {
                 (void)dev_free(pg);
             }
-            if (best_frac >= 0.95) break;
+            if (best_cost <= 1.1 * (double)a->nnz) break;   // no tile height costs less than one per entry
         }
         if (!(p.user_kernel == 2 || best_frac >= 0.5)) (void)dev_free(best_pages);
         if (p.user_kernel == 2 || best_frac >= 0.5) {
@@ -788,8 +825,14 @@ int csr_plan_build(spal_csr *a) {
                     lds_rows += std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
             p.lds_row_fraction = (double)lds_rows / (double)a->nrows;
             SPAL_HIP_TRY(dev_alloc((void **)&a->d_desc, (size_t)p.nblocks * sizeof(uint4)));
-            SPAL_HIP_TRY(hipMemcpyAsync(a->d_desc, best_desc.data(), (size_t)p.nblocks * sizeof(uint4),
+            std::vector<uint4> packed(best_desc);   // + the tiles to skip (see desc_skip_bits)
+            for (uint32_t b = 0; b < p.nblocks; ++b) {
+                packed[b].w |= (best_skip[b] & 0xffffu) << 16;
+                packed[b].z |= best_skip[b] & 0xffff0000u;
+            }
+            SPAL_HIP_TRY(hipMemcpyAsync(a->d_desc, packed.data(), (size_t)p.nblocks * sizeof(uint4),
                                         hipMemcpyHostToDevice, a->stream));
+            SPAL_HIP_TRY(hipStreamSynchronize(a->stream));   // `packed` goes out of scope
             // 16-bit columns only where some super-tile reads them (a matrix whose columns are scattered
             // everywhere streams with the 32-bit ones: no 2 B/entry array to allocate and clear)
             bool any_stream = false;
@@ -810,8 +853,8 @@ int csr_plan_build(spal_csr *a) {
                 SPAL_HIP_TRY(hipMemsetAsync(d_list, 0, 4, a->stream));
                 const uint64_t ntile = (a->nrows + (uint64_t)best_rpt - 1) / (uint64_t)best_rpt;
                 hipLaunchKernelGGL(csr_overflow_tiles, dim3((uint32_t)((ntile + 255) / 256)), dim3(256), 0, a->stream,
-                                   a->d_rowptr, a->d_desc, (uint32_t)a->nrows, R, (uint32_t)best_rpt, best_over,
-                                   d_list, d_list + 1);
+                                   a->d_desc, (uint32_t)a->nrows, R, (uint32_t)best_rpt, best_over, d_list,
+                                   d_list + 1);
                 SPAL_HIP_TRY(hipGetLastError());
                 uint32_t listed = 0;
                 SPAL_HIP_TRY(hipMemcpyAsync(&listed, d_list, 4, hipMemcpyDeviceToHost, a->stream));
@@ -1233,6 +1276,10 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         // at two workgroups per CU, or up to 60 at one when that is estimated to pay)
         if (value < 0 || value > 64) return fail(SPAL_ERR_INVALID_ARGUMENT, "window_pages must be in [0, 64]");
         p.window_pages = (int)value;
+    } else if (!strcmp(key, "stream_row_max")) {
+        // stream kernel: a tile with a row longer than this is left to the overflow kernel
+        if (value < 1 || value > 1024) return fail(SPAL_ERR_INVALID_ARGUMENT, "stream_row_max must be in [1, 1024]");
+        p.stream_row_max = (int)value;
     } else if (!strcmp(key, "nt_store")) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "nt_store must be 0 or 1");
         p.nt_store = (int)value;

@@ -96,6 +96,7 @@ struct CsrPlan {
     int rows_per_tile = 64;  // stream kernel: rows of a wave-tile (64, 32 or 16)
     int persistent = 0;      // stream kernel: fixed grid walking chunks of super-tiles
     int nt_store = 0;        // stream kernel: non-temporal stores of y
+    int stream_row_max = 128; // stream kernel: tiles with a longer row go to the overflow kernel (a lane sums a row)
     int window_pages = 0;    // stream kernel: page budget of a super-tile's LDS x window (0 = automatic)
     int stream_global = 1;   // stream kernel: super-tiles whose pages exceed the LDS budget gather x from global
     int persistent_blocks = 0;    // its grid; 0 = what the device holds at once (LDS per workgroup decides: f64 band 512)

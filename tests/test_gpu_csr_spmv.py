@@ -191,14 +191,15 @@ def test_stream_kernel_mixed_supertiles(oracle):
 @pytest.mark.parametrize("rpt", [64, 32, 16])
 def test_oversized_tiles_go_to_the_overflow_kernel(oracle, dtype, rpt):
     """heavy rows among light ones: only their TILE leaves the stream path (a second kernel computes its
-    rows); every other row keeps the reference's summation order bit for bit."""
+    rows); every other row keeps the reference's summation order bit for bit.  A tile leaves when it holds
+    more than 1024 entries or a row of more than 128 (option stream_row_max)."""
     rng = np.random.default_rng(77 + rpt)
     n = 20_011                                   # ragged last super-tile and last tile
     rp, ci, va = sp.synth.banded_csr(n, n, 14, 2048, 21, dtype=dtype)
     rp = rp.astype(np.int64)
     ci, va = list(np.split(ci, rp[1:-1])), list(np.split(va, rp[1:-1]))
     heavy = [(0, 1200), (63, 1500), (64, 1100), (700, 600), (701, 600), (4096, 3000), (4097 + rpt, 2500),
-             (9000, 5000), (n - 1, 1300)]
+             (9000, 5000), (15_000, 129), (16_000, 128), (n - 1, 1300)]
     for r, k in heavy:
         span = max(4000, 2 * k)
         lo = max(0, min(r - span // 2, n - span))
@@ -210,7 +211,9 @@ def test_oversized_tiles_go_to_the_overflow_kernel(oracle, dtype, rpt):
     x = sp.synth.vector(n, dtype=dtype)
     starts = np.arange(0, n, rpt)
     ends = np.minimum(starts + rpt, n)
-    big = (rp[ends] - (rp[starts] & ~np.uint64(1))) > 1024
+    lens = np.diff(rp.astype(np.int64))
+    longest = np.array([lens[s0:e0].max() for s0, e0 in zip(starts, ends)])
+    big = ((rp[ends] - (rp[starts] & ~np.uint64(1))) > 1024) | (longest > 128)   # the plan's two criteria
     y_ref = oracle.csr_spmv(rp, ci, va, x)
     light = np.ones(n, dtype=bool)
     for s0, e0 in zip(starts[big], ends[big]):
