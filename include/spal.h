@@ -122,7 +122,8 @@ int spal_csr_download_f32(spal_csr_t a, uint64_t *rowptr, uint64_t *colind,
  * "tiles_per_wave", "persistent", "persistent_blocks" (0 = what the device
  * holds at once), "nt_store", "stream_global", "window_pages" (0 auto; LDS x
  * window budget in 256-column pages), "stream_row_max" (64-row tiles with a
- * longer row go to the overflow kernel; default 128) (stream kernel).  Unknown key or a value
+ * longer row go to the overflow kernel; default 128), "skew" (-1 auto, 0, 1:
+ * skewed LDS product strips) (stream kernel).  Unknown key or a value
  * the kernels are not instantiated for: SPAL_ERR_INVALID_ARGUMENT. */
 int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value);
 /* Setup-time autotune: runs the planned kernel's variants (today: the stream

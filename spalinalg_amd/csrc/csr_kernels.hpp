@@ -393,6 +393,15 @@ constexpr int kStreamWaves = kStreamBlock / kWave;                          // 4
 constexpr int stream_rows(int tpw, int rpt = 64) { return kStreamWaves * tpw * rpt; }
 constexpr int kStreamSteps = 8;                                             // 128 entries per step
 constexpr int kStreamTileNnz = kStreamSteps * 128;                          // 1024 incl. alignment slack
+// SKEW: the product strip in LDS is skewed by one entry per 128 bytes.  A lane sums its row out of the strip,
+// and rows whose length is a multiple of 16 (f64; 32 f32) start in the same bank for every lane: 16 / 32 / 64 per
+// row ran at 61 / 60 / 59 % of the HBM peak against 73 / 80 / 84 % for 15 / 31 / 63.  Skewed: 77 / 73 / 80 %, but
+// 67 / 69 / 76 % for 15 / 31 / 63 (two LDS instructions where one did, address arithmetic) -- so it is a template
+// parameter and the plan's choice (csr_plan_build: most rows a multiple of 128 bytes long).
+template <bool SKEW>
+constexpr int stream_strip() { return SKEW ? kStreamTileNnz + kStreamTileNnz / 16 : kStreamTileNnz; }   // entries of LDS per wave
+template <typename T, bool SKEW>
+__device__ __forceinline__ uint32_t strip_pos(uint32_t e) { return SKEW ? e + (e >> (sizeof(T) == 8 ? 4 : 5)) : e; }
 constexpr int kStreamPad = 256;  // device arrays are over-allocated by this many entries
 
 
@@ -457,12 +466,11 @@ __device__ __forceinline__ void stream_load(StreamTile<T> &t, const uint32_t *__
     t.rp1 = rowptr[min(row0 + lane + 1, rlast)];
 }
 
-template <typename T, int RPT>
+template <typename T, int RPT, bool SKEW>
 __device__ __forceinline__ void stream_compute(const StreamTile<T> &t, const T *xw, uint32_t wmax,
                                                T *prod, T *__restrict__ y, uint32_t row0,
                                                uint32_t row1, uint32_t lane, bool nt_store = false) {
     using pair_t = typename Pair<T>::type;
-    pair_t *prod2 = reinterpret_cast<pair_t *>(prod);
 #pragma unroll
     for (int j = 0; j < kStreamSteps; ++j) {
         if ((uint32_t)j < t.steps) {  // uniform
@@ -473,7 +481,13 @@ __device__ __forceinline__ void stream_compute(const StreamTile<T> &t, const T *
             pair_t p;
             p.x = t.v[j].x * xw[c0];
             p.y = t.v[j].y * xw[c1];
-            prod2[j * 64 + lane] = p;
+            if constexpr (SKEW) {
+                const uint32_t at = strip_pos<T, true>(2u * (j * 64 + lane));   // an even entry and its odd neighbour stay adjacent
+                prod[at] = p.x;
+                prod[at + 1] = p.y;
+            } else {
+                reinterpret_cast<pair_t *>(prod)[j * 64 + lane] = p;
+            }
         }
     }
     // the wave's own LDS writes are read back by other lanes of the same wave:
@@ -486,17 +500,17 @@ __device__ __forceinline__ void stream_compute(const StreamTile<T> &t, const T *
     // stay in stored order (the order is the contract, the batching is not)
     T acc = T(0);
     if (len) {
-        acc = prod[off];
+        acc = prod[strip_pos<T, SKEW>(off)];
         uint32_t k = 1;
         for (; k + 4 <= len; k += 4) {
-            const T p0 = prod[off + k], p1 = prod[off + k + 1], p2 = prod[off + k + 2],
-                    p3 = prod[off + k + 3];
+            const T p0 = prod[strip_pos<T, SKEW>(off + k)], p1 = prod[strip_pos<T, SKEW>(off + k + 1)],
+                    p2 = prod[strip_pos<T, SKEW>(off + k + 2)], p3 = prod[strip_pos<T, SKEW>(off + k + 3)];
             acc = acc + p0;
             acc = acc + p1;
             acc = acc + p2;
             acc = acc + p3;
         }
-        for (; k < len; ++k) acc = acc + prod[off + k];
+        for (; k < len; ++k) acc = acc + prod[strip_pos<T, SKEW>(off + k)];
     }
     __builtin_amdgcn_wave_barrier();  // the next tile's products overwrite this strip
     if (row0 + lane < min(row0 + (uint32_t)RPT, row1)) {
@@ -539,13 +553,12 @@ __device__ __forceinline__ void stream_load_g(StreamTileG<T> &t, const uint32_t 
     t.rp1 = rowptr[min(row0 + lane + 1, rlast)];
 }
 
-template <typename T, int RPT>
+template <typename T, int RPT, bool SKEW>
 __device__ __forceinline__ void stream_compute_g(const StreamTileG<T> &t, const T *__restrict__ x,
                                                  uint32_t cmax, T *prod, T *__restrict__ y,
                                                  uint32_t row0, uint32_t row1, uint32_t lane,
                                                  bool nt_store) {
     using pair_t = typename Pair<T>::type;
-    pair_t *prod2 = reinterpret_cast<pair_t *>(prod);
     T xa[kStreamSteps], xb[kStreamSteps];
 #pragma unroll
     for (int j = 0; j < kStreamSteps; ++j) {
@@ -560,7 +573,13 @@ __device__ __forceinline__ void stream_compute_g(const StreamTileG<T> &t, const 
             pair_t p;
             p.x = t.v[j].x * xa[j];
             p.y = t.v[j].y * xb[j];
-            prod2[j * 64 + lane] = p;
+            if constexpr (SKEW) {
+                const uint32_t at = strip_pos<T, true>(2u * (j * 64 + lane));   // an even entry and its odd neighbour stay adjacent
+                prod[at] = p.x;
+                prod[at + 1] = p.y;
+            } else {
+                reinterpret_cast<pair_t *>(prod)[j * 64 + lane] = p;
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -568,17 +587,17 @@ __device__ __forceinline__ void stream_compute_g(const StreamTileG<T> &t, const 
     const uint32_t len = t.rp1 - t.rp0;
     T acc = T(0);
     if (len) {
-        acc = prod[off];
+        acc = prod[strip_pos<T, SKEW>(off)];
         uint32_t k = 1;
         for (; k + 4 <= len; k += 4) {
-            const T p0 = prod[off + k], p1 = prod[off + k + 1], p2 = prod[off + k + 2],
-                    p3 = prod[off + k + 3];
+            const T p0 = prod[strip_pos<T, SKEW>(off + k)], p1 = prod[strip_pos<T, SKEW>(off + k + 1)],
+                    p2 = prod[strip_pos<T, SKEW>(off + k + 2)], p3 = prod[strip_pos<T, SKEW>(off + k + 3)];
             acc = acc + p0;
             acc = acc + p1;
             acc = acc + p2;
             acc = acc + p3;
         }
-        for (; k < len; ++k) acc = acc + prod[off + k];
+        for (; k < len; ++k) acc = acc + prod[strip_pos<T, SKEW>(off + k)];
     }
     __builtin_amdgcn_wave_barrier();
     if (row0 + lane < min(row0 + (uint32_t)RPT, row1)) {
@@ -588,7 +607,7 @@ __device__ __forceinline__ void stream_compute_g(const StreamTileG<T> &t, const 
 }
 
 // one super-tile in stream-global mode (no window, no workgroup barrier)
-template <typename T, int TPW, int RPT>
+template <typename T, int TPW, int RPT, bool SKEW>
 __device__ __forceinline__ void stream_global_super_tile(const uint32_t *__restrict__ rowptr,
                                                          const uint32_t *__restrict__ colind,
                                                          const T *__restrict__ vals,
@@ -617,7 +636,7 @@ __device__ __forceinline__ void stream_global_super_tile(const uint32_t *__restr
             if (more) stream_load_g<T, RPT>(nxt, rowptr, colind, vals, rn, row1, tb[k + 1],
                                             tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
             if (!OV || !((ovmask >> k) & 1u))  // oversized tiles: csr_spmv_overflow
-                stream_compute_g<T, RPT>(cur, x, ncols - 1, prod, y, r0, row1, lane, nt_store);
+                stream_compute_g<T, RPT, SKEW>(cur, x, ncols - 1, prod, y, r0, row1, lane, nt_store);
             if (more) cur = nxt;
         }
     };
@@ -627,7 +646,7 @@ __device__ __forceinline__ void stream_global_super_tile(const uint32_t *__restr
 
 // desc[b] = Stream: {first page id or offset into pages[], number of pages, mode, 1 if the pages are a
 // contiguous run}; VectorLds: {window base column, window length, mode, 0}
-template <typename T, int L, int U, bool USE_DPP, int TPW, int RPT>
+template <typename T, int L, int U, bool USE_DPP, int TPW, int RPT, bool SKEW = false>
 __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
     const uint16_t *__restrict__ col16, const T *__restrict__ vals, const T *__restrict__ x,
@@ -637,7 +656,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     const bool nt_store = flags & 1u;
     // [ products: 4 waves x kStreamTileNnz ][ x window ]
     T *prod_all = reinterpret_cast<T *>(spal_smem);
-    T *xw = prod_all + kStreamWaves * kStreamTileNnz;
+    T *xw = prod_all + kStreamWaves * stream_strip<SKEW>();
 
     const uint32_t b = xcd_contiguous_block(blockIdx.x, per_xcd);
     if (b >= nblocks) return;
@@ -652,7 +671,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     if (d.z == kModeStream) {
         const uint32_t lane = threadIdx.x & (kWave - 1);
         const uint32_t wave = threadIdx.x / kWave;
-        T *prod = prod_all + wave * kStreamTileNnz;
+        T *prod = prod_all + wave * stream_strip<SKEW>();
         // this wave's tiles: rows row0 + (wave*4 + k) * 64
         const uint32_t wrow = row0 + wave * (TPW * (uint32_t)RPT);
         // entry offsets of this wave's tile boundaries, fetched once (lane k holds
@@ -679,7 +698,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
                 const bool more = (k + 1 < TPW) && rn < row1;
                 if (more) stream_load<T, RPT>(nxt, rowptr, col16, vals, rn, row1, tb[k + 1], tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
                 if (!OV || !((ovmask >> k) & 1u))  // oversized tiles: csr_spmv_overflow
-                    stream_compute<T, RPT>(cur, xw, wmax, prod, y, r0, row1, lane, nt_store);
+                    stream_compute<T, RPT, SKEW>(cur, xw, wmax, prod, y, r0, row1, lane, nt_store);
                 if (more) cur = nxt;
             }
         };
@@ -688,8 +707,8 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
         return;
     }
     if (d.z == kModeStreamGlobal) {
-        stream_global_super_tile<T, TPW, RPT>(rowptr, colind, vals, x, y,
-                                              prod_all + (threadIdx.x / kWave) * kStreamTileNnz, row0,
+        stream_global_super_tile<T, TPW, RPT, SKEW>(rowptr, colind, vals, x, y,
+                                              prod_all + (threadIdx.x / kWave) * stream_strip<SKEW>(), row0,
                                               row1, ncols, nt_store, skip_bits);
         return;
     }
@@ -715,7 +734,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
 // barriers that retire the old x window and publish the new one.  This removes
 // the per-workgroup cold start (boundary load -> tile loads -> window) and the
 // drain that the one-super-tile-per-workgroup form pays every 1024 rows.
-template <typename T, int L, int U, bool USE_DPP, int TPW, int RPT>
+template <typename T, int L, int U, bool USE_DPP, int TPW, int RPT, bool SKEW = false>
 __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
     const uint16_t *__restrict__ col16, const T *__restrict__ vals, const T *__restrict__ x,
@@ -724,7 +743,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
     const bool nt_store = flags & 1u;
     T *prod_all = reinterpret_cast<T *>(spal_smem);
-    T *xw = prod_all + kStreamWaves * kStreamTileNnz;
+    T *xw = prod_all + kStreamWaves * stream_strip<SKEW>();
     constexpr uint32_t kRows = stream_rows(TPW, RPT);
 
     // this workgroup's super-tiles: [s_begin, s_end) inside its XCD's run
@@ -736,7 +755,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = threadIdx.x / kWave;
-    T *prod = prod_all + wave * kStreamTileNnz;
+    T *prod = prod_all + wave * stream_strip<SKEW>();
     const uint32_t last_nz = nnz - 1;
 
     // tile boundaries (entry offsets) of this wave's TPW tiles in super-tile s
@@ -797,7 +816,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
                             }
                         }
                         if (!OV || !((ovmask >> k) & 1u))  // oversized tiles: csr_spmv_overflow
-                            stream_compute<T, RPT>(cur, xw, wmax, prod, y, r0, row1, lane, nt_store);
+                            stream_compute<T, RPT, SKEW>(cur, xw, wmax, prod, y, r0, row1, lane, nt_store);
                         if (more || fetched_next) cur = nxt;
                     }
                 };
@@ -807,7 +826,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
             cur_valid = fetched_next;
         } else if (d.z == kModeStreamGlobal) {
             cur_valid = false;   // (no window involved: no barrier needed)
-            stream_global_super_tile<T, TPW, RPT>(rowptr, colind, vals, x, y, prod, row0, row1, ncols,
+            stream_global_super_tile<T, TPW, RPT, SKEW>(rowptr, colind, vals, x, y, prod, row0, row1, ncols,
                                                   nt_store, skip_bits);
         } else {
             cur_valid = false;

@@ -206,9 +206,10 @@ __global__ __launch_bounds__(256) void csr_block_windows(
 // workgroup keeps two workgroups resident, smaller windows admit more.
 static constexpr uint32_t kLdsBudgetBytes = 64 * 1024;
 // stream kernel: 4 product strips (kStreamTileNnz each, 32 KiB f64) + a window of
-// at most 48 KiB -> at most 80 KiB per workgroup, two workgroups per CU.
+// at most 48 KiB -> at most 80 KiB per workgroup, two workgroups per CU (skewed strips, 34 KiB: 44 KiB).
 static constexpr uint32_t kStreamWindowBytes = 48 * 1024;
-// ... or one workgroup per CU with a window of up to 120 KiB (+ 32 KiB of strips), for matrices whose
+static constexpr uint32_t kStreamWindowBytesSkew = 44 * 1024;
+// ... or one workgroup per CU with a window of up to 120 KiB (+ 32 / 34 KiB of strips), for matrices whose
 // super-tiles touch more pages than 48 KiB hold: LDS gathers at half the occupancy still beat x through L2
 // (band of 8192 columns, f64: 463 / 392 us against 722 us)
 static constexpr uint32_t kStreamBigWindowBytes = 120 * 1024;
@@ -250,6 +251,22 @@ __global__ __launch_bounds__(256) void csr_stream_check(const uint32_t *__restri
         for (int o = 32; o > 0; o >>= 1) cost += (uint32_t)__shfl_xor((int)cost, o, 64);
         if (t == 0) chk[b] = make_uint4((uint32_t)m, cost, rowptr[row1] - rowptr[row0], 0u);
     }
+}
+
+// Plan time: how many rows are a (non-zero) multiple of `quantum` entries long -- of 128 bytes, the width of the
+// LDS banks: their lanes' sums would walk the product strip in lockstep through one bank (see SKEW in
+// csr_kernels.hpp).  (Multiples of 64 bytes only -- 8 or 24 f64 entries per row -- hit two banks: skewing those
+// measured 68 vs 66 % and 66 vs 74 %, so they are left alone.)
+__global__ __launch_bounds__(256) void csr_count_aligned_rows(const uint32_t *__restrict__ rowptr, uint32_t nrows,
+                                                              uint32_t quantum, unsigned long long *__restrict__ count) {
+    uint32_t mine = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256) {
+        const uint32_t len = rowptr[r + 1] - rowptr[r];
+        mine += (len != 0u && len % quantum == 0u) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += (uint32_t)__shfl_xor((int)mine, o, 64);
+    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(count, (unsigned long long)mine);
 }
 
 // Plan time: the first rows of the tiles the descriptors mark, appended in any order.
@@ -467,15 +484,15 @@ static hipError_t launch_vec_unroll(const spal_csr *a, const void *x, void *y, h
 }
 
 // stream kernel; its vector fallback for non-streamable super-tiles uses U = 2
-template <typename T, int TPW, int RPT>
+template <typename T, int TPW, int RPT, bool SKEW = false>
 static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     // the in-kernel vector fallback takes super-tiles with a tile of more than 1024 entries, i.e. with heavy
     // rows: a wave per row, four (colind, value) pairs per lane in flight (any geometry is correct)
     constexpr int L = 64;
     const CsrPlan &p = a->plan;
     const uint32_t per_xcd = (p.nblocks + 7) / 8;
-    const size_t lds = ((size_t)kStreamWaves * kStreamTileNnz + p.lds_entries) * sizeof(T);
-    auto kern = csr_spmv_stream<T, L, 1, true, TPW, RPT>;
+    const size_t lds = ((size_t)kStreamWaves * stream_strip<SKEW>() + p.lds_entries) * sizeof(T);
+    auto kern = csr_spmv_stream<T, L, 1, true, TPW, RPT, SKEW>;
     static std::atomic<uint64_t> configured{0};
     hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
     if (e != hipSuccess) return e;
@@ -487,12 +504,12 @@ static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, h
 }
 
 // persistent form: 2 workgroups per CU, contiguous chunks of each XCD's run
-template <typename T, int RPT>
+template <typename T, int RPT, bool SKEW = false>
 static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     constexpr int L = 64;
     const CsrPlan &p = a->plan;
     const uint32_t per_xcd = (p.nblocks + 7) / 8;
-    const size_t lds = ((size_t)kStreamWaves * kStreamTileNnz + p.lds_entries) * sizeof(T);
+    const size_t lds = ((size_t)kStreamWaves * stream_strip<SKEW>() + p.lds_entries) * sizeof(T);
     // grid: as many workgroups as the device holds at once -- 160 KiB of LDS per CU decide
     // (f64 band: 2 per CU = 512; f32, whose strips and window are half the size: 4 per CU)
     int grid = p.persistent_blocks;
@@ -503,7 +520,7 @@ static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, voi
     const uint32_t slots = (uint32_t)std::max(1, grid / 8);                   // workgroups per XCD
     const uint32_t chunk = (per_xcd + slots - 1) / slots;
     const uint32_t used = (per_xcd + chunk - 1) / chunk;                      // non-empty slots
-    auto kern = csr_spmv_stream_persistent<T, L, 1, true, 4, RPT>;
+    auto kern = csr_spmv_stream_persistent<T, L, 1, true, 4, RPT, SKEW>;
     static std::atomic<uint64_t> configured{0};
     hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
     if (e != hipSuccess) return e;
@@ -537,12 +554,19 @@ template <typename T>
 static hipError_t launch_stream_main(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     const CsrPlan &p = a->plan;
     if (p.tiles_per_wave == 8) return launch_stream_tpw<T, 8, 64>(a, x, y, st);  // (64-row tiles only)
+#define SPAL_STREAM_CASE(RPT, SKEW) \
+    case RPT: return p.persistent ? launch_stream_persistent<T, RPT, SKEW>(a, x, y, st) : launch_stream_tpw<T, 4, RPT, SKEW>(a, x, y, st);
+    if (p.skew) {
+        switch (p.rows_per_tile) {
+            SPAL_STREAM_CASE(64, true) SPAL_STREAM_CASE(32, true) SPAL_STREAM_CASE(16, true) SPAL_STREAM_CASE(8, true)
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (p.rows_per_tile) {
-        case 64: return p.persistent ? launch_stream_persistent<T, 64>(a, x, y, st) : launch_stream_tpw<T, 4, 64>(a, x, y, st);
-        case 32: return p.persistent ? launch_stream_persistent<T, 32>(a, x, y, st) : launch_stream_tpw<T, 4, 32>(a, x, y, st);
-        case 16: return p.persistent ? launch_stream_persistent<T, 16>(a, x, y, st) : launch_stream_tpw<T, 4, 16>(a, x, y, st);
+        SPAL_STREAM_CASE(64, false) SPAL_STREAM_CASE(32, false) SPAL_STREAM_CASE(16, false) SPAL_STREAM_CASE(8, false)
         default: return hipErrorInvalidValue;
     }
+#undef SPAL_STREAM_CASE
 }
 
 template <typename T>
@@ -628,7 +652,8 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
     // page budgets: `small` keeps two workgroups per CU, `page_cap` (<= 64: page ids travel in a wave's lanes) one
     const uint32_t page_bytes = kPageCols * (uint32_t)a->elem_size;
     const uint32_t page_cap = std::min<uint32_t>(64u, kStreamBigWindowBytes / page_bytes);
-    const uint32_t small_cap = std::min<uint32_t>(page_cap, a->elem_size == 4 ? 64u : kStreamWindowBytes / page_bytes);
+    const uint32_t small_cap = std::min<uint32_t>(page_cap, a->plan.skew ? (a->elem_size == 4 ? 62u : kStreamWindowBytesSkew / page_bytes)
+                                                                          : (a->elem_size == 4 ? 64u : kStreamWindowBytes / page_bytes));
     uint32_t *d_pages = nullptr;
     uint4 *d_info = nullptr, *d_ok = nullptr;
     SPAL_HIP_TRY(dev_alloc((void **)&d_ok, (size_t)nb * sizeof(uint4)));
@@ -767,16 +792,17 @@ int csr_plan_build(spal_csr *a) {
     }
     const uint32_t valign = 16u / (uint32_t)a->elem_size;
 
-    // ---- stream kernel: rows short enough that 64 / 32 / 16 of them fit a tile and
-    // whose windows fit LDS (auto: at least half the rows).  Widest tile first.
-    // (measured crossover to the vector kernel: 54/row streams at 82 % vs 51 %, 64/row at 61 % vs 66 %)
-    if ((p.user_kernel == 0 && mean <= 56.0) || p.user_kernel == 2) {
+    // ---- stream kernel: rows short enough that 64 / 32 / 16 / 8 of them fit a tile (auto: at least half the
+    // rows in tiles that stream).  Measured against the vector kernel on bands (tools/lab_rpt8.py): 54/row 82 % vs
+    // 51 %, 63/row 84 % vs 47 %, 64/row 80 % (skewed strips) vs 50 %, 81/row 67 % vs 46 %, 100/row 71 % vs 54 %,
+    // 120/row 68 % vs 56 %; 4-row tiles for 150 ... 250/row were level with or behind the vector kernel.
+    if ((p.user_kernel == 0 && mean <= 120.0) || p.user_kernel == 2) {
         if (p.tiles_per_wave != 4 && p.tiles_per_wave != 8) p.tiles_per_wave = 4;
-        const int rpt_all[] = {64, 32, 16};
+        const int rpt_all[] = {64, 32, 16, 8};
         std::vector<int> rpts;
         if (p.user_rows_per_tile) rpts.push_back(p.rows_per_tile);
         else if (p.tiles_per_wave == 8) rpts.push_back(64);
-        else rpts.assign(rpt_all, rpt_all + 3);
+        else rpts.assign(rpt_all, rpt_all + 4);
         std::vector<uint4> desc, best_desc;
         uint32_t cap = 0, best_cap = 0;
         double frac = 0.0, best_frac = -1.0, best_cost = -1.0;
@@ -784,6 +810,19 @@ int csr_plan_build(spal_csr *a) {
         uint32_t *best_pages = nullptr;
         uint32_t n_over = 0, best_over = 0;
         std::vector<uint32_t> skip, best_skip;
+        if (!p.user_skew) {   // skewed product strips when most rows are a multiple of 128 bytes long (16 f64 / 32 f32 entries)
+            unsigned long long *d_cnt = nullptr, cnt = 0;
+            SPAL_HIP_TRY(dev_alloc((void **)&d_cnt, sizeof(unsigned long long)));
+            SPAL_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), a->stream));
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(2048, (a->nrows + 255) / 256);
+            hipLaunchKernelGGL(csr_count_aligned_rows, dim3(grid), dim3(256), 0, a->stream, a->d_rowptr,
+                               (uint32_t)a->nrows, 128u / (uint32_t)a->elem_size, d_cnt);
+            hipError_t e = hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, a->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
+            (void)dev_free(d_cnt);
+            SPAL_HIP_TRY(e);
+            p.skew = 2 * cnt > a->nrows ? 1 : 0;
+        }
         if (a->d_pages) { SPAL_HIP_TRY(dev_free(a->d_pages)); a->d_pages = nullptr; }
         if (a->d_ovtiles) { SPAL_HIP_TRY(dev_free(a->d_ovtiles)); a->d_ovtiles = nullptr; }
         a->n_ovtiles = 0;
@@ -817,7 +856,7 @@ int csr_plan_build(spal_csr *a) {
             // one workgroup per CU (the large page budget): nothing else on the CU hides a workgroup's
             // cold start, the persistent form does (band of 8192 columns: 400 vs 460 us)
             if (!p.user_persistent)
-                p.persistent = ((size_t)kStreamWaves * kStreamTileNnz + p.lds_entries) * a->elem_size > 80u * 1024u ? 1 : 0;
+                p.persistent = ((size_t)kStreamWaves * (p.skew ? stream_strip<true>() : stream_strip<false>()) + p.lds_entries) * a->elem_size > 80u * 1024u ? 1 : 0;
             p.stream_row_fraction = best_frac;
             uint64_t lds_rows = 0;
             for (uint32_t b = 0; b < p.nblocks; ++b)
@@ -1276,6 +1315,11 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         // at two workgroups per CU, or up to 60 at one when that is estimated to pay)
         if (value < 0 || value > 64) return fail(SPAL_ERR_INVALID_ARGUMENT, "window_pages must be in [0, 64]");
         p.window_pages = (int)value;
+    } else if (!strcmp(key, "skew")) {
+        // stream kernel: skewed product strips (-1 = automatic: when most rows are a multiple of 128 bytes long)
+        if (value < -1 || value > 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "skew must be -1 (auto), 0 or 1");
+        p.user_skew = value >= 0;
+        if (value >= 0) p.skew = (int)value;
     } else if (!strcmp(key, "stream_row_max")) {
         // stream kernel: a tile with a row longer than this is left to the overflow kernel
         if (value < 1 || value > 1024) return fail(SPAL_ERR_INVALID_ARGUMENT, "stream_row_max must be in [1, 1024]");
@@ -1293,8 +1337,8 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         p.persistent_blocks = (int)value;
     } else if (!strcmp(key, "rows_per_tile")) {
         if (value == 0) p.user_rows_per_tile = false;
-        else if (value != 64 && value != 32 && value != 16)
-            return fail(SPAL_ERR_INVALID_ARGUMENT, "rows_per_tile must be 0 (auto), 64, 32 or 16");
+        else if (value != 64 && value != 32 && value != 16 && value != 8)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "rows_per_tile must be 0 (auto), 64, 32, 16 or 8");
         else { p.rows_per_tile = (int)value; p.user_rows_per_tile = true; }
     } else if (!strcmp(key, "tiles_per_wave")) {
         if (value != 4 && value != 8) return fail(SPAL_ERR_INVALID_ARGUMENT, "tiles_per_wave must be 4 or 8");
@@ -1327,13 +1371,13 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "\"index_bits\": %d, \"kernel\": \"%s\", \"lanes_per_row\": %d, \"unroll\": %d, "
              "\"rows_per_block\": %d, \"rows_per_tile\": %d, \"blocks\": %u, \"threads_per_block\": %d, \"lds_x\": %d, "
              "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f, "
-             "\"overflow_tiles\": %u, \"persistent\": %d, \"nt_store\": %d, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f]}",
+             "\"overflow_tiles\": %u, \"skew\": %d, \"persistent\": %d, \"nt_store\": %d, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f]}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, p.kernel == 2 ? 16 : 32,
              p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
              p.rows_per_block, p.kernel == 2 ? p.rows_per_tile : 0, p.nblocks, p.threads, p.lds_x,
              (unsigned long long)p.lds_entries * (unsigned long long)a->elem_size, p.lds_row_fraction,
-             p.stream_row_fraction, p.kernel == 2 ? a->n_ovtiles : 0u,
+             p.stream_row_fraction, p.kernel == 2 ? a->n_ovtiles : 0u, (p.kernel == 2 && p.skew) ? 1 : 0,
              (p.kernel == 2 && p.persistent && p.tiles_per_wave == 4) ? 1 : 0,
              (p.kernel == 2 && p.nt_store) ? 1 : 0, (double)a->tuned_us[0], (double)a->tuned_us[1],
              (double)a->tuned_us[2], (double)a->tuned_us[3]);

@@ -96,6 +96,8 @@ struct CsrPlan {
     int rows_per_tile = 64;  // stream kernel: rows of a wave-tile (64, 32 or 16)
     int persistent = 0;      // stream kernel: fixed grid walking chunks of super-tiles
     int nt_store = 0;        // stream kernel: non-temporal stores of y
+    int skew = 0;            // stream kernel: skewed product strips (rows a multiple of 128 bytes long: LDS bank conflicts)
+    bool user_skew = false;
     int stream_row_max = 128; // stream kernel: tiles with a longer row go to the overflow kernel (a lane sums a row)
     int window_pages = 0;    // stream kernel: page budget of a super-tile's LDS x window (0 = automatic)
     int stream_global = 1;   // stream kernel: super-tiles whose pages exceed the LDS budget gather x from global

@@ -135,6 +135,37 @@ def test_stream_kernel_narrow_tiles_bit_identical(oracle, maxlen, rpt, dtype):
         same(dev.spmv(x), d2["stream_row_fraction"])
 
 
+@pytest.mark.parametrize("per_row,dtype,rpt,skew", [(16, np.float64, 64, 1), (32, np.float64, 32, 1), (64, np.float64, 16, 1),
+                                                    (96, np.float64, 8, 1), (100, np.float64, 8, 0), (81, np.float32, 8, 0),
+                                                    (32, np.float32, 32, 1), (15, np.float64, 64, 0)])
+def test_stream_kernel_bank_skew_and_8_row_tiles(oracle, per_row, dtype, rpt, skew):
+    """Rows whose length is a multiple of 128 bytes get skewed product strips (their lanes would sum through one
+    LDS bank otherwise); rows of 65 ... 120 entries stream in tiles of 8 rows.  Both are layout / geometry only:
+    every form stays bit-identical to the reference order."""
+    n = 40_003
+    rp, ci, va = sp.synth.banded_csr(n, n, per_row, 2048, 40 + per_row, dtype=dtype)
+    x = sp.synth.vector(n, dtype=dtype)
+    dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    d = dev.describe()
+    assert d["kernel"] == "stream" and d["rows_per_tile"] == rpt and d["skew"] == skew, d
+    assert d["stream_row_fraction"] == 1.0 and d["overflow_tiles"] == 0, d
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    for sk in (skew, 1 - skew):
+        dev.set_option("skew", sk)
+        assert dev.describe()["skew"] == sk
+        for persistent in (0, 1):
+            dev.set_option("persistent", persistent)
+            assert np.array_equal(dev.spmv(x), y_ref)
+    dev.set_option("skew", -1)
+    assert dev.describe()["skew"] == skew
+    # the same rows with columns all over the matrix: x through L2 (32-bit columns), same strips
+    rp, ci, va = sp.synth.banded_csr(n, n, per_row, n, 41 + per_row, dtype=dtype)
+    dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    d = dev.describe()
+    assert d["kernel"] == "stream" and d["skew"] == skew and d["lds_row_fraction"] == 0.0, d
+    assert np.array_equal(dev.spmv(x), oracle.csr_spmv(rp, ci, va, x))
+
+
 def test_stream_global_mode_bit_identical(oracle):
     """column windows too wide for LDS: the stream kernel gathers x through L2
     instead (32-bit columns), still summing each row in the reference order."""
@@ -225,6 +256,14 @@ def test_oversized_tiles_go_to_the_overflow_kernel(oracle, dtype, rpt):
         assert d["overflow_tiles"] == int(big.sum()) > 0
         y = dev.spmv(x)
         assert np.array_equal(y[light], y_ref[light])
+    # the row-length criterion is an option: at 1024 only the tiles that cannot fit the strip are left
+    dev.set_option("stream_row_max", 1024)
+    only_size = (rp[ends] - (rp[starts] & ~np.uint64(1))) > 1024
+    assert dev.describe()["overflow_tiles"] == int(only_size.sum()) < int(big.sum())
+    bound = oracle.csr_abs_bound(rp, ci, va.astype(np.float64), x.astype(np.float64))
+    assert_spmv_close(dev.spmv(x), y_ref, bound, TOL[va.dtype])
+    with pytest.raises(Exception):
+        dev.set_option("stream_row_max", 0)
 
 
 @pytest.mark.parametrize("lanes", [2, 4, 8, 16, 32, 64])
