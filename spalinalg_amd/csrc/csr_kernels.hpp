@@ -217,8 +217,8 @@ __device__ __forceinline__ RowStep<U> load_rows(const uint32_t *__restrict__ row
     return o;
 }
 
-template <typename T, int U>
-__device__ __forceinline__ EntryStep<T, U> load_entries(const uint32_t *__restrict__ colind,
+template <typename T, int U, typename CI = uint32_t>
+__device__ __forceinline__ EntryStep<T, U> load_entries(const CI *__restrict__ colind,
                                                         const T *__restrict__ vals,
                                                         const RowStep<U> &rs, uint32_t last_nz) {
     EntryStep<T, U> o;
@@ -231,9 +231,11 @@ __device__ __forceinline__ EntryStep<T, U> load_entries(const uint32_t *__restri
     return o;
 }
 
-template <typename T, int L, int U, bool INLDS, bool USE_DPP, int BLOCK, int LB = 1>
+// CI = uint16_t: `colind` holds columns relative to the block's LDS window (column - cbase), 2 bytes per entry
+// instead of 4 (INLDS only).
+template <typename T, int L, int U, bool INLDS, bool USE_DPP, int BLOCK, int LB = 1, typename CI = uint32_t>
 __device__ __forceinline__ void vector_rows(const uint32_t *__restrict__ rowptr,
-                                            const uint32_t *__restrict__ colind,
+                                            const CI *__restrict__ colind,
                                             const T *__restrict__ vals, const T *__restrict__ x,
                                             const T *xw, T *__restrict__ y, uint32_t row0,
                                             uint32_t row1, uint32_t cbase, uint32_t last_nz) {
@@ -243,6 +245,9 @@ __device__ __forceinline__ void vector_rows(const uint32_t *__restrict__ rowptr,
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = threadIdx.x / kWave;
     const uint32_t g = lane / L, s = lane % L;
+    constexpr bool REL = sizeof(CI) == 2;            // columns already relative to the window
+    static_assert(!REL || INLDS, "16-bit columns address the LDS window");
+    const uint32_t coff = REL ? 0u : cbase;          // what to subtract from a column / an idle lane's column
 
     uint32_t base = row0 + wave * (G * U);
     if (base >= row1) return;  // wave-uniform
@@ -262,8 +267,8 @@ __device__ __forceinline__ void vector_rows(const uint32_t *__restrict__ rowptr,
         for (int u = 0; u < U; ++u) {
             live[u] = rs.p[u] < rs.e[u];
             // an idle lane's clamped column may lie outside this block's window
-            const uint32_t cc = live[u] ? es.c[u] : cbase;
-            xv[u] = INLDS ? xw[cc - cbase] : x[cc];
+            const uint32_t cc = live[u] ? es.c[u] : coff;
+            xv[u] = INLDS ? xw[cc - coff] : x[cc];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -280,7 +285,7 @@ __device__ __forceinline__ void vector_rows(const uint32_t *__restrict__ rowptr,
                 for (uint32_t q = rs.p[u] + L; q < rs.e[u]; q += L) {
                     const uint32_t cc = load_stream(colind + q);
                     const T vv = load_stream(vals + q);
-                    const T xv = INLDS ? xw[cc - cbase] : x[cc];
+                    const T xv = INLDS ? xw[cc - coff] : x[cc];
                     acc[u] = __builtin_fma(vv, xv, acc[u]);
                 }
             }
@@ -304,8 +309,8 @@ __device__ __forceinline__ void vector_rows(const uint32_t *__restrict__ rowptr,
 #pragma unroll
                     for (int k = 0; k < LB; ++k) {
                         const bool live4 = q + k * L < e;
-                        const uint32_t c4 = live4 ? cc[k] : cbase;
-                        xv[k] = INLDS ? xw[c4 - cbase] : x[c4];
+                        const uint32_t c4 = live4 ? cc[k] : coff;
+                        xv[k] = INLDS ? xw[c4 - coff] : x[c4];
                     }
 #pragma unroll
                     for (int k = 0; k < LB; ++k) {
@@ -359,6 +364,34 @@ __global__ __launch_bounds__(BLOCK, 8) void csr_spmv_vector(
     }
     vector_rows<T, L, U, false, USE_DPP, BLOCK, LB>(rowptr, colind, vals, x, nullptr, y, row0, row1, 0u,
                                                     last_nz);
+}
+
+// The long-row form of the vector kernel with 16-bit columns: blocks whose x window is in LDS read `col16`
+// (column - window base, written by csr_encode_col16_window at plan time) -- 10 instead of 12 bytes per entry,
+// and these rows run at the HBM rate (400 entries per row: 5.2 TB/s actual with 32-bit columns); the other blocks
+// read the 32-bit columns and gather x from global memory.  A wave per row (L = 64, or 32), one row group in flight.
+template <typename T, int L, int BLOCK, int LB>
+__global__ __launch_bounds__(BLOCK, 8) void csr_spmv_vector_col16(
+    const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
+    const uint16_t *__restrict__ col16, const T *__restrict__ vals, const T *__restrict__ x,
+    T *__restrict__ y, const uint4 *__restrict__ desc, uint32_t nrows, uint32_t nnz, uint32_t R,
+    uint32_t nblocks, uint32_t per_xcd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
+    T *xw = reinterpret_cast<T *>(spal_smem);
+    const uint32_t b = xcd_contiguous_block(blockIdx.x, per_xcd);
+    if (b >= nblocks) return;
+    const uint32_t row0 = b * R;
+    const uint32_t row1 = min(row0 + R, nrows);
+    const uint32_t last_nz = nnz - 1;
+    const uint4 d = desc[b];  // block-uniform
+    if (d.z == kModeVectorLds) {
+        stage_window<T, BLOCK>(xw, x, d.x, d.y);
+        __syncthreads();
+        vector_rows<T, L, 1, true, true, BLOCK, LB, uint16_t>(rowptr, col16, vals, x, xw, y, row0, row1, d.x,
+                                                              last_nz);
+        return;
+    }
+    vector_rows<T, L, 1, false, true, BLOCK, LB>(rowptr, colind, vals, x, nullptr, y, row0, row1, 0u, last_nz);
 }
 
 // ---- the "stream" kernel: one lane per row, products parked in LDS ----------

@@ -393,6 +393,20 @@ __global__ __launch_bounds__(256) void csr_block_pages(
     if (t == 0) info[b] = make_uint4(cmin, cmax, s_count, s_count == span ? 1u : 0u);   // (every page of the span: a run after all)
 }
 
+// Vector plans with long rows: col16 = column - window base for the blocks (R rows) whose x window is in LDS.
+__global__ __launch_bounds__(256) void csr_encode_col16_window(const uint32_t *__restrict__ rowptr,
+                                                               const uint32_t *__restrict__ colind,
+                                                               const uint4 *__restrict__ desc,
+                                                               uint16_t *__restrict__ col16, uint32_t nrows,
+                                                               uint32_t R) {
+    const uint32_t b = blockIdx.x;
+    const uint4 d = desc[b];
+    if (d.z != kModeVectorLds) return;
+    const uint32_t row0 = b * R, row1 = min(row0 + R, nrows);
+    const uint32_t e0 = rowptr[row0], e1 = rowptr[row1];
+    for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) col16[e] = (uint16_t)(colind[e] - d.x);
+}
+
 // One workgroup per super-tile: col16 = slot of the column's page * kPageCols + column
 // inside the page (the slot by binary search in the super-tile's ascending page list).
 __global__ __launch_bounds__(256) void csr_encode_col16(const uint32_t *__restrict__ rowptr,
@@ -456,8 +470,29 @@ static hipError_t launch_vec(const spal_csr *a, const void *x, void *y, hipStrea
     return hipGetLastError();
 }
 
+// long rows, x windows in LDS: the kernel that reads 16-bit window-relative columns (plan: vec_col16)
+template <typename T, int L, int BLOCK>
+static hipError_t launch_vec_col16(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    const CsrPlan &p = a->plan;
+    const uint32_t per_xcd = (p.nblocks + 7) / 8;
+    const size_t lds = (size_t)p.lds_entries * sizeof(T);
+    auto kern = csr_spmv_vector_col16<T, L, BLOCK, 1>;   // (the batched rest-of-row loop, LB = 4, measured 10 ... 20 % slower here)
+    static std::atomic<uint64_t> configured{0};
+    hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(BLOCK), lds, st, a->d_rowptr, a->d_colind, a->d_col16,
+                       (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc, (uint32_t)a->nrows,
+                       (uint32_t)a->nnz, (uint32_t)p.rows_per_block, p.nblocks, per_xcd);
+    return hipGetLastError();
+}
+
 template <typename T, int L, int U, bool LDSX>
 static hipError_t launch_vec_block(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    if constexpr ((L == 64 || L == 32) && U == 1 && LDSX) {
+        if (a->plan.vec_col16)
+            return a->plan.threads == 1024 ? launch_vec_col16<T, L, 1024>(a, x, y, st)
+                                           : launch_vec_col16<T, L, 512>(a, x, y, st);
+    }
     if constexpr (L == 16) {  // the long-row form exists for 16 lanes per row only (the planner's choice)
         if (a->plan.long_rows)
             return a->plan.threads == 1024 ? launch_vec<T, L, U, LDSX, 1024, 4>(a, x, y, st)
@@ -783,6 +818,7 @@ int csr_plan_build(spal_csr *a) {
         a->d_desc = nullptr;
     }
     p.stream_row_fraction = 0.0;
+    p.vec_col16 = 0;
     if (a->nnz == 0) {
         p.kernel = 1;
         p.rows_per_block = 1024;
@@ -973,6 +1009,19 @@ int csr_plan_build(spal_csr *a) {
     SPAL_HIP_TRY(dev_alloc((void **)&a->d_desc, (size_t)p.nblocks * sizeof(uint4)));
     SPAL_HIP_TRY(hipMemcpy(a->d_desc, best_desc.data(), (size_t)p.nblocks * sizeof(uint4),
                            hipMemcpyHostToDevice));
+    // long rows with LDS windows (at most 64 KiB: 16 bits address them): 2-byte columns for those blocks
+    p.vec_col16 = (p.vec_col16_allowed && use_lds && p.long_rows && p.unroll == 1 &&
+                   (p.lanes_per_row == 64 || p.lanes_per_row == 32) && best_cap <= 65536u) ? 1 : 0;
+    if (p.vec_col16) {
+        if (!a->d_col16) {
+            SPAL_HIP_TRY(dev_alloc((void **)&a->d_col16, (size_t)a->cap_entries * sizeof(uint16_t)));
+            SPAL_HIP_TRY(hipMemsetAsync(a->d_col16, 0, (size_t)a->cap_entries * sizeof(uint16_t), a->stream));
+        }
+        hipLaunchKernelGGL(csr_encode_col16_window, dim3(p.nblocks), dim3(256), 0, a->stream, a->d_rowptr,
+                           a->d_colind, a->d_desc, a->d_col16, (uint32_t)a->nrows, best_R);
+        SPAL_HIP_TRY(hipGetLastError());
+        SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
+    }
     return SPAL_OK;
 }
 
@@ -1315,6 +1364,10 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         // at two workgroups per CU, or up to 60 at one when that is estimated to pay)
         if (value < 0 || value > 64) return fail(SPAL_ERR_INVALID_ARGUMENT, "window_pages must be in [0, 64]");
         p.window_pages = (int)value;
+    } else if (!strcmp(key, "col16")) {
+        // vector kernel, long rows: 16-bit window-relative columns for blocks whose x window is in LDS
+        if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "col16 must be 0 or 1");
+        p.vec_col16_allowed = (int)value;
     } else if (!strcmp(key, "skew")) {
         // stream kernel: skewed product strips (-1 = automatic: when most rows are a multiple of 128 bytes long)
         if (value < -1 || value > 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "skew must be -1 (auto), 0 or 1");
@@ -1373,7 +1426,7 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f, "
              "\"overflow_tiles\": %u, \"skew\": %d, \"persistent\": %d, \"nt_store\": %d, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f]}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
-             (unsigned long long)a->ncols, (unsigned long long)a->nnz, p.kernel == 2 ? 16 : 32,
+             (unsigned long long)a->ncols, (unsigned long long)a->nnz, (p.kernel == 2 || p.vec_col16) ? 16 : 32,
              p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
              p.rows_per_block, p.kernel == 2 ? p.rows_per_tile : 0, p.nblocks, p.threads, p.lds_x,
              (unsigned long long)p.lds_entries * (unsigned long long)a->elem_size, p.lds_row_fraction,

@@ -90,6 +90,8 @@ struct CsrPlan {
     bool user_persistent = false;  // `persistent` was set by the caller or by the autotune
     int lanes_per_row = 0;   // L in {2,4,8,16,32,64}
     int unroll = 1;          // row groups in flight per wave iteration
+    int vec_col16 = 0;       // vector kernel (long rows, LDS windows): reads 16-bit window-relative columns
+    int vec_col16_allowed = 1;
     int long_rows = 0;       // vector kernel: batched rest-of-row loop (mean row length above 64)
     int threads = 512;       // workgroup size: 512 or 1024
     int tiles_per_wave = 4;  // stream kernel: tiles per wave (4 or 8)

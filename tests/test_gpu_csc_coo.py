@@ -252,6 +252,46 @@ def test_coo_long_runs_and_skew(oracle):
     assemble_and_compare(oracle, 50, 4000, r, c, v)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_coo_assembly_randomised(oracle, seed):
+    """shapes, lengths, row skew, input order, duplicate and cancellation rates at random: arrays bit-exact
+    (whatever route -- group sort of some geometry or the general one -- the assembly takes), then y = A*x."""
+    rng = np.random.default_rng(7000 + seed)
+    dtype = np.float32 if seed % 4 == 3 else np.float64
+    nr = int(rng.choice([7, 300, 5000, 200_000, 1_500_000]))
+    nc = int(rng.choice([5, 4000, 300_000, 1_500_000]))
+    n = int(rng.choice([1, 1000, 200_000, 1_500_000]))
+    kind = seed % 4
+    if kind == 0:
+        r = rng.integers(0, nr, n)
+    elif kind == 1:      # power-law rows
+        r = np.minimum((rng.pareto(1.2, n) * nr / 50).astype(np.int64), nr - 1)
+    elif kind == 2:      # a handful of rows hold almost everything
+        r = np.where(rng.random(n) < 0.9, rng.integers(0, min(nr, 5), n), rng.integers(0, nr, n))
+    else:                # banded: columns near the row
+        r = rng.integers(0, nr, n)
+    c = rng.integers(0, nc, n) if kind != 3 else np.clip(r * nc // nr + rng.integers(-30, 30, n), 0, nc - 1)
+    v = rng.uniform(-1, 1, n).astype(dtype)
+    dup = rng.random(n) < rng.choice([0.0, 0.05, 0.5])          # duplicates of an earlier triplet ...
+    src = rng.integers(0, n, n)
+    r, c = np.where(dup, r[src], r), np.where(dup, c[src], c)
+    cancel = dup & (rng.random(n) < 0.3)                         # ... some of which cancel it exactly
+    v = np.where(cancel, -v[src], v).astype(dtype)
+    v[rng.random(n) < 0.02] = 0.0
+    order = rng.choice(3)
+    if order == 1:
+        o = np.lexsort((c, r))
+        r, c, v = r[o], c[o], v[o]
+    elif order == 2:
+        o = np.lexsort((c, r))[::-1]
+        r, c, v = r[o], c[o], v[o]
+    csr = assemble_and_compare(oracle, nr, nc, r.astype(np.uint64), c.astype(np.uint64), v)
+    x = rng.uniform(-1, 1, nc).astype(dtype)
+    rp, ci, va = csr.rowptr(), csr.colind(), csr.values()
+    bound = oracle.csr_abs_bound(rp, ci, va.astype(np.float64), x.astype(np.float64))
+    assert_spmv_close(csr * x, oracle.csr_spmv(rp, ci, va, x), bound, 1e-10 if dtype == np.float64 else 1e-4)
+
+
 def test_coo_out_of_bounds_panics():
     with pytest.raises(sp.Panic):
         sp.CooMatrix.with_triplets(2, 2, [0, 2], [0, 0], np.array([1.0, 2.0]))

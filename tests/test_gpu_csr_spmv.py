@@ -195,6 +195,33 @@ def test_long_rows_go_to_the_vector_kernel(oracle):
     assert dev.describe()["kernel"] == "vector"
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_long_rows_read_16_bit_columns(oracle, dtype):
+    """rows of hundreds of entries: the vector kernel, a wave per row, with 16-bit window-relative columns where the
+    block's x window is in LDS -- the index width changes nothing in the arithmetic."""
+    n = 30_011
+    rp, ci, va = sp.synth.banded_csr(n, n, 250, 4096, 77, dtype=dtype)
+    rp = rp.astype(np.int64)
+    ci, va = list(np.split(ci, rp[1:-1])), list(np.split(va, rp[1:-1]))
+    rng = np.random.default_rng(3)
+    for r in (5, 12_000, n - 1):          # rows whose columns are all over the matrix: their blocks gather from global memory
+        ci[r] = np.sort(rng.choice(n, 250, replace=False)).astype(np.uint64)
+    rp = np.concatenate([[0], np.cumsum([c.size for c in ci])]).astype(np.uint64)
+    ci, va = np.concatenate(ci), np.concatenate(va)
+    x = sp.synth.vector(n, dtype=dtype)
+    dev = check(oracle, rp, ci, va, x, n)
+    d = dev.describe()
+    assert d["kernel"] == "vector" and d["index_bits"] == 16 and 0.9 < d["lds_row_fraction"] < 1.0, d
+    y16 = dev.spmv(x)
+    dev.set_option("col16", 0)
+    assert dev.describe()["index_bits"] == 32
+    assert np.array_equal(dev.spmv(x), y16)
+    dev.set_option("col16", 1)
+    for threads in (512, 1024):
+        dev.set_option("threads", threads)
+        assert np.array_equal(dev.spmv(x), y16)
+
+
 def test_stream_kernel_mixed_supertiles(oracle):
     """a few heavy rows take their tiles out of the stream path (overflow kernel); one wide row forces
     the global-gather mode."""

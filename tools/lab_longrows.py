@@ -22,7 +22,12 @@ def main():
         y = torch.empty(n, dtype=torch.float64, device="cuda")
         t = timeit(lambda: dev.spmv_torch(x, out=y))
         d = dev.describe()
-        print(f"{per}/row n={n} nnz={nnz}: auto {t*1e3:8.1f} us = {100*B/(t*1e-3)/8e12:5.1f} %  [{d['kernel']} L={d['lanes_per_row']} U={d['unroll']} R={d['rows_per_block']} lds={d['lds_x']}]", flush=True)
+        print(f"{per}/row n={n} nnz={nnz}: auto {t*1e3:8.1f} us = {100*B/(t*1e-3)/8e12:5.1f} %  [{d['kernel']} L={d['lanes_per_row']} U={d['unroll']} R={d['rows_per_block']} lds={d['lds_x']} index_bits={d['index_bits']}]", flush=True)
+        if d["kernel"] == "vector":      # the same plan with 32-bit columns, and back
+            for col16 in (0, 1, 0, 1):
+                dev.set_option("col16", col16)
+                t = timeit(lambda: dev.spmv_torch(x, out=y))
+                print(f"    col16={col16}: {t*1e3:8.1f} us = {100*B/(t*1e-3)/8e12:5.1f} %  [index_bits={dev.describe()['index_bits']}]", flush=True)
         for L in ():
             for U in (1, 2, 4):
                 for R in (64, 128, 256, 512, 1024):
