@@ -28,6 +28,20 @@ def main():
                 dev.set_option("col16", col16)
                 t = timeit(lambda: dev.spmv_torch(x, out=y))
                 print(f"    col16={col16}: {t*1e3:8.1f} us = {100*B/(t*1e-3)/8e12:5.1f} %  [index_bits={dev.describe()['index_bits']}]", flush=True)
+        if "sweep" in sys.argv[1:] and d["kernel"] == "vector":
+            for threads in (512, 1024):
+                for R in (32, 64, 128, 256, 512, 1024):
+                    try:
+                        dev.set_option("threads", threads)
+                        dev.set_option("rows_per_block", R)
+                    except Exception as exc:  # noqa: BLE001
+                        print("   ", threads, R, "refused:", exc)
+                        continue
+                    t = timeit(lambda: dev.spmv_torch(x, out=y), iters=20)
+                    dd = dev.describe()
+                    print(f"    threads={threads} R={R:4d}: {t*1e3:8.1f} us = {100*B/(t*1e-3)/8e12:5.1f} %  [L={dd['lanes_per_row']} U={dd['unroll']} lds={dd['lds_x']} bits={dd['index_bits']}]", flush=True)
+            dev.set_option("rows_per_block", 0)
+            dev.set_option("threads", 0)
         for L in ():
             for U in (1, 2, 4):
                 for R in (64, 128, 256, 512, 1024):

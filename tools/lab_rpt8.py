@@ -29,7 +29,8 @@ def main():
                      [("kernel", 2), ("stream_row_max", 256), ("rows_per_tile", 8), ("persistent", 0)])
         pow2_opts = ([("kernel", 0)], [("kernel", 2), ("persistent", 0), ("skew", 0)], [("skew", 1)], [("skew", -1), ("kernel", 1)])
         for opts in pow2_opts if "pow2" in sys.argv[1:] else long_opts if "long" in sys.argv[1:] else ([("kernel", 0)], [("kernel", 2), ("rows_per_tile", 16), ("persistent", 0)],
-                     [("kernel", 2), ("rows_per_tile", 8), ("persistent", 0)], [("kernel", 2), ("rows_per_tile", 8), ("persistent", 1)]):
+                     [("kernel", 2), ("rows_per_tile", 8), ("persistent", 0)], [("kernel", 2), ("rows_per_tile", 8), ("persistent", 1)],
+                     [("rows_per_tile", 0), ("kernel", 1)], [("kernel", 0)]):
             for k, v in opts:
                 dev.set_option(k, v)
             t = timeit(lambda: dev.spmv_torch(x, out=y))
