@@ -957,6 +957,22 @@ int csr_plan_build(spal_csr *a) {
         // that there are workgroups enough for 256 CUs -- 4096 rows of 400 entries were 61 workgroups
         uint32_t r0 = 1024;
         while (r0 > 64 && (double)r0 * mean > 131072.0) r0 >>= 1;
+        // ... and a number of workgroups that fills whole rounds of the 512 the device holds at once (two of 1024
+        // threads per CU): these launches are two or three rounds long, and 1250 workgroups (2.44 rounds) ran at
+        // 60 ... 67 % where 980 (1.9 rounds) ran at 73 ... 78 % (tools/lab_longrows.py threads).  R need not be
+        // a power of two.
+        if (p.threads == 1024) {
+            const double want = std::max(1.0, (double)a->nnz / 100000.0);              // workgroups of ~100 000 entries
+            const uint64_t rounds = std::max<uint64_t>(1, (uint64_t)(want / 512.0 + 0.5));
+            // (98 % of the slots, rounded down by taking R up to a multiple of 16: a launch planned to the last slot
+            // spills into one more round -- 200 entries per row: 947 ... 977 workgroups 213 ... 218 us, 1009 of them
+            // 232 ... 240 us -- and an R that gives some waves one row more than others costs as much: 1500 per
+            // row, R = 64: 162 ... 168 us, R = 68 or 72: 174 us)
+            const uint64_t nb = rounds * 502;
+            uint64_t R = (a->nrows + nb - 1) / nb;
+            R = std::min<uint64_t>(4096, std::max<uint64_t>(16, (R + 15) / 16 * 16));   // 16 waves, the same number of rows each
+            cands.push_back((uint32_t)R);
+        }
         cands.push_back(r0);
         if (r0 > 64) cands.push_back(r0 >> 1);
     } else {
@@ -1340,8 +1356,8 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         }
     } else if (!strcmp(key, "rows_per_block")) {
         if (value == 0) p.user_rows_per_block = false;
-        else if (value < 64 || value > 65536 || (value & (value - 1)))
-            return fail(SPAL_ERR_INVALID_ARGUMENT, "rows_per_block must be a power of two in [64, 65536]");
+        else if (value < 16 || value > 65536 || (value % 16))
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "rows_per_block must be a multiple of 16 in [16, 65536]");
         else { p.rows_per_block = (int)value; p.user_rows_per_block = true; }
     } else if (!strcmp(key, "lanes_per_row")) {
         if (value == 0) p.user_lanes = false;

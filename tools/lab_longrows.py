@@ -13,7 +13,12 @@ from tools.lab_zoo import from_lens, timeit  # noqa: E402
 
 def main():
     rng = np.random.default_rng(5)
-    for per, n, W in ((70, 1_400_000, 2048), (100, 1_000_000, 2048), (200, 500_000, 4096), (400, 250_000, 4096), (1500, 64_000, 8192)):
+    cases = ((70, 1_400_000, 2048), (100, 1_000_000, 2048), (200, 500_000, 4096), (400, 250_000, 4096), (1500, 64_000, 8192))
+    if "rsweep" in sys.argv[1:]:
+        cases = ((200, 500_000, 4096),)
+    elif "threads" in sys.argv[1:]:
+        cases = ((150, 640_000, 4096), (300, 320_000, 4096), (400, 250_000, 4096), (600, 160_000, 4096), (800, 120_000, 4096), (1000, 96_000, 8192))
+    for per, n, W in cases:
         rp, ci, va = from_lens(np.full(n, per, np.int64), lambda r, p, g: np.clip(r - W // 2 + g.integers(0, W, r.size), 0, n - 1), rng)
         nnz = int(rp[-1])
         B = sp.synth.spmv_bytes(nnz, n, n, n, 8)
@@ -28,6 +33,20 @@ def main():
                 dev.set_option("col16", col16)
                 t = timeit(lambda: dev.spmv_torch(x, out=y))
                 print(f"    col16={col16}: {t*1e3:8.1f} us = {100*B/(t*1e-3)/8e12:5.1f} %  [index_bits={dev.describe()['index_bits']}]", flush=True)
+        if "rsweep" in sys.argv[1:] and d["kernel"] == "vector":
+            for R in (448, 480, 496, 512, 528, 576, 640, 496, 512):
+                dev.set_option("rows_per_block", R)
+                t = timeit(lambda: dev.spmv_torch(x, out=y), iters=20)
+                dd = dev.describe()
+                print(f"    R={R}: {t*1e3:8.1f} us = {100*B/(t*1e-3)/8e12:5.1f} %  [blocks={dd['blocks']} win={dd['lds_window_bytes']} bits={dd['index_bits']}]", flush=True)
+            continue
+        if "threads" in sys.argv[1:] and d["kernel"] == "vector":
+            for threads in (512, 1024, 512, 1024):
+                dev.set_option("threads", threads)
+                t = timeit(lambda: dev.spmv_torch(x, out=y), iters=20)
+                dd = dev.describe()
+                print(f"    threads={threads}: {t*1e3:8.1f} us = {100*B/(t*1e-3)/8e12:5.1f} %  [R={dd['rows_per_block']} lds={dd['lds_x']} bits={dd['index_bits']}]", flush=True)
+            continue
         if "sweep" in sys.argv[1:] and d["kernel"] == "vector":
             for threads in (512, 1024):
                 for R in (32, 64, 128, 256, 512, 1024):
