@@ -315,7 +315,7 @@ def test_every_lane_width_and_unroll(oracle, lanes, unroll):
         check(oracle, rp, ci, va, x, nc, kernel=2, lanes_per_row=lanes, persistent=1)
 
 
-@pytest.mark.parametrize("rows_per_block", [64, 512, 2048, 4096, 16384])
+@pytest.mark.parametrize("rows_per_block", [16, 64, 80, 512, 1008, 2048, 4096, 16384])
 def test_rows_per_block_and_window_fallback(oracle, rows_per_block):
     """banded blocks use the LDS window; a few wide rows force the per-block
     global-gather fallback inside the same launch."""
