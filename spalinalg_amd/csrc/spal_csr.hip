@@ -594,12 +594,14 @@ static hipError_t launch_stream_main(const spal_csr *a, const void *x, void *y, 
     case RPT: return p.persistent ? launch_stream_persistent<T, RPT, SKEW>(a, x, y, st) : launch_stream_tpw<T, 4, RPT, SKEW>(a, x, y, st);
     if (p.skew) {
         switch (p.rows_per_tile) {
-            SPAL_STREAM_CASE(64, true) SPAL_STREAM_CASE(32, true) SPAL_STREAM_CASE(16, true) SPAL_STREAM_CASE(8, true)
+            SPAL_STREAM_CASE(64, true) SPAL_STREAM_CASE(32, true) SPAL_STREAM_CASE(24, true)
+            SPAL_STREAM_CASE(16, true) SPAL_STREAM_CASE(12, true) SPAL_STREAM_CASE(8, true)
             default: return hipErrorInvalidValue;
         }
     }
     switch (p.rows_per_tile) {
-        SPAL_STREAM_CASE(64, false) SPAL_STREAM_CASE(32, false) SPAL_STREAM_CASE(16, false) SPAL_STREAM_CASE(8, false)
+        SPAL_STREAM_CASE(64, false) SPAL_STREAM_CASE(32, false) SPAL_STREAM_CASE(24, false)
+        SPAL_STREAM_CASE(16, false) SPAL_STREAM_CASE(12, false) SPAL_STREAM_CASE(8, false)
         default: return hipErrorInvalidValue;
     }
 #undef SPAL_STREAM_CASE
@@ -829,17 +831,18 @@ int csr_plan_build(spal_csr *a) {
     }
     const uint32_t valign = 16u / (uint32_t)a->elem_size;
 
-    // ---- stream kernel: rows short enough that 64 / 32 / 16 / 8 of them fit a tile (auto: at least half the
-    // rows in tiles that stream).  Measured against the vector kernel on bands (tools/lab_rpt8.py): 54/row 82 % vs
+    // ---- stream kernel: rows short enough that 64 / 32 / 24 / 16 / 12 / 8 of them fit a tile (auto: at least half
+    // the rows in tiles that stream; fuller strips pay: 33/row 24 rows per tile 100 us vs 16 rows 109 us, 70/row
+    // 12 rows 143 us vs 8 rows 159 us, 81/row 155 vs 187 us).  Measured against the vector kernel on bands (tools/lab_rpt8.py): 54/row 82 % vs
     // 51 %, 63/row 84 % vs 47 %, 64/row 80 % (skewed strips) vs 50 %, 81/row 67 % vs 46 %, 100/row 71 % vs 54 %,
     // 120/row 68 % vs 56 %; 4-row tiles for 150 ... 250/row were level with or behind the vector kernel.
     if ((p.user_kernel == 0 && mean <= 120.0) || p.user_kernel == 2) {
         if (p.tiles_per_wave != 4 && p.tiles_per_wave != 8) p.tiles_per_wave = 4;
-        const int rpt_all[] = {64, 32, 16, 8};
+        const int rpt_all[] = {64, 32, 24, 16, 12, 8};   // (48 rows per tile measured behind 32: 20/row 124 vs 111 us)
         std::vector<int> rpts;
         if (p.user_rows_per_tile) rpts.push_back(p.rows_per_tile);
         else if (p.tiles_per_wave == 8) rpts.push_back(64);
-        else rpts.assign(rpt_all, rpt_all + 4);
+        else rpts.assign(rpt_all, rpt_all + 6);
         std::vector<uint4> desc, best_desc;
         uint32_t cap = 0, best_cap = 0;
         double frac = 0.0, best_frac = -1.0, best_cost = -1.0;
@@ -1407,8 +1410,8 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         p.persistent_blocks = (int)value;
     } else if (!strcmp(key, "rows_per_tile")) {
         if (value == 0) p.user_rows_per_tile = false;
-        else if (value != 64 && value != 32 && value != 16 && value != 8)
-            return fail(SPAL_ERR_INVALID_ARGUMENT, "rows_per_tile must be 0 (auto), 64, 32, 16 or 8");
+        else if (value != 64 && value != 32 && value != 24 && value != 16 && value != 12 && value != 8)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "rows_per_tile must be 0 (auto), 64, 32, 24, 16, 12 or 8");
         else { p.rows_per_tile = (int)value; p.user_rows_per_tile = true; }
     } else if (!strcmp(key, "tiles_per_wave")) {
         if (value != 4 && value != 8) return fail(SPAL_ERR_INVALID_ARGUMENT, "tiles_per_wave must be 4 or 8");

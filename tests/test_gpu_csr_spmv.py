@@ -136,7 +136,7 @@ def test_stream_kernel_narrow_tiles_bit_identical(oracle, maxlen, rpt, dtype):
 
 
 @pytest.mark.parametrize("per_row,dtype,rpt,skew", [(16, np.float64, 64, 1), (32, np.float64, 32, 1), (64, np.float64, 16, 1),
-                                                    (96, np.float64, 8, 1), (100, np.float64, 8, 0), (81, np.float32, 8, 0),
+                                                    (96, np.float64, 8, 1), (100, np.float64, 8, 0), (81, np.float32, 12, 0), (40, np.float64, 24, 0),
                                                     (32, np.float32, 32, 1), (15, np.float64, 64, 0)])
 def test_stream_kernel_bank_skew_and_8_row_tiles(oracle, per_row, dtype, rpt, skew):
     """Rows whose length is a multiple of 128 bytes get skewed product strips (their lanes would sum through one

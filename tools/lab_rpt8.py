@@ -17,6 +17,8 @@ def main():
         sizes = ((150, 640_000), (200, 480_000), (250, 400_000))
     if "pow2" in sys.argv[1:]:
         sizes = tuple((k, 3_000_000 if k <= 17 else 1_500_000 if k < 70 else 1_000_000) for k in (8, 15, 16, 24, 32, 48, 63, 64, 65, 81, 96, 100, 120))
+    if "mid" in sys.argv[1:]:
+        sizes = tuple((k, 3_000_000 if k <= 20 else 1_500_000 if k < 70 else 1_000_000) for k in (17, 20, 24, 33, 40, 48, 70, 81, 100))
     for per_row, n in sizes:
         rp, ci, va = sp.synth.banded_csr(n, n, per_row, 2048, 7)
         nnz = int(rp[-1])
@@ -27,8 +29,9 @@ def main():
         print(f"band {per_row}/row, W=2048, {n} rows: nnz {nnz}, floor {B/8e12*1e6:.1f} us", flush=True)
         long_opts = ([("kernel", 0)], [("kernel", 2), ("stream_row_max", 256), ("rows_per_tile", 4), ("persistent", 0)],
                      [("kernel", 2), ("stream_row_max", 256), ("rows_per_tile", 8), ("persistent", 0)])
+        mid_opts = ([("kernel", 0)], [("kernel", 0), ("persistent", 0)]) + tuple([("kernel", 2), ("rows_per_tile", r), ("persistent", 0)] for r in (64, 48, 32, 24, 16, 12, 8) if 128 <= r * per_row <= 1024)
         pow2_opts = ([("kernel", 0)], [("kernel", 2), ("persistent", 0), ("skew", 0)], [("skew", 1)], [("skew", -1), ("kernel", 1)])
-        for opts in pow2_opts if "pow2" in sys.argv[1:] else long_opts if "long" in sys.argv[1:] else ([("kernel", 0)], [("kernel", 2), ("rows_per_tile", 16), ("persistent", 0)],
+        for opts in mid_opts if "mid" in sys.argv[1:] else pow2_opts if "pow2" in sys.argv[1:] else long_opts if "long" in sys.argv[1:] else ([("kernel", 0)], [("kernel", 2), ("rows_per_tile", 16), ("persistent", 0)],
                      [("kernel", 2), ("rows_per_tile", 8), ("persistent", 0)], [("kernel", 2), ("rows_per_tile", 8), ("persistent", 1)],
                      [("rows_per_tile", 0), ("kernel", 1)], [("kernel", 0)]):
             for k, v in opts:
