@@ -215,7 +215,7 @@ static constexpr uint32_t kStreamWindowBytesSkew = 44 * 1024;
 // (band of 8192 columns, f64: 463 / 392 us against 722 us)
 static constexpr uint32_t kStreamBigWindowBytes = 120 * 1024;
 
-// One workgroup per super-tile: chk[b] = {skip bits, cost, entries, 0}.
+// One workgroup per super-tile: chk[b] = {skip bits, cost, entries, rows a multiple of 128 bytes long}.
 //  - skip: a bit per tile that the stream kernels must leave to csr_spmv_overflow -- it holds more entries
 //    than the product strip, or a row of more than row_max entries (the stream kernels sum a row per lane:
 //    such a row keeps 63 lanes waiting, 25 cycles per entry);
@@ -227,14 +227,24 @@ static constexpr uint32_t kStreamBigWindowBytes = 120 * 1024;
 constexpr uint32_t kTileFloorEntries = 512, kOverflowTileFixed = 1000;
 __global__ __launch_bounds__(256) void csr_stream_check(const uint32_t *__restrict__ rowptr,
                                                         uint32_t nrows, uint32_t R, uint32_t rpt,
-                                                        uint32_t row_max, uint4 *__restrict__ chk) {
+                                                        uint32_t row_max, uint32_t quantum,
+                                                        uint4 *__restrict__ chk) {
     __shared__ uint32_t s_long[32];
+    __shared__ uint32_t s_aligned;
     const uint32_t t = threadIdx.x, b = blockIdx.x;
     const uint32_t row0 = b * R, row1 = min(row0 + R, nrows);
     if (t < 32) s_long[t] = 0u;
+    if (t == 0) s_aligned = 0u;
     __syncthreads();
-    for (uint32_t r = row0 + t; r < row1; r += 256)
-        if (rowptr[r + 1] - rowptr[r] > row_max) s_long[(r - row0) / rpt] = 1u;   // (same value from every writer)
+    uint32_t aligned = 0;   // rows a non-zero multiple of `quantum` entries (128 bytes) long: see SKEW in csr_kernels.hpp
+    for (uint32_t r = row0 + t; r < row1; r += 256) {
+        const uint32_t len = rowptr[r + 1] - rowptr[r];
+        if (len > row_max) s_long[(r - row0) / rpt] = 1u;   // (same value from every writer)
+        aligned += (len != 0u && len % quantum == 0u) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) aligned += (uint32_t)__shfl_xor((int)aligned, o, 64);
+    if ((t & 63u) == 0 && aligned) atomicAdd(&s_aligned, aligned);
     __syncthreads();
     if (t < 64) {   // R / rpt <= 32 tiles
         const uint32_t r0 = row0 + t * rpt;
@@ -250,24 +260,8 @@ __global__ __launch_bounds__(256) void csr_stream_check(const uint32_t *__restri
         const uint64_t m = __ballot(bad);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cost += (uint32_t)__shfl_xor((int)cost, o, 64);
-        if (t == 0) chk[b] = make_uint4((uint32_t)m, cost, rowptr[row1] - rowptr[row0], 0u);
+        if (t == 0) chk[b] = make_uint4((uint32_t)m, cost, rowptr[row1] - rowptr[row0], s_aligned);
     }
-}
-
-// Plan time: how many rows are a (non-zero) multiple of `quantum` entries long -- of 128 bytes, the width of the
-// LDS banks: their lanes' sums would walk the product strip in lockstep through one bank (see SKEW in
-// csr_kernels.hpp).  (Multiples of 64 bytes only -- 8 or 24 f64 entries per row -- hit two banks: skewing those
-// measured 68 vs 66 % and 66 vs 74 %, so they are left alone.)
-__global__ __launch_bounds__(256) void csr_count_aligned_rows(const uint32_t *__restrict__ rowptr, uint32_t nrows,
-                                                              uint32_t quantum, unsigned long long *__restrict__ count) {
-    uint32_t mine = 0;
-    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < nrows; r += (uint64_t)gridDim.x * 256) {
-        const uint32_t len = rowptr[r + 1] - rowptr[r];
-        mine += (len != 0u && len % quantum == 0u) ? 1u : 0u;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mine += (uint32_t)__shfl_xor((int)mine, o, 64);
-    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(count, (unsigned long long)mine);
 }
 
 // Plan time: the first rows of the tiles the descriptors mark, appended in any order.
@@ -682,7 +676,7 @@ static int block_windows(spal_csr *a, uint32_t R, std::vector<uint2> &win) {
 // that can be streamed and fills `desc`.
 static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4> &desc, uint32_t &cap,
                        double &frac, uint32_t **out_pages, uint32_t &n_over, std::vector<uint32_t> &skip,
-                       double &cost) {
+                       double &cost, bool decide_skew) {
     *out_pages = nullptr;
     n_over = 0;
     const uint32_t nb = (uint32_t)((a->nrows + R - 1) / R);
@@ -690,15 +684,18 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
     // page budgets: `small` keeps two workgroups per CU, `page_cap` (<= 64: page ids travel in a wave's lanes) one
     const uint32_t page_bytes = kPageCols * (uint32_t)a->elem_size;
     const uint32_t page_cap = std::min<uint32_t>(64u, kStreamBigWindowBytes / page_bytes);
-    const uint32_t small_cap = std::min<uint32_t>(page_cap, a->plan.skew ? (a->elem_size == 4 ? 62u : kStreamWindowBytesSkew / page_bytes)
-                                                                          : (a->elem_size == 4 ? 64u : kStreamWindowBytes / page_bytes));
+    auto small_pages = [&]() {
+        return std::min<uint32_t>(page_cap, a->plan.skew ? (a->elem_size == 4 ? 62u : kStreamWindowBytesSkew / page_bytes)
+                                                         : (a->elem_size == 4 ? 64u : kStreamWindowBytes / page_bytes));
+    };
+    uint32_t small_cap = small_pages();
     uint32_t *d_pages = nullptr;
     uint4 *d_info = nullptr, *d_ok = nullptr;
     SPAL_HIP_TRY(dev_alloc((void **)&d_ok, (size_t)nb * sizeof(uint4)));
     SPAL_HIP_TRY(dev_alloc((void **)&d_info, (size_t)nb * sizeof(uint4)));
     SPAL_HIP_TRY(dev_alloc((void **)&d_pages, (size_t)nb * page_cap * 4));
     hipLaunchKernelGGL(csr_stream_check, dim3(nb), dim3(256), 0, a->stream, a->d_rowptr, (uint32_t)a->nrows, R,
-                       rpt, (uint32_t)a->plan.stream_row_max, d_ok);
+                       rpt, (uint32_t)a->plan.stream_row_max, 128u / (uint32_t)a->elem_size, d_ok);
     // column windows already known per 256 rows (e.g. handed over by the assembly): fold and pass them
     uint2 *d_win = nullptr;
     if (!a->win_base.empty() && R % kWinBase == 0) {
@@ -723,6 +720,13 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
     (void)dev_free(d_win);
     if (e != hipSuccess) { (void)dev_free(d_pages); }
     SPAL_HIP_TRY(e);
+    if (decide_skew) {   // skewed product strips when most rows are a multiple of 128 bytes long (16 f64 / 32 f32 entries)
+        uint64_t aligned = 0;
+        for (uint32_t b = 0; b < nb; ++b) aligned += chk[b].w;
+        a->plan.skew = 2 * aligned > a->nrows ? 1 : 0;
+        small_cap = small_pages();   // (the page kernel above ran with the budget of the previous setting: at worst
+                                     //  a super-tile of 23 or 24 pages gathers x through L2)
+    }
     const uint32_t budget = kStreamWindowBytes / (uint32_t)a->elem_size;
     const uint32_t valign = 16u / (uint32_t)a->elem_size;
     // which page budget?  Rows weighted by what their mode costs per entry, from measurements on bands
@@ -850,19 +854,6 @@ int csr_plan_build(spal_csr *a) {
         uint32_t *best_pages = nullptr;
         uint32_t n_over = 0, best_over = 0;
         std::vector<uint32_t> skip, best_skip;
-        if (!p.user_skew) {   // skewed product strips when most rows are a multiple of 128 bytes long (16 f64 / 32 f32 entries)
-            unsigned long long *d_cnt = nullptr, cnt = 0;
-            SPAL_HIP_TRY(dev_alloc((void **)&d_cnt, sizeof(unsigned long long)));
-            SPAL_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), a->stream));
-            const uint32_t grid = (uint32_t)std::min<uint64_t>(2048, (a->nrows + 255) / 256);
-            hipLaunchKernelGGL(csr_count_aligned_rows, dim3(grid), dim3(256), 0, a->stream, a->d_rowptr,
-                               (uint32_t)a->nrows, 128u / (uint32_t)a->elem_size, d_cnt);
-            hipError_t e = hipMemcpyAsync(&cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, a->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
-            (void)dev_free(d_cnt);
-            SPAL_HIP_TRY(e);
-            p.skew = 2 * cnt > a->nrows ? 1 : 0;
-        }
         if (a->d_pages) { SPAL_HIP_TRY(dev_free(a->d_pages)); a->d_pages = nullptr; }
         if (a->d_ovtiles) { SPAL_HIP_TRY(dev_free(a->d_ovtiles)); a->d_ovtiles = nullptr; }
         a->n_ovtiles = 0;
@@ -870,7 +861,7 @@ int csr_plan_build(spal_csr *a) {
             const uint32_t R = (uint32_t)stream_rows(p.tiles_per_wave, rpt);
             uint32_t *pg = nullptr;
             double cost = 0.0;
-            int st = stream_plan(a, R, (uint32_t)rpt, desc, cap, frac, &pg, n_over, skip, cost);
+            int st = stream_plan(a, R, (uint32_t)rpt, desc, cap, frac, &pg, n_over, skip, cost, !p.user_skew && rpt == rpts[0]);
             if (st != SPAL_OK) { (void)dev_free(best_pages); return st; }
             if (best_cost < 0.0 || cost < 0.95 * best_cost) {  // a narrower tile must be estimated cheaper (see csr_stream_check)
                 best_cost = cost;
