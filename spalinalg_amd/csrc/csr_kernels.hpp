@@ -414,14 +414,14 @@ __global__ __launch_bounds__(BLOCK, 8) void csr_spmv_vector_col16(
 // About 0.17 wave-instructions per stored entry against 1.1 for the vector
 // kernel, and 10 instead of 12 bytes per entry from HBM.
 //
-// A super-tile is streamable when every 64-row tile has at most
-// kStreamTileNnz entries and its column span fits the LDS window; others are
-// done by vector_rows() in the same launch (block-uniform branch).
+// A super-tile streams out of LDS when the pages of x its rows touch fit the window budget (otherwise the
+// same pipeline gathers x from global memory: stream_global_super_tile); a TILE that holds more than
+// kStreamTileNnz entries or a very long row is skipped here and left to csr_spmv_overflow (below).
 constexpr int kStreamBlock = 256;
 constexpr int kStreamWaves = kStreamBlock / kWave;                          // 4
-// A tile holds RPT rows (64, 32 or 16: one lane per row, the other lanes idle
+// A tile holds RPT rows (64, 32, 24, 16, 12 or 8: one lane per row, the other lanes idle
 // in the reduction) and at most kStreamTileNnz entries; narrower tiles let
-// matrices with up to ~64 entries per row stream as well.
+// matrices with up to ~120 entries per row stream as well.
 // rows of a super-tile when every wave owns TPW tiles of RPT rows (4 x 64: 1024)
 constexpr int stream_rows(int tpw, int rpt = 64) { return kStreamWaves * tpw * rpt; }
 constexpr int kStreamSteps = 8;                                             // 128 entries per step
