@@ -464,11 +464,60 @@ __device__ __forceinline__ uint32_t wave_skip_mask(uint32_t bits, uint32_t wave)
     return (bits >> (wave * TPW)) & ((1u << TPW) - 1u);
 }
 
+// A lane's left-to-right sum of the products of one row out of the wave's strip: the reads of four products go
+// out together, the adds stay in stored order (the order is the contract, the batching is not).
+template <typename T, bool SKEW>
+__device__ __forceinline__ T strip_row_sum(const T *prod, uint32_t off, uint32_t len) {
+    T acc = T(0);
+    if (len) {
+        acc = prod[strip_pos<T, SKEW>(off)];
+        uint32_t k = 1;
+        for (; k + 4 <= len; k += 4) {
+            const T p0 = prod[strip_pos<T, SKEW>(off + k)], p1 = prod[strip_pos<T, SKEW>(off + k + 1)],
+                    p2 = prod[strip_pos<T, SKEW>(off + k + 2)], p3 = prod[strip_pos<T, SKEW>(off + k + 3)];
+            acc = acc + p0;
+            acc = acc + p1;
+            acc = acc + p2;
+            acc = acc + p3;
+        }
+        for (; k < len; ++k) acc = acc + prod[strip_pos<T, SKEW>(off + k)];
+    }
+    return acc;
+}
+// ... and the stores of a tile's results: RPT <= 64 a row per lane, RPT = 128 the lane's two adjacent rows
+template <typename T, int RPT, bool SKEW, typename Tile>
+__device__ __forceinline__ void strip_sums_to_y(const Tile &t, const T *prod, T *__restrict__ y, uint32_t row0,
+                                                uint32_t row1, uint32_t lane, bool nt_store) {
+    const uint32_t rlast = min(row0 + (uint32_t)RPT, row1);
+    if constexpr (RPT > 64) {
+        const T acc0 = strip_row_sum<T, SKEW>(prod, t.rp0 - t.start, t.rp1 - t.rp0);
+        const T acc1 = strip_row_sum<T, SKEW>(prod, t.rp1 - t.start, t.rp2 - t.rp1);
+        __builtin_amdgcn_wave_barrier();  // the next tile's products overwrite this strip
+        const uint32_t r = row0 + 2 * lane;
+        if (r < rlast) {
+            if (nt_store) __builtin_nontemporal_store(acc0, &y[r]);
+            else y[r] = acc0;
+        }
+        if (r + 1 < rlast) {
+            if (nt_store) __builtin_nontemporal_store(acc1, &y[r + 1]);
+            else y[r + 1] = acc1;
+        }
+    } else {
+        const T acc = strip_row_sum<T, SKEW>(prod, t.rp0 - t.start, t.rp1 - t.rp0);
+        __builtin_amdgcn_wave_barrier();  // the next tile's products overwrite this strip
+        if (row0 + lane < rlast) {
+            if (nt_store) __builtin_nontemporal_store(acc, &y[row0 + lane]);  // y is written once, never re-read here
+            else y[row0 + lane] = acc;
+        }
+    }
+}
+
 template <typename T>
 struct StreamTile {
     typename Pair<T>::type v[kStreamSteps];
     uint32_t c[kStreamSteps];  // two 16-bit LDS-window positions (page slot * 256 + column inside the page)
     uint32_t rp0, rp1;         // rowptr[row], rowptr[row + 1] of this lane's row
+    uint32_t rp2;              // RPT = 128 (two adjacent rows per lane): rowptr[row + 2]
     uint32_t start;            // first loaded entry (tile start rounded down to even); wave-uniform
     uint32_t steps;            // 128-entry steps that hold entries of the tile; wave-uniform
 };
@@ -495,8 +544,14 @@ __device__ __forceinline__ void stream_load(StreamTile<T> &t, const uint32_t *__
     // ... then this lane's row bounds (needed only by the reduction).  Both
     // loads are unconditional: lanes past the tile's last row read
     // rowptr[rlast] twice, i.e. an empty row -- no select, hence no wait here.
-    t.rp0 = rowptr[min(row0 + lane, rlast)];
-    t.rp1 = rowptr[min(row0 + lane + 1, rlast)];
+    if constexpr (RPT > 64) {   // rows of very few entries: lane l owns the adjacent rows 2l and 2l + 1
+        t.rp0 = rowptr[min(row0 + 2 * lane, rlast)];
+        t.rp1 = rowptr[min(row0 + 2 * lane + 1, rlast)];
+        t.rp2 = rowptr[min(row0 + 2 * lane + 2, rlast)];
+    } else {
+        t.rp0 = rowptr[min(row0 + lane, rlast)];
+        t.rp1 = rowptr[min(row0 + lane + 1, rlast)];
+    }
 }
 
 template <typename T, int RPT, bool SKEW>
@@ -527,29 +582,7 @@ __device__ __forceinline__ void stream_compute(const StreamTile<T> &t, const T *
     // LDS executes a wave's instructions in order, only the compiler must not
     // move the reads above the writes
     __builtin_amdgcn_wave_barrier();
-    const uint32_t off = t.rp0 - t.start;
-    const uint32_t len = t.rp1 - t.rp0;
-    // left-to-right sum; the reads of four products go out together, the adds
-    // stay in stored order (the order is the contract, the batching is not)
-    T acc = T(0);
-    if (len) {
-        acc = prod[strip_pos<T, SKEW>(off)];
-        uint32_t k = 1;
-        for (; k + 4 <= len; k += 4) {
-            const T p0 = prod[strip_pos<T, SKEW>(off + k)], p1 = prod[strip_pos<T, SKEW>(off + k + 1)],
-                    p2 = prod[strip_pos<T, SKEW>(off + k + 2)], p3 = prod[strip_pos<T, SKEW>(off + k + 3)];
-            acc = acc + p0;
-            acc = acc + p1;
-            acc = acc + p2;
-            acc = acc + p3;
-        }
-        for (; k < len; ++k) acc = acc + prod[strip_pos<T, SKEW>(off + k)];
-    }
-    __builtin_amdgcn_wave_barrier();  // the next tile's products overwrite this strip
-    if (row0 + lane < min(row0 + (uint32_t)RPT, row1)) {
-        if (nt_store) __builtin_nontemporal_store(acc, &y[row0 + lane]);  // y is written once, never re-read here
-        else y[row0 + lane] = acc;
-    }
+    strip_sums_to_y<T, RPT, SKEW>(t, prod, y, row0, row1, lane, nt_store);
 }
 
 // ---- stream tiles whose x window does not fit LDS ------------------------------
@@ -561,7 +594,7 @@ struct StreamTileG {
     typename Pair<T>::type v[kStreamSteps];
     typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
     u32x2 c[kStreamSteps];     // two 32-bit columns
-    uint32_t rp0, rp1, start, steps;
+    uint32_t rp0, rp1, rp2, start, steps;
 };
 
 template <typename T, int RPT>
@@ -582,8 +615,14 @@ __device__ __forceinline__ void stream_load_g(StreamTileG<T> &t, const uint32_t 
                 reinterpret_cast<const typename StreamTileG<T>::u32x2 *>(colind + e0 + j * 128));
         }
     }
-    t.rp0 = rowptr[min(row0 + lane, rlast)];
-    t.rp1 = rowptr[min(row0 + lane + 1, rlast)];
+    if constexpr (RPT > 64) {   // rows of very few entries: lane l owns the adjacent rows 2l and 2l + 1
+        t.rp0 = rowptr[min(row0 + 2 * lane, rlast)];
+        t.rp1 = rowptr[min(row0 + 2 * lane + 1, rlast)];
+        t.rp2 = rowptr[min(row0 + 2 * lane + 2, rlast)];
+    } else {
+        t.rp0 = rowptr[min(row0 + lane, rlast)];
+        t.rp1 = rowptr[min(row0 + lane + 1, rlast)];
+    }
 }
 
 template <typename T, int RPT, bool SKEW>
@@ -616,27 +655,7 @@ __device__ __forceinline__ void stream_compute_g(const StreamTileG<T> &t, const 
         }
     }
     __builtin_amdgcn_wave_barrier();
-    const uint32_t off = t.rp0 - t.start;
-    const uint32_t len = t.rp1 - t.rp0;
-    T acc = T(0);
-    if (len) {
-        acc = prod[strip_pos<T, SKEW>(off)];
-        uint32_t k = 1;
-        for (; k + 4 <= len; k += 4) {
-            const T p0 = prod[strip_pos<T, SKEW>(off + k)], p1 = prod[strip_pos<T, SKEW>(off + k + 1)],
-                    p2 = prod[strip_pos<T, SKEW>(off + k + 2)], p3 = prod[strip_pos<T, SKEW>(off + k + 3)];
-            acc = acc + p0;
-            acc = acc + p1;
-            acc = acc + p2;
-            acc = acc + p3;
-        }
-        for (; k < len; ++k) acc = acc + prod[strip_pos<T, SKEW>(off + k)];
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (row0 + lane < min(row0 + (uint32_t)RPT, row1)) {
-        if (nt_store) __builtin_nontemporal_store(acc, &y[row0 + lane]);
-        else y[row0 + lane] = acc;
-    }
+    strip_sums_to_y<T, RPT, SKEW>(t, prod, y, row0, row1, lane, nt_store);
 }
 
 // one super-tile in stream-global mode (no window, no workgroup barrier)

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void csr_stream_check(const uint32_t *__restri
     }
 }
 
-// Plan time: the first rows of the tiles the descriptors mark, appended in any order.
+// Plan time: the first rows of the tiles the descriptors mark (in pieces of at most 64 rows), appended in any order.
 __global__ __launch_bounds__(256) void csr_overflow_tiles(const uint4 *__restrict__ desc, uint32_t nrows,
                                                           uint32_t R, uint32_t rpt, uint32_t cap,
                                                           uint32_t *__restrict__ count,
@@ -276,8 +276,10 @@ __global__ __launch_bounds__(256) void csr_overflow_tiles(const uint4 *__restric
     const uint32_t mode = desc_mode(d);
     if (mode != kModeStream && mode != kModeStreamGlobal) return;
     if (!((desc_skip_bits(d) >> (uint32_t)((r0 % R) / rpt)) & 1u)) return;
-    const uint32_t at = atomicAdd(count, 1u);
-    if (at < cap) tiles[at] = (uint32_t)r0;
+    for (uint64_t r = r0; r < min(r0 + rpt, (uint64_t)nrows); r += 64) {   // (csr_spmv_overflow takes up to 64 rows a piece)
+        const uint32_t at = atomicAdd(count, 1u);
+        if (at < cap) tiles[at] = (uint32_t)r;
+    }
 }
 
 // ---- the pages a super-tile's rows touch ----------------------------------------------
@@ -534,7 +536,7 @@ static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, h
 }
 
 // persistent form: 2 workgroups per CU, contiguous chunks of each XCD's run
-template <typename T, int RPT, bool SKEW = false>
+template <typename T, int TPW, int RPT, bool SKEW = false>
 static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     constexpr int L = 64;
     const CsrPlan &p = a->plan;
@@ -550,7 +552,7 @@ static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, voi
     const uint32_t slots = (uint32_t)std::max(1, grid / 8);                   // workgroups per XCD
     const uint32_t chunk = (per_xcd + slots - 1) / slots;
     const uint32_t used = (per_xcd + chunk - 1) / chunk;                      // non-empty slots
-    auto kern = csr_spmv_stream_persistent<T, L, 1, true, 4, RPT, SKEW>;
+    auto kern = csr_spmv_stream_persistent<T, L, 1, true, TPW, RPT, SKEW>;
     static std::atomic<uint64_t> configured{0};
     hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
     if (e != hipSuccess) return e;
@@ -566,7 +568,7 @@ template <typename T>
 static hipError_t launch_overflow(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     hipLaunchKernelGGL(csr_spmv_overflow<T>, dim3(a->n_ovtiles), dim3(kStreamBlock), 0, st, a->d_rowptr,
                        a->d_colind, (const T *)a->d_values, (const T *)x, (T *)y, a->d_ovtiles + 1,
-                       a->n_ovtiles, (uint32_t)a->plan.rows_per_tile, (uint32_t)a->nrows);
+                       a->n_ovtiles, (uint32_t)std::min(a->plan.rows_per_tile, 64), (uint32_t)a->nrows);
     return hipGetLastError();
 }
 
@@ -585,16 +587,17 @@ static hipError_t launch_stream_main(const spal_csr *a, const void *x, void *y, 
     const CsrPlan &p = a->plan;
     if (p.tiles_per_wave == 8) return launch_stream_tpw<T, 8, 64>(a, x, y, st);  // (64-row tiles only)
 #define SPAL_STREAM_CASE(RPT, SKEW) \
-    case RPT: return p.persistent ? launch_stream_persistent<T, RPT, SKEW>(a, x, y, st) : launch_stream_tpw<T, 4, RPT, SKEW>(a, x, y, st);
+    case RPT: return p.persistent ? launch_stream_persistent<T, (RPT > 64 ? 2 : 4), RPT, SKEW>(a, x, y, st) \
+                                  : launch_stream_tpw<T, (RPT > 64 ? 2 : 4), RPT, SKEW>(a, x, y, st);
     if (p.skew) {
         switch (p.rows_per_tile) {
-            SPAL_STREAM_CASE(64, true) SPAL_STREAM_CASE(32, true) SPAL_STREAM_CASE(24, true)
+            SPAL_STREAM_CASE(128, true) SPAL_STREAM_CASE(64, true) SPAL_STREAM_CASE(32, true) SPAL_STREAM_CASE(24, true)
             SPAL_STREAM_CASE(16, true) SPAL_STREAM_CASE(12, true) SPAL_STREAM_CASE(8, true)
             default: return hipErrorInvalidValue;
         }
     }
     switch (p.rows_per_tile) {
-        SPAL_STREAM_CASE(64, false) SPAL_STREAM_CASE(32, false) SPAL_STREAM_CASE(24, false)
+        SPAL_STREAM_CASE(128, false) SPAL_STREAM_CASE(64, false) SPAL_STREAM_CASE(32, false) SPAL_STREAM_CASE(24, false)
         SPAL_STREAM_CASE(16, false) SPAL_STREAM_CASE(12, false) SPAL_STREAM_CASE(8, false)
         default: return hipErrorInvalidValue;
     }
@@ -842,11 +845,11 @@ int csr_plan_build(spal_csr *a) {
     // 120/row 68 % vs 56 %; 4-row tiles for 150 ... 250/row were level with or behind the vector kernel.
     if ((p.user_kernel == 0 && mean <= 120.0) || p.user_kernel == 2) {
         if (p.tiles_per_wave != 4 && p.tiles_per_wave != 8) p.tiles_per_wave = 4;
-        const int rpt_all[] = {64, 32, 24, 16, 12, 8};   // (48 rows per tile measured behind 32: 20/row 124 vs 111 us)
+        const int rpt_all[] = {128, 64, 32, 24, 16, 12, 8};   // (48 rows per tile measured behind 32: 20/row 124 vs 111 us)
         std::vector<int> rpts;
         if (p.user_rows_per_tile) rpts.push_back(p.rows_per_tile);
         else if (p.tiles_per_wave == 8) rpts.push_back(64);
-        else rpts.assign(rpt_all, rpt_all + 6);
+        else rpts.assign(rpt_all + (mean <= 8.0 ? 0 : 1), rpt_all + 7);   // (128 rows of more than 8 entries do not fit a tile)
         std::vector<uint4> desc, best_desc;
         uint32_t cap = 0, best_cap = 0;
         double frac = 0.0, best_frac = -1.0, best_cost = -1.0;
@@ -858,7 +861,7 @@ int csr_plan_build(spal_csr *a) {
         if (a->d_ovtiles) { SPAL_HIP_TRY(dev_free(a->d_ovtiles)); a->d_ovtiles = nullptr; }
         a->n_ovtiles = 0;
         for (int rpt : rpts) {
-            const uint32_t R = (uint32_t)stream_rows(p.tiles_per_wave, rpt);
+            const uint32_t R = (uint32_t)stream_rows(rpt > 64 ? 2 : p.tiles_per_wave, rpt);   // (128-row tiles: two per wave, the same 1024 rows)
             uint32_t *pg = nullptr;
             double cost = 0.0;
             int st = stream_plan(a, R, (uint32_t)rpt, desc, cap, frac, &pg, n_over, skip, cost, !p.user_skew && rpt == rpts[0]);
@@ -876,7 +879,7 @@ int csr_plan_build(spal_csr *a) {
         if (!(p.user_kernel == 2 || best_frac >= 0.5)) (void)dev_free(best_pages);
         if (p.user_kernel == 2 || best_frac >= 0.5) {
             a->d_pages = best_pages;
-            const uint32_t R = (uint32_t)stream_rows(p.tiles_per_wave, best_rpt);
+            const uint32_t R = (uint32_t)stream_rows(best_rpt > 64 ? 2 : p.tiles_per_wave, best_rpt);
             p.kernel = 2;
             p.rows_per_tile = best_rpt;
             p.rows_per_block = (int)R;
@@ -918,19 +921,20 @@ int csr_plan_build(spal_csr *a) {
             }
             if (best_over) {   // the tiles the stream kernels skip: listed for csr_spmv_overflow
                 uint32_t *d_list = nullptr;   // [count][first rows]
-                SPAL_HIP_TRY(dev_alloc((void **)&d_list, ((size_t)best_over + 1) * 4));
+                const uint32_t pieces = best_rpt > 64 ? 2u * best_over : best_over;   // (at most)
+                SPAL_HIP_TRY(dev_alloc((void **)&d_list, ((size_t)pieces + 1) * 4));
                 a->d_ovtiles = d_list;
                 SPAL_HIP_TRY(hipMemsetAsync(d_list, 0, 4, a->stream));
                 const uint64_t ntile = (a->nrows + (uint64_t)best_rpt - 1) / (uint64_t)best_rpt;
                 hipLaunchKernelGGL(csr_overflow_tiles, dim3((uint32_t)((ntile + 255) / 256)), dim3(256), 0, a->stream,
-                                   a->d_desc, (uint32_t)a->nrows, R, (uint32_t)best_rpt, best_over, d_list,
+                                   a->d_desc, (uint32_t)a->nrows, R, (uint32_t)best_rpt, pieces, d_list,
                                    d_list + 1);
                 SPAL_HIP_TRY(hipGetLastError());
                 uint32_t listed = 0;
                 SPAL_HIP_TRY(hipMemcpyAsync(&listed, d_list, 4, hipMemcpyDeviceToHost, a->stream));
                 SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
-                if (listed != best_over) return SPAL_ERR_HIP;   // (cannot happen: both count the same tiles)
-                a->n_ovtiles = best_over;
+                if (listed > pieces || listed < best_over) return SPAL_ERR_HIP;   // (cannot happen: both count the same tiles)
+                a->n_ovtiles = listed;
             }
             SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
             return SPAL_OK;
@@ -1401,8 +1405,8 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         p.persistent_blocks = (int)value;
     } else if (!strcmp(key, "rows_per_tile")) {
         if (value == 0) p.user_rows_per_tile = false;
-        else if (value != 64 && value != 32 && value != 24 && value != 16 && value != 12 && value != 8)
-            return fail(SPAL_ERR_INVALID_ARGUMENT, "rows_per_tile must be 0 (auto), 64, 32, 24, 16, 12 or 8");
+        else if (value != 128 && value != 64 && value != 32 && value != 24 && value != 16 && value != 12 && value != 8)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "rows_per_tile must be 0 (auto), 128, 64, 32, 24, 16, 12 or 8");
         else { p.rows_per_tile = (int)value; p.user_rows_per_tile = true; }
     } else if (!strcmp(key, "tiles_per_wave")) {
         if (value != 4 && value != 8) return fail(SPAL_ERR_INVALID_ARGUMENT, "tiles_per_wave must be 4 or 8");

@@ -25,7 +25,8 @@ def main():
         x = torch.from_numpy(sp.synth.vector(n)).cuda()
         y = torch.empty(n, dtype=torch.float64, device="cuda")
         print(f"{name}: nnz {nnz}, floor {B/8e12*1e6:.1f} us", flush=True)
-        variants = [[("kernel", 0)], [("kernel", 2), ("persistent", 1)], [("kernel", 2), ("persistent", 0), ("tiles_per_wave", 8)],
+        variants = [[("kernel", 0)], [("kernel", 2), ("rows_per_tile", 64), ("persistent", 0)], [("kernel", 2), ("rows_per_tile", 128), ("persistent", 0)],
+                    [("kernel", 2), ("rows_per_tile", 128), ("persistent", 1)], [("rows_per_tile", 0), ("kernel", 2), ("persistent", 1)], [("kernel", 2), ("persistent", 0), ("tiles_per_wave", 8)],
                     [("tiles_per_wave", 4), ("kernel", 1), ("lanes_per_row", 2), ("unroll", 4)],
                     [("kernel", 1), ("lanes_per_row", 4), ("unroll", 4)],
                     [("kernel", 1), ("lanes_per_row", 2), ("unroll", 4), ("rows_per_block", 4096)],
@@ -40,7 +41,7 @@ def main():
                 continue
             t = timeit(lambda: dev.spmv_torch(x, out=y))
             d = dev.describe()
-            print(f"  {str(dict(opts)):90s} {t*1e3:7.1f} us = {100*B/(t*1e-3)/8e12:5.1f} %  [{d['kernel']} L={d['lanes_per_row']} U={d['unroll']} "
+            print(f"  {str(dict(opts)):90s} {t*1e3:7.1f} us = {100*B/(t*1e-3)/8e12:5.1f} %  [{d['kernel']} rpt={d['rows_per_tile']} L={d['lanes_per_row']} U={d['unroll']} "
                   f"R={d['rows_per_block']} lds={d['lds_x']} pers={d['persistent']}]", flush=True)
         del dev
 
