@@ -136,7 +136,12 @@ int spal_csr_autotune_f64(spal_csr_t a, const double *x_dev, double *y_dev,
                           void *stream, int iters);
 int spal_csr_autotune_f32(spal_csr_t a, const float *x_dev, float *y_dev,
                           void *stream, int iters);
-/* Writes a one-line JSON description of the active plan into buf. */
+/* Writes a one-line JSON description of the active plan into buf: "kernel"
+ * ("stream" | "vector"), "index_bits" (16: window-relative columns), the
+ * geometry ("rows_per_tile", "rows_per_block", "lanes_per_row", ...),
+ * "lds_window_bytes", "stream_row_fraction" (rows in tiles that stream),
+ * "overflow_tiles" (tiles left to the overflow kernel), "skew", "persistent",
+ * "nt_store", "autotune_us". */
 int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len);
 
 /* ---- CSC: y = A * x (atomic scatter) --------------------------------------
