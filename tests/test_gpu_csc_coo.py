@@ -1,4 +1,6 @@
 """GPU parity: CSC scatter SpMV and device COO -> CSR assembly vs the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -252,7 +254,7 @@ def test_coo_long_runs_and_skew(oracle):
     assemble_and_compare(oracle, 50, 4000, r, c, v)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SPAL_FUZZ_SEEDS", "12"))))
 def test_coo_assembly_randomised(oracle, seed):
     """shapes, lengths, row skew, input order, duplicate and cancellation rates at random: arrays bit-exact
     (whatever route -- group sort of some geometry or the general one -- the assembly takes), then y = A*x."""

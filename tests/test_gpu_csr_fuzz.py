@@ -3,6 +3,8 @@ distributions, column patterns and shapes that steer the planner through all of 
 skewed strips, skipped tiles + overflow kernel, LDS pages / x through L2, the vector kernel).
 
 Tolerance as in test_gpu_csr_spmv.py: f64 1e-10, f32 1e-4, normwise and componentwise."""
+import os
+
 import numpy as np
 import pytest
 
@@ -55,7 +57,7 @@ def _matrix(rng, n, ncols, lens, pattern, dtype):
     return rp, cols2.astype(np.uint64), rng.uniform(-1, 1, cols2.size).astype(dtype)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SPAL_FUZZ_SEEDS", "24"))))   # (more seeds: a longer soak)
 def test_random_matrices_all_planner_paths(oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     dtype = np.float64 if seed % 3 else np.float32
