@@ -119,7 +119,7 @@ int spal_csr_download_f32(spal_csr_t a, uint64_t *rowptr, uint64_t *colind,
 /* Kernel plan knobs (tuning / tests).  Keys: "kernel" (0 = auto, 1 = vector,
  * 2 = stream), "rows_per_block", "lanes_per_row", "lds_x" (-1 auto/0/1),
  * "unroll", "threads", "col16" (long rows: 16-bit columns, default 1) (vector
- * kernel); "rows_per_tile" (0 auto, 128, 64, 32, 24, 16, 12, 8),
+ * kernel); "rows_per_tile" (0 auto, 256, 128, 64, 32, 24, 16, 12, 8),
  * "tiles_per_wave", "persistent", "persistent_blocks" (0 = what the device
  * holds at once), "nt_store", "stream_global", "window_pages" (0 auto; LDS x
  * window budget in 256-column pages), "stream_row_max" (64-row tiles with a

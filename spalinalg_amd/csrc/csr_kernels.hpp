@@ -420,7 +420,7 @@ __global__ __launch_bounds__(BLOCK, 8) void csr_spmv_vector_col16(
 constexpr int kStreamBlock = 256;
 constexpr int kStreamWaves = kStreamBlock / kWave;                          // 4
 // A tile holds RPT rows (64, 32, 24, 16, 12 or 8: one lane per row, the other lanes idle
-// in the reduction) and at most kStreamTileNnz entries; narrower tiles let
+// in the reduction; 128 or 256: two or four adjacent rows per lane, for rows of at most 8 / 4 entries) and at most kStreamTileNnz entries; narrower tiles let
 // matrices with up to ~120 entries per row stream as well.
 // rows of a super-tile when every wave owns TPW tiles of RPT rows (4 x 64: 1024)
 constexpr int stream_rows(int tpw, int rpt = 64) { return kStreamWaves * tpw * rpt; }
@@ -484,23 +484,25 @@ __device__ __forceinline__ T strip_row_sum(const T *prod, uint32_t off, uint32_t
     }
     return acc;
 }
-// ... and the stores of a tile's results: RPT <= 64 a row per lane, RPT = 128 the lane's two adjacent rows
+// ... and the stores of a tile's results: RPT <= 64 a row per lane, RPT = 128 / 256 the lane's two / four adjacent rows
 template <typename T, int RPT, bool SKEW, typename Tile>
 __device__ __forceinline__ void strip_sums_to_y(const Tile &t, const T *prod, T *__restrict__ y, uint32_t row0,
                                                 uint32_t row1, uint32_t lane, bool nt_store) {
     const uint32_t rlast = min(row0 + (uint32_t)RPT, row1);
     if constexpr (RPT > 64) {
-        const T acc0 = strip_row_sum<T, SKEW>(prod, t.rp0 - t.start, t.rp1 - t.rp0);
-        const T acc1 = strip_row_sum<T, SKEW>(prod, t.rp1 - t.start, t.rp2 - t.rp1);
+        constexpr uint32_t RPL = RPT / 64;
+        T acc[RPL];
+#pragma unroll
+        for (uint32_t i = 0; i < RPL; ++i)
+            acc[i] = strip_row_sum<T, SKEW>(prod, t.rpl[i] - t.start, t.rpl[i + 1] - t.rpl[i]);
         __builtin_amdgcn_wave_barrier();  // the next tile's products overwrite this strip
-        const uint32_t r = row0 + 2 * lane;
-        if (r < rlast) {
-            if (nt_store) __builtin_nontemporal_store(acc0, &y[r]);
-            else y[r] = acc0;
-        }
-        if (r + 1 < rlast) {
-            if (nt_store) __builtin_nontemporal_store(acc1, &y[r + 1]);
-            else y[r + 1] = acc1;
+#pragma unroll
+        for (uint32_t i = 0; i < RPL; ++i) {
+            const uint32_t r = row0 + RPL * lane + i;
+            if (r < rlast) {
+                if (nt_store) __builtin_nontemporal_store(acc[i], &y[r]);
+                else y[r] = acc[i];
+            }
         }
     } else {
         const T acc = strip_row_sum<T, SKEW>(prod, t.rp0 - t.start, t.rp1 - t.rp0);
@@ -517,7 +519,7 @@ struct StreamTile {
     typename Pair<T>::type v[kStreamSteps];
     uint32_t c[kStreamSteps];  // two 16-bit LDS-window positions (page slot * 256 + column inside the page)
     uint32_t rp0, rp1;         // rowptr[row], rowptr[row + 1] of this lane's row
-    uint32_t rp2;              // RPT = 128 (two adjacent rows per lane): rowptr[row + 2]
+    uint32_t rpl[5];           // RPT = 128 / 256 (two / four adjacent rows per lane): rowptr[first row + 0 ... 4]
     uint32_t start;            // first loaded entry (tile start rounded down to even); wave-uniform
     uint32_t steps;            // 128-entry steps that hold entries of the tile; wave-uniform
 };
@@ -544,10 +546,10 @@ __device__ __forceinline__ void stream_load(StreamTile<T> &t, const uint32_t *__
     // ... then this lane's row bounds (needed only by the reduction).  Both
     // loads are unconditional: lanes past the tile's last row read
     // rowptr[rlast] twice, i.e. an empty row -- no select, hence no wait here.
-    if constexpr (RPT > 64) {   // rows of very few entries: lane l owns the adjacent rows 2l and 2l + 1
-        t.rp0 = rowptr[min(row0 + 2 * lane, rlast)];
-        t.rp1 = rowptr[min(row0 + 2 * lane + 1, rlast)];
-        t.rp2 = rowptr[min(row0 + 2 * lane + 2, rlast)];
+    if constexpr (RPT > 64) {   // rows of very few entries: lane l owns RPT / 64 adjacent rows
+        constexpr uint32_t RPL = RPT / 64;
+#pragma unroll
+        for (uint32_t i = 0; i <= RPL; ++i) t.rpl[i] = rowptr[min(row0 + RPL * lane + i, rlast)];
     } else {
         t.rp0 = rowptr[min(row0 + lane, rlast)];
         t.rp1 = rowptr[min(row0 + lane + 1, rlast)];
@@ -594,7 +596,7 @@ struct StreamTileG {
     typename Pair<T>::type v[kStreamSteps];
     typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
     u32x2 c[kStreamSteps];     // two 32-bit columns
-    uint32_t rp0, rp1, rp2, start, steps;
+    uint32_t rp0, rp1, rpl[5], start, steps;
 };
 
 template <typename T, int RPT>
@@ -615,10 +617,10 @@ __device__ __forceinline__ void stream_load_g(StreamTileG<T> &t, const uint32_t 
                 reinterpret_cast<const typename StreamTileG<T>::u32x2 *>(colind + e0 + j * 128));
         }
     }
-    if constexpr (RPT > 64) {   // rows of very few entries: lane l owns the adjacent rows 2l and 2l + 1
-        t.rp0 = rowptr[min(row0 + 2 * lane, rlast)];
-        t.rp1 = rowptr[min(row0 + 2 * lane + 1, rlast)];
-        t.rp2 = rowptr[min(row0 + 2 * lane + 2, rlast)];
+    if constexpr (RPT > 64) {   // rows of very few entries: lane l owns RPT / 64 adjacent rows
+        constexpr uint32_t RPL = RPT / 64;
+#pragma unroll
+        for (uint32_t i = 0; i <= RPL; ++i) t.rpl[i] = rowptr[min(row0 + RPL * lane + i, rlast)];
     } else {
         t.rp0 = rowptr[min(row0 + lane, rlast)];
         t.rp1 = rowptr[min(row0 + lane + 1, rlast)];

@@ -587,17 +587,17 @@ static hipError_t launch_stream_main(const spal_csr *a, const void *x, void *y, 
     const CsrPlan &p = a->plan;
     if (p.tiles_per_wave == 8) return launch_stream_tpw<T, 8, 64>(a, x, y, st);  // (64-row tiles only)
 #define SPAL_STREAM_CASE(RPT, SKEW) \
-    case RPT: return p.persistent ? launch_stream_persistent<T, (RPT > 64 ? 2 : 4), RPT, SKEW>(a, x, y, st) \
-                                  : launch_stream_tpw<T, (RPT > 64 ? 2 : 4), RPT, SKEW>(a, x, y, st);
+    case RPT: return p.persistent ? launch_stream_persistent<T, (RPT > 128 ? 1 : RPT > 64 ? 2 : 4), RPT, SKEW>(a, x, y, st) \
+                                  : launch_stream_tpw<T, (RPT > 128 ? 1 : RPT > 64 ? 2 : 4), RPT, SKEW>(a, x, y, st);
     if (p.skew) {
         switch (p.rows_per_tile) {
-            SPAL_STREAM_CASE(128, true) SPAL_STREAM_CASE(64, true) SPAL_STREAM_CASE(32, true) SPAL_STREAM_CASE(24, true)
+            SPAL_STREAM_CASE(256, true) SPAL_STREAM_CASE(128, true) SPAL_STREAM_CASE(64, true) SPAL_STREAM_CASE(32, true) SPAL_STREAM_CASE(24, true)
             SPAL_STREAM_CASE(16, true) SPAL_STREAM_CASE(12, true) SPAL_STREAM_CASE(8, true)
             default: return hipErrorInvalidValue;
         }
     }
     switch (p.rows_per_tile) {
-        SPAL_STREAM_CASE(128, false) SPAL_STREAM_CASE(64, false) SPAL_STREAM_CASE(32, false) SPAL_STREAM_CASE(24, false)
+        SPAL_STREAM_CASE(256, false) SPAL_STREAM_CASE(128, false) SPAL_STREAM_CASE(64, false) SPAL_STREAM_CASE(32, false) SPAL_STREAM_CASE(24, false)
         SPAL_STREAM_CASE(16, false) SPAL_STREAM_CASE(12, false) SPAL_STREAM_CASE(8, false)
         default: return hipErrorInvalidValue;
     }
@@ -845,11 +845,11 @@ int csr_plan_build(spal_csr *a) {
     // 120/row 68 % vs 56 %; 4-row tiles for 150 ... 250/row were level with or behind the vector kernel.
     if ((p.user_kernel == 0 && mean <= 120.0) || p.user_kernel == 2) {
         if (p.tiles_per_wave != 4 && p.tiles_per_wave != 8) p.tiles_per_wave = 4;
-        const int rpt_all[] = {128, 64, 32, 24, 16, 12, 8};   // (48 rows per tile measured behind 32: 20/row 124 vs 111 us)
+        const int rpt_all[] = {256, 128, 64, 32, 24, 16, 12, 8};   // (48 rows per tile measured behind 32: 20/row 124 vs 111 us)
         std::vector<int> rpts;
         if (p.user_rows_per_tile) rpts.push_back(p.rows_per_tile);
         else if (p.tiles_per_wave == 8) rpts.push_back(64);
-        else rpts.assign(rpt_all + (mean <= 8.0 ? 0 : 1), rpt_all + 7);   // (128 rows of more than 8 entries do not fit a tile)
+        else rpts.assign(rpt_all + (mean <= 4.0 ? 0 : mean <= 8.0 ? 1 : 2), rpt_all + 8);   // (256 / 128 rows of more than 4 / 8 entries do not fit a tile)
         std::vector<uint4> desc, best_desc;
         uint32_t cap = 0, best_cap = 0;
         double frac = 0.0, best_frac = -1.0, best_cost = -1.0;
@@ -861,7 +861,7 @@ int csr_plan_build(spal_csr *a) {
         if (a->d_ovtiles) { SPAL_HIP_TRY(dev_free(a->d_ovtiles)); a->d_ovtiles = nullptr; }
         a->n_ovtiles = 0;
         for (int rpt : rpts) {
-            const uint32_t R = (uint32_t)stream_rows(rpt > 64 ? 2 : p.tiles_per_wave, rpt);   // (128-row tiles: two per wave, the same 1024 rows)
+            const uint32_t R = (uint32_t)stream_rows(rpt > 128 ? 1 : rpt > 64 ? 2 : p.tiles_per_wave, rpt);   // (128 / 256-row tiles: two / one per wave, the same 1024 rows)
             uint32_t *pg = nullptr;
             double cost = 0.0;
             int st = stream_plan(a, R, (uint32_t)rpt, desc, cap, frac, &pg, n_over, skip, cost, !p.user_skew && rpt == rpts[0]);
@@ -879,7 +879,7 @@ int csr_plan_build(spal_csr *a) {
         if (!(p.user_kernel == 2 || best_frac >= 0.5)) (void)dev_free(best_pages);
         if (p.user_kernel == 2 || best_frac >= 0.5) {
             a->d_pages = best_pages;
-            const uint32_t R = (uint32_t)stream_rows(best_rpt > 64 ? 2 : p.tiles_per_wave, best_rpt);
+            const uint32_t R = (uint32_t)stream_rows(best_rpt > 128 ? 1 : best_rpt > 64 ? 2 : p.tiles_per_wave, best_rpt);
             p.kernel = 2;
             p.rows_per_tile = best_rpt;
             p.rows_per_block = (int)R;
@@ -921,7 +921,7 @@ int csr_plan_build(spal_csr *a) {
             }
             if (best_over) {   // the tiles the stream kernels skip: listed for csr_spmv_overflow
                 uint32_t *d_list = nullptr;   // [count][first rows]
-                const uint32_t pieces = best_rpt > 64 ? 2u * best_over : best_over;   // (at most)
+                const uint32_t pieces = (uint32_t)std::max(1, best_rpt / 64) * best_over;   // (at most)
                 SPAL_HIP_TRY(dev_alloc((void **)&d_list, ((size_t)pieces + 1) * 4));
                 a->d_ovtiles = d_list;
                 SPAL_HIP_TRY(hipMemsetAsync(d_list, 0, 4, a->stream));
@@ -1405,8 +1405,8 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         p.persistent_blocks = (int)value;
     } else if (!strcmp(key, "rows_per_tile")) {
         if (value == 0) p.user_rows_per_tile = false;
-        else if (value != 128 && value != 64 && value != 32 && value != 24 && value != 16 && value != 12 && value != 8)
-            return fail(SPAL_ERR_INVALID_ARGUMENT, "rows_per_tile must be 0 (auto), 128, 64, 32, 24, 16, 12 or 8");
+        else if (value != 256 && value != 128 && value != 64 && value != 32 && value != 24 && value != 16 && value != 12 && value != 8)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "rows_per_tile must be 0 (auto), 256, 128, 64, 32, 24, 16, 12 or 8");
         else { p.rows_per_tile = (int)value; p.user_rows_per_tile = true; }
     } else if (!strcmp(key, "tiles_per_wave")) {
         if (value != 4 && value != 8) return fail(SPAL_ERR_INVALID_ARGUMENT, "tiles_per_wave must be 4 or 8");

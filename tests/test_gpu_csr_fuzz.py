@@ -77,7 +77,7 @@ def test_random_matrices_all_planner_paths(oracle, seed):
     d = dev.describe()
     assert_spmv_close(dev.spmv(x), y_ref, bound, TOL[va.dtype])
     if d["kernel"] == "stream":
-        for key, value in (("persistent", 1), ("skew", 1 - d["skew"]), ("rows_per_tile", 8), ("rows_per_tile", 128), ("rows_per_tile", 12), ("stream_row_max", 16),
+        for key, value in (("persistent", 1), ("skew", 1 - d["skew"]), ("rows_per_tile", 8), ("rows_per_tile", 128), ("rows_per_tile", 256), ("rows_per_tile", 12), ("stream_row_max", 16),
                            ("window_pages", 4)):
             dev.set_option(key, value)
             assert_spmv_close(dev.spmv(x), y_ref, bound, TOL[va.dtype])

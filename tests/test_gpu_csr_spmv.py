@@ -166,13 +166,15 @@ def test_stream_kernel_bank_skew_and_8_row_tiles(oracle, per_row, dtype, rpt, sk
     assert np.array_equal(dev.spmv(x), oracle.csr_spmv(rp, ci, va, x))
 
 
+@pytest.mark.parametrize("lo,hi,rpt", [(0, 4, 256), (3, 9, 128)])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_stream_kernel_128_row_tiles_two_rows_per_lane(oracle, dtype):
-    """rows of at most 8 entries (diagonal, tridiagonal, 5- and 7-point stencils) stream in tiles of 128 rows, a lane
-    summing two adjacent rows: bit-identical; a heavy row takes its tile to the overflow kernel in two pieces."""
-    rng = np.random.default_rng(8)
-    n = 70_001                                                   # odd: the last tile ends on a lane's first row
-    lens = rng.integers(0, 8, n)                                 # empty rows included
+def test_stream_kernel_tall_tiles_several_rows_per_lane(oracle, dtype, lo, hi, rpt):
+    """rows of at most 4 / 8 entries (diagonal, tridiagonal, 5- and 7-point stencils) stream in tiles of 256 / 128
+    rows, a lane summing four / two adjacent rows: bit-identical; a heavy row takes its tile to the overflow
+    kernel in pieces of 64 rows."""
+    rng = np.random.default_rng(8 + rpt)
+    n = 70_001                                                   # odd: the last tile ends inside a lane's rows
+    lens = rng.integers(lo, hi, n)                               # (empty rows included when lo == 0)
     lens[::1000] = 7
     rows = np.repeat(np.arange(n), lens)
     cols = np.clip(rows + rng.integers(-300, 300, rows.size), 0, n - 1)
@@ -182,7 +184,7 @@ def test_stream_kernel_128_row_tiles_two_rows_per_lane(oracle, dtype):
     x = sp.synth.vector(n, dtype=dtype)
     dev = sp.CsrMatrix(n, n, rp, ci, va).device()
     d = dev.describe()
-    assert d["kernel"] == "stream" and d["rows_per_tile"] == 128 and d["overflow_tiles"] == 0, d
+    assert d["kernel"] == "stream" and d["rows_per_tile"] == rpt and d["overflow_tiles"] == 0, d
     y_ref = oracle.csr_spmv(rp, ci, va, x)
     for persistent, nt, skew in ((0, 0, 0), (1, 0, 0), (0, 1, 1), (1, 1, 1)):
         dev.set_option("persistent", persistent)
@@ -191,21 +193,23 @@ def test_stream_kernel_128_row_tiles_two_rows_per_lane(oracle, dtype):
         assert np.array_equal(dev.spmv(x), y_ref)
     dev.set_option("rows_per_tile", 64)                          # the same matrix, a row per lane
     assert np.array_equal(dev.spmv(x), y_ref)
-    # heavy rows: first row, a lane's second row, last row
+    # heavy rows: first row, a row in the middle of a lane's rows, last row
     rp = rp.astype(np.int64)
     ci, va = list(np.split(ci, rp[1:-1])), list(np.split(va, rp[1:-1]))
-    for r, k in ((0, 1500), (4001, 300), (n - 1, 1100)):
+    heavy = ((0, 1500), (4001, 300), (n - 1, 1100))
+    for r, k in heavy:
         ci[r] = np.sort(rng.choice(n, k, replace=False)).astype(np.uint64)
         va[r] = rng.uniform(-1, 1, k).astype(dtype)
     rp = np.concatenate([[0], np.cumsum([c.size for c in ci])]).astype(np.uint64)
     ci, va = np.concatenate(ci), np.concatenate(va)
     dev = check(oracle, rp, ci, va, x, n)
     d = dev.describe()
-    assert d["rows_per_tile"] == 128 and 5 <= d["overflow_tiles"] <= 6, d     # 3 tiles, two pieces each (the last tile: 1 or 2)
+    pieces = sum(-(-(min(r // rpt * rpt + rpt, n) - r // rpt * rpt) // 64) for r, _ in heavy)
+    assert d["rows_per_tile"] == rpt and d["overflow_tiles"] == pieces, d
     y, y_ref = dev.spmv(x), oracle.csr_spmv(rp, ci, va, x)
     light = np.ones(n, dtype=bool)
-    for r in (0, 4001, n - 1):
-        light[r // 128 * 128:r // 128 * 128 + 128] = False
+    for r, _ in heavy:
+        light[r // rpt * rpt:r // rpt * rpt + rpt] = False
     assert np.array_equal(y[light], y_ref[light])
 
 

@@ -25,7 +25,7 @@ def main():
         x = torch.from_numpy(sp.synth.vector(n)).cuda()
         y = torch.empty(n, dtype=torch.float64, device="cuda")
         print(f"{name}: nnz {nnz}, floor {B/8e12*1e6:.1f} us", flush=True)
-        variants = [[("kernel", 0)], [("kernel", 2), ("rows_per_tile", 64), ("persistent", 0)], [("kernel", 2), ("rows_per_tile", 128), ("persistent", 0)],
+        variants = [[("kernel", 0)], [("kernel", 2), ("rows_per_tile", 64), ("persistent", 0)], [("kernel", 2), ("rows_per_tile", 128), ("persistent", 0)], [("kernel", 2), ("rows_per_tile", 256), ("persistent", 0)],
                     [("kernel", 2), ("rows_per_tile", 128), ("persistent", 1)], [("rows_per_tile", 0), ("kernel", 2), ("persistent", 1)], [("kernel", 2), ("persistent", 0), ("tiles_per_wave", 8)],
                     [("tiles_per_wave", 4), ("kernel", 1), ("lanes_per_row", 2), ("unroll", 4)],
                     [("kernel", 1), ("lanes_per_row", 4), ("unroll", 4)],
