@@ -114,11 +114,12 @@ def bench_csc(args):
     import torch
     import scipy.sparse as sps
     import spalinalg_amd as sp
-    cfg = sp.synth.CONFIGS[4]
+    import spal_synth as synth
+    cfg = synth.CONFIGS[4]
     n, per_row = cfg["nrows"], cfg["per_row"]
     np_dt = np.float64 if args.dtype == "f64" else np.float32
     esz = np.dtype(np_dt).itemsize
-    rp, ci, va = sp.synth.banded_csr(n, n, per_row, cfg["window"], sp.synth.matrix_seed(2), dtype=np_dt)
+    rp, ci, va = synth.banded_csr(n, n, per_row, cfg["window"], synth.matrix_seed(2), dtype=np_dt)
     csc = sps.csr_matrix((va, ci.astype(np.int64), rp.astype(np.int64)), shape=(n, n)).tocsc()
     csc.sort_indices()
     cp, ri, cv = csc.indptr.astype(np.uint64), csc.indices.astype(np.uint64), csc.data.astype(np_dt)
@@ -131,7 +132,7 @@ def bench_csc(args):
             k, v = kv.split("=")
             d.set_option(k, int(v))
     dev = devs[0]
-    xh = sp.synth.vector(n, dtype=np_dt)
+    xh = synth.vector(n, dtype=np_dt)
     xs = [torch.from_numpy(xh).cuda() for _ in range(copies)]
     ys = [torch.empty_like(xs[0]) for _ in range(copies)]
     x, y = xs[0], ys[0]
@@ -148,9 +149,9 @@ def bench_csc(args):
         d.set_option("kernel", 1)
     ms = timed(rotating(launches), args.steps, args.warmup, torch)
     nnz = n * per_row
-    B = sp.synth.spmv_bytes(nnz, n, n, n, esz)
+    B = synth.spmv_bytes(nnz, n, n, n, esz)
     out = base_record(args, "CSC SpMV GFLOP/s (f64, 1Mx1M, 14M nnz, atomic scatter)",
-                      sp.synth.spmv_flops(nnz) / (ms * 1e-3) / 1e9, "GFLOP/s", ms,
+                      synth.spmv_flops(nnz) / (ms * 1e-3) / 1e9, "GFLOP/s", ms,
                       f"CscMatrix {args.dtype} SpMV y=A*x by atomic scatter, {n}x{n}, {nnz} nnz, CSC of the "
                       f"config-2 banded matrix (BASELINE configs[3]), single GPU; launches rotate over {copies} "
                       f"independent copies of (A, x, y) = {copies * B / 1e6:.0f} MB > the 256 MB Infinity Cache",
@@ -162,7 +163,7 @@ def bench_csc(args):
                        "algorithmic_bytes_per_launch": B,
                        "note": "bound in practice by LDS / global float-atomic rates, not by HBM"}
     out["transposed_route"] = {"ms_per_step": round(ms_transposed, 6),
-                               "gflops": round(sp.synth.spmv_flops(nnz) / (ms_transposed * 1e-3) / 1e9, 2),
+                               "gflops": round(synth.spmv_flops(nnz) / (ms_transposed * 1e-3) / 1e9, 2),
                                "roofline_frac": round(B / (ms_transposed * 1e-3) / 8e12, 4),
                                "agrees_with_scatter": bool(torch.allclose(y, y_transposed, rtol=1e-10, atol=1e-12)),
                                "note": "kernel=2 (library default): device CSC->CSR once, then csr_spmv_stream; "
@@ -176,7 +177,7 @@ def bench_csc(args):
             el = time.perf_counter() - t0
             if el >= args.cpu_seconds or passes >= 2000:
                 break
-        out["cpu_baseline"] = {"value": round(sp.synth.spmv_flops(nnz) * passes / el / 1e9, 4), "unit": "GFLOP/s",
+        out["cpu_baseline"] = {"value": round(synth.spmv_flops(nnz) * passes / el / 1e9, 4), "unit": "GFLOP/s",
                                "cores": 1, "kind": "port",
                                "sample": f"{passes} full passes over the same matrix in {el:.1f} s, 1 thread",
                                "gpu_agrees_with_cpu": bool(np.allclose(y.cpu().numpy(), yh, rtol=1e-10 if esz == 8 else 1e-4,
@@ -189,13 +190,14 @@ def bench_small(args):
     CsrMatrix on the device -> SpMV; the CPU baseline leg runs the same on one core and compares in full."""
     import torch
     import spalinalg_amd as sp
-    cfg = sp.synth.CONFIGS[1]
+    import spal_synth as synth
+    cfg = synth.CONFIGS[1]
     nr, nc, length = cfg["nrows"], cfg["ncols"], cfg["length"]
     np_dt = np.float64 if args.dtype == "f64" else np.float32
-    r, c, v = sp.synth.coo(nr, nc, length, sp.synth.matrix_seed(1), dtype=np_dt)
+    r, c, v = synth.coo(nr, nc, length, synth.matrix_seed(1), dtype=np_dt)
     d = sp.CooMatrix.with_triplets(nr, nc, r, c, v).upload()
     csr = d.assemble_csr()
-    x = torch.from_numpy(sp.synth.vector(nc, dtype=np_dt)).cuda()
+    x = torch.from_numpy(synth.vector(nc, dtype=np_dt)).cuda()
     y = torch.empty(nr, dtype=x.dtype, device="cuda")
     ms = timed(lambda: csr.spmv_torch(x, out=y), args.steps, args.warmup, torch)
     t0 = time.perf_counter()
@@ -205,8 +207,8 @@ def bench_small(args):
     asm_ms = (time.perf_counter() - t0) * 1e3 / 20
     rp, ci, va = csr.download()
     nnz = int(rp[-1])
-    B = sp.synth.spmv_bytes(nnz, nr, nr, nc, np.dtype(np_dt).itemsize)
-    out = base_record(args, f"CSR SpMV GFLOP/s ({args.dtype}, config 1)", sp.synth.spmv_flops(nnz) / (ms * 1e-3) / 1e9,
+    B = synth.spmv_bytes(nnz, nr, nr, nc, np.dtype(np_dt).itemsize)
+    out = base_record(args, f"CSR SpMV GFLOP/s ({args.dtype}, config 1)", synth.spmv_flops(nnz) / (ms * 1e-3) / 1e9,
                       "GFLOP/s", ms, f"CooMatrix {length} triplets -> CsrMatrix {nr}x{nc} ({nnz} stored) -> y=A*x "
                       f"(BASELINE configs[0], the reference's CPU-sized case; launch-bound on a GPU), single GPU",
                       csr.describe())
@@ -227,7 +229,7 @@ def bench_small(args):
             yh = oracle.csr_spmv(p, i, w, xh)
             passes += 1
         el = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(sp.synth.spmv_flops(nnz) * passes / el / 1e9, 4), "unit": "GFLOP/s", "cores": 1,
+        out["cpu_baseline"] = {"value": round(synth.spmv_flops(nnz) * passes / el / 1e9, 4), "unit": "GFLOP/s", "cores": 1,
                                "kind": "port", "sample": f"{passes} passes of the same matrix in {el:.1f} s, 1 thread; "
                                                          f"assembly of the {length} triplets on the CPU: {asm_cpu_ms:.2f} ms",
                                "gpu_assembly_equals_cpu_bit_for_bit": bool(np.array_equal(rp, p) and np.array_equal(ci, i)
@@ -242,11 +244,12 @@ def bench_coo(args):
     (+1 % duplicates, +0.1 % cancelling pairs) into 5M x 5M, then one SpMV on the result."""
     import torch
     import spalinalg_amd as sp
-    cfg = sp.synth.CONFIGS[5]
+    import spal_synth as synth
+    cfg = synth.CONFIGS[5]
     nr, length = cfg["nrows"], cfg["length"]
     np_dt = np.float64 if args.dtype == "f64" else np.float32
     esz = np.dtype(np_dt).itemsize
-    r, c, v = sp.synth.coo(nr, nr, length, sp.synth.matrix_seed(5), cfg["dup_permille"], cfg["cancel_permille"],
+    r, c, v = synth.coo(nr, nr, length, synth.matrix_seed(5), cfg["dup_permille"], cfg["cancel_permille"],
                            dtype=np_dt)
     coo = sp.CooMatrix.with_triplets(nr, nr, r, c, v)
     d = coo.upload()      # triplets + workspace resident in HBM before the timed region
@@ -270,10 +273,10 @@ def bench_coo(args):
     if os.environ.get("SPAL_BENCH_DEBUG"):
         print("per-step ms:", [round(t, 2) for t in per_step], file=sys.stderr)
     # the assembled matrix multiplies (the config's second half)
-    x = torch.from_numpy(sp.synth.vector(nr, dtype=np_dt)).cuda()
+    x = torch.from_numpy(synth.vector(nr, dtype=np_dt)).cuda()
     y = torch.empty_like(x)
     spmv_ms = timed(lambda: csr.spmv_torch(x, out=y), 20, 3, torch)
-    lb = sp.synth.assembly_bytes(length, nnz, nr, esz)
+    lb = synth.assembly_bytes(length, nnz, nr, esz)
     args.steps, args.warmup = steps, warm
     out = base_record(args, "COO->CSR assembly Mentries/s (f64, 50M triplets into 5Mx5M)",
                       length / (ms * 1e-3) / 1e6, "Mentries/s", ms,
@@ -289,7 +292,7 @@ def bench_coo(args):
                                "inherently moves several times this",
                        "route": d.describe()}
     out["spmv_on_result"] = {"ms": round(spmv_ms, 6),
-                             "gflops": round(sp.synth.spmv_flops(nnz) / (spmv_ms * 1e-3) / 1e9, 2)}
+                             "gflops": round(synth.spmv_flops(nnz) / (spmv_ms * 1e-3) / 1e9, 2)}
     if not args.no_cpu_baseline:
         import oracle  # CPU baseline leg only
         sample = min(length, 50_000_000)   # the whole config-5 input: 5-15 s on one core
@@ -319,6 +322,7 @@ def main():
             sys.exit("configs 1, 4 and 5 are single-GPU (BASELINE.json); only the CSR configs shard over GPUs")
         import torch
         import spalinalg_amd as sp
+        import spal_synth as synth
         if not torch.cuda.is_available() or sp.device_count() < 1:
             sys.exit("bench.py needs a GPU: libspal_hip has no CPU fallback")
         return bench_small(args) if args.config == 1 else bench_csc(args) if args.config == 4 else bench_coo(args)
@@ -334,6 +338,7 @@ def main():
     import torch
     import torch.distributed as dist
     import spalinalg_amd as sp
+    import spal_synth as synth
     from spalinalg_amd.dist import RowPartitionedSpmv, even_rows
 
     if not torch.cuda.is_available() or sp.device_count() < 1:
@@ -349,7 +354,7 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    cfg = sp.synth.CONFIGS[args.config]
+    cfg = synth.CONFIGS[args.config]
     nrows, ncols, per_row = cfg["nrows"], cfg["ncols"], cfg["per_row"]
     window = cfg["window"] if args.dist == "banded" else ncols
     np_dt = np.float64 if args.dtype == "f64" else np.float32
@@ -361,7 +366,7 @@ def main():
     bounds = even_rows(nrows, world)  # same entries in every row: even rows == even entries
     r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
     t0 = time.time()
-    rp, ci, va = sp.synth.banded_csr(nrows, ncols, per_row, window, sp.synth.matrix_seed(args.config),
+    rp, ci, va = synth.banded_csr(nrows, ncols, per_row, window, synth.matrix_seed(args.config),
                                      dtype=np_dt, rows=(r0, r1))
     t_gen = time.time() - t0
     t0 = time.time()
@@ -396,7 +401,7 @@ def main():
 
     # ---- x: generated on rank 0, broadcast once over RCCL
     if rank == 0:
-        x = torch.from_numpy(sp.synth.vector(ncols, dtype=np_dt)).to(device)
+        x = torch.from_numpy(synth.vector(ncols, dtype=np_dt)).to(device)
     else:
         x = torch.zeros(ncols, dtype=t_dt, device=device)
     torch.cuda.synchronize()
@@ -566,16 +571,16 @@ def main():
     kern_ms_max = float(kmax.item())
 
     local_nnz = (r1 - r0) * per_row
-    local_bytes = sp.synth.spmv_bytes(local_nnz, r1 - r0, r1 - r0, ncols, esz)
-    whole_bytes = sp.synth.spmv_bytes(nnz, nrows, nrows, ncols, esz)
+    local_bytes = synth.spmv_bytes(local_nnz, r1 - r0, r1 - r0, ncols, esz)
+    whole_bytes = synth.spmv_bytes(nnz, nrows, nrows, ncols, esz)
     achieved = local_bytes / (kern_ms * 1e-3) / 1e9          # GB/s, this rank's launch
-    peak = sp.synth.HBM_PEAK_BYTES_PER_S / 1e9
-    gflops = sp.synth.spmv_flops(nnz) / (ms_per_step * 1e-3) / 1e9
+    peak = synth.HBM_PEAK_BYTES_PER_S / 1e9
+    gflops = synth.spmv_flops(nnz) / (ms_per_step * 1e-3) / 1e9
 
     # ---- a spot check so a wrong kernel / exchange cannot post a number: every rank evaluates the
     # first and last two rows of ITS shard in numpy against its slice; rank 0 also regenerates the
     # first and last row of EVERY shard and looks them up in the gathered y
-    xh = sp.synth.vector(ncols, dtype=np_dt)
+    xh = synth.vector(ncols, dtype=np_dt)
     tol = 1e-10 if esz == 8 else 1e-4
     bad = 0
     nloc = r1 - r0
@@ -590,7 +595,7 @@ def main():
     if rank == 0 and world > 1:
         for g in range(world):
             for r in (int(bounds[g]), int(bounds[g + 1]) - 1):
-                _, c1, v1 = sp.synth.banded_csr(nrows, ncols, per_row, window, sp.synth.matrix_seed(args.config),
+                _, c1, v1 = synth.banded_csr(nrows, ncols, per_row, window, synth.matrix_seed(args.config),
                                                 dtype=np_dt, rows=(r, r + 1))
                 ref = float(np.dot(v1.astype(np.float64), xh[c1.astype(np.int64)].astype(np.float64)))
                 got = float(y[r].item())
@@ -658,7 +663,7 @@ def main():
             "y_collection": y_mode if world > 1 else "none",
             "plan": plan,
         },
-        "achieved_hbm_pct": round(100.0 * whole_bytes / (ms_per_step * 1e-3) / (world * sp.synth.HBM_PEAK_BYTES_PER_S), 2),
+        "achieved_hbm_pct": round(100.0 * whole_bytes / (ms_per_step * 1e-3) / (world * synth.HBM_PEAK_BYTES_PER_S), 2),
         "algorithmic_bytes_per_step": whole_bytes,
         "roofline": {
             "bound": "hbm",
@@ -674,13 +679,13 @@ def main():
         },
         "compute_only": {
             "ms_per_step": round(kern_ms_max, 6),
-            "value": round(sp.synth.spmv_flops(nnz) / (kern_ms_max * 1e-3) / 1e9, 3),
+            "value": round(synth.spmv_flops(nnz) / (kern_ms_max * 1e-3) / 1e9, 3),
             "unit": "GFLOP/s",
         },
         "x_bcast_ms": round(x_bcast_ms, 4),
         "allgather_every_step": None if allgather_ms is None else {
             "ms_per_step": round(allgather_ms, 6),
-            "value": round(sp.synth.spmv_flops(nnz) / (allgather_ms * 1e-3) / 1e9, 3), "unit": "GFLOP/s"},
+            "value": round(synth.spmv_flops(nnz) / (allgather_ms * 1e-3) / 1e9, 3), "unit": "GFLOP/s"},
         "setup_s": {"generate": round(t_gen, 2), "validate_narrow_upload_plan": round(t_upload, 2)},
     }
 
@@ -697,7 +702,7 @@ def main():
             if el >= args.cpu_seconds or passes >= 1000:
                 break
         out["cpu_baseline"] = {
-            "value": round(sp.synth.spmv_flops(nnz) * passes / el / 1e9, 4),
+            "value": round(synth.spmv_flops(nnz) * passes / el / 1e9, 4),
             "unit": "GFLOP/s",
             "cores": 1,
             "kind": "port",
@@ -722,7 +727,7 @@ def main():
                     if el >= min(args.cpu_seconds, 4.0) or passes >= 50:
                         break
             out["cpu_baseline_all_cores"] = {
-                "value": round(sp.synth.spmv_flops(nnz) * passes / el / 1e9, 4), "unit": "GFLOP/s",
+                "value": round(synth.spmv_flops(nnz) * passes / el / 1e9, 4), "unit": "GFLOP/s",
                 "cores": threads, "kind": "port",
                 "sample": f"{passes} full passes in {el:.1f} s, {threads} threads, one row range each "
                           f"(informational: the reference has no threads)",

@@ -279,42 +279,6 @@ int spal_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t byte
 int spal_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);
 int spal_device_synchronize(int device);
 
-/* ---- synthetic inputs of BASELINE.json's configs ---
- * SplitMix64 based, bit-exact across implementations; host side, threaded.
- * banded: every row has exactly `per_row` distinct sorted columns drawn from
- * a window of `window` columns centred on the diagonal (window == ncols gives
- * the uniform "stress" distribution); values in [-1, 1). */
-int spal_gen_banded_csr_f64(uint64_t nrows, uint64_t ncols, uint32_t per_row,
-                            uint64_t window, uint64_t seed, uint64_t *rowptr,
-                            uint64_t *colind, double *values);
-int spal_gen_banded_csr_f32(uint64_t nrows, uint64_t ncols, uint32_t per_row,
-                            uint64_t window, uint64_t seed, uint64_t *rowptr,
-                            uint64_t *colind, float *values);
-/* rows [row_begin, row_end) of the same matrix only (a rank's shard of the
- * row-partitioned product); rowptr has row_end - row_begin + 1 entries and
- * starts at 0. */
-int spal_gen_banded_csr_rows_f64(uint64_t nrows, uint64_t ncols, uint32_t per_row,
-                                 uint64_t window, uint64_t seed, uint64_t row_begin,
-                                 uint64_t row_end, uint64_t *rowptr,
-                                 uint64_t *colind, double *values);
-int spal_gen_banded_csr_rows_f32(uint64_t nrows, uint64_t ncols, uint32_t per_row,
-                                 uint64_t window, uint64_t seed, uint64_t row_begin,
-                                 uint64_t row_end, uint64_t *rowptr,
-                                 uint64_t *colind, float *values);
-/* sequential 2u-1 stream: x vectors */
-int spal_gen_vector_f64(uint64_t n, uint64_t seed, double *x);
-int spal_gen_vector_f32(uint64_t n, uint64_t seed, float *x);
-/* `len` uniform random triplets row=r()%nrows, col=r()%ncols, val=2u-1; then,
- * deterministically, `dup_permille` per mille of the entries are overwritten
- * by exact copies of an earlier entry's (row, col) and `cancel_permille` per
- * mille by an earlier entry with the value negated. */
-int spal_gen_coo_f64(uint64_t nrows, uint64_t ncols, uint64_t len, uint64_t seed,
-                     uint32_t dup_permille, uint32_t cancel_permille,
-                     uint64_t *rows, uint64_t *cols, double *vals);
-int spal_gen_coo_f32(uint64_t nrows, uint64_t ncols, uint64_t len, uint64_t seed,
-                     uint32_t dup_permille, uint32_t cancel_permille,
-                     uint64_t *rows, uint64_t *cols, float *vals);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1,22 +1,58 @@
-"""Synthetic inputs of BASELINE.json's configs.
+"""Synthetic inputs of BASELINE.json's configs and the
+algorithmic byte / flop counts the roofline figures are built from.
 
-Thin wrappers over the library's host generators (`spal_gen_*`, SplitMix64
-based, bit-exact across implementations; tests/test_synth.py re-implements
-them in pure Python for small sizes).  Also the algorithmic byte / flop
-counts the roofline figures are built from.
+Bench / test support, NOT part of the product: the generators live in their own
+host-only library (spal_synth/libspal_synth.so, built by `make -C spal_synth`;
+SplitMix64 based, bit-exact across implementations -- tests/test_synth.py
+restates them in pure Python).  libspal_hip.so does not contain them.
 """
 from __future__ import annotations
 
 import ctypes as C
+import os
+import subprocess
 
 import numpy as np
 
-from . import _ffi
-from ._ffi import check, u64
-from .matrix import _p, _sfx
-
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspal_synth.so")
 SEED_X = 0xC0FFEE
 HBM_PEAK_BYTES_PER_S = 8.0e12  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+_lib = None
+u64 = C.c_uint64
+
+
+def build() -> None:
+    subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        src = os.path.join(_HERE, "spal_synth.cpp")
+        if not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.spal_synth_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _check(status: int) -> None:
+    if status:
+        raise ValueError(lib().spal_synth_last_error().decode())
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _sfx(dt: np.dtype) -> str:
+    if dt == np.float64:
+        return "f64"
+    if dt == np.float32:
+        return "f32"
+    raise TypeError("Scalar is implemented for f32 and f64 only (src/scalar.rs:56-57)")
 
 
 def matrix_seed(cfg: int) -> int:
@@ -33,16 +69,31 @@ def banded_csr(nrows, ncols, per_row, window, seed, dtype=np.float64, rows=None)
     rp = np.empty(n + 1, dtype=np.uint64)
     ci = np.empty(n * per_row, dtype=np.uint64)
     va = np.empty(n * per_row, dtype=dtype)
-    check(getattr(_ffi.lib(), f"spal_gen_banded_csr_rows_{_sfx(dtype)}")(
+    _check(getattr(lib(), f"spal_synth_banded_csr_rows_{_sfx(dtype)}")(
         u64(nrows), u64(ncols), C.c_uint32(per_row), u64(window), u64(seed), u64(r0), u64(r1),
         _p(rp), _p(ci), _p(va)))
+    return rp, ci, va
+
+
+def ragged_csr(nrows, ncols, window, seed, dtype=np.float64, rows=None):
+    """The robustness variant: row length 1 + next() % 27 (mean 14) from the
+    first draw of the row's stream, then columns and values as banded_csr."""
+    dtype = np.dtype(dtype)
+    r0, r1 = (0, nrows) if rows is None else rows
+    rp = np.empty(r1 - r0 + 1, dtype=np.uint64)
+    _check(lib().spal_synth_ragged_rowptr(u64(nrows), u64(seed), u64(r0), u64(r1), _p(rp)))
+    nnz = int(rp[-1])
+    ci = np.empty(nnz, dtype=np.uint64)
+    va = np.empty(nnz, dtype=dtype)
+    _check(getattr(lib(), f"spal_synth_ragged_fill_{_sfx(dtype)}")(
+        u64(nrows), u64(ncols), u64(window), u64(seed), u64(r0), u64(r1), _p(rp), _p(ci), _p(va)))
     return rp, ci, va
 
 
 def vector(n, seed=SEED_X, dtype=np.float64):
     dtype = np.dtype(dtype)
     x = np.empty(n, dtype=dtype)
-    check(getattr(_ffi.lib(), f"spal_gen_vector_{_sfx(dtype)}")(u64(n), u64(seed), _p(x)))
+    _check(getattr(lib(), f"spal_synth_vector_{_sfx(dtype)}")(u64(n), u64(seed), _p(x)))
     return x
 
 
@@ -51,7 +102,7 @@ def coo(nrows, ncols, length, seed, dup_permille=0, cancel_permille=0, dtype=np.
     r = np.empty(length, dtype=np.uint64)
     c = np.empty(length, dtype=np.uint64)
     v = np.empty(length, dtype=dtype)
-    check(getattr(_ffi.lib(), f"spal_gen_coo_{_sfx(dtype)}")(
+    _check(getattr(lib(), f"spal_synth_coo_{_sfx(dtype)}")(
         u64(nrows), u64(ncols), u64(length), u64(seed), C.c_uint32(dup_permille),
         C.c_uint32(cancel_permille), _p(r), _p(c), _p(v)))
     return r, c, v

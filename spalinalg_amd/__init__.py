@@ -7,7 +7,6 @@ CPU fallback.
 """
 from ._ffi import Panic, SpalError, device_count  # noqa: F401
 from .matrix import CooMatrix, CscMatrix, CsrMatrix, DeviceCoo, DeviceCsr, DeviceCsc, MultiGpuCsr  # noqa: F401
-from . import synth  # noqa: F401
 
 __all__ = ["CsrMatrix", "CscMatrix", "CooMatrix", "DeviceCsr", "DeviceCsc", "DeviceCoo", "MultiGpuCsr", "Panic",
-           "SpalError", "device_count", "synth"]
+           "SpalError", "device_count"]

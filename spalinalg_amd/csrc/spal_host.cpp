@@ -1,6 +1,5 @@
 // spal_host.cpp -- host-only parts of libspal_hip.so: error state, the
-// constructor invariants of the reference, the row partitioner and the
-// synthetic-input generators.  Nothing here touches a device.
+// constructor invariants of the reference and the row partitioner.  Nothing here touches a device.
 #include "spal_internal.hpp"
 
 namespace spal {
@@ -110,116 +109,6 @@ const char *invariant_text(int reason, bool csr) {
     }
 }
 
-// ---------------------------------------------------------------------------
-// SplitMix64.  The state after k draws is
-// seed + k*GAMMA, so any draw is addressable without the ones before it.
-// ---------------------------------------------------------------------------
-static constexpr uint64_t GAMMA = 0x9E3779B97F4A7C15ull;
-static constexpr uint64_t ROW_MULT = 0xD1B54A32D192ED03ull;
-
-static inline uint64_t mix64(uint64_t z) {
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-struct SplitMix {
-    uint64_t s;
-    explicit SplitMix(uint64_t seed) : s(seed) {}
-    inline uint64_t next() { s += GAMMA; return mix64(s); }
-};
-static inline uint64_t draw_at(uint64_t seed, uint64_t k) {  // k-th draw, k >= 0
-    return mix64(seed + (k + 1) * GAMMA);
-}
-static inline double unit_value(uint64_t r) {  // 2u - 1, u = (r >> 11) * 2^-53
-    return 2.0 * ((double)(r >> 11) * (1.0 / 9007199254740992.0)) - 1.0;
-}
-
-// Generates rows [row_begin, row_end) of the nrows x ncols matrix; rowptr
-// (row_end - row_begin + 1 entries) is rebased to start at 0.
-template <typename T>
-static int gen_banded(uint64_t nrows, uint64_t ncols, uint32_t per_row, uint64_t window,
-                      uint64_t seed, uint64_t row_begin, uint64_t row_end, uint64_t *rowptr,
-                      uint64_t *colind, T *values) {
-    if (!rowptr || !colind || !values)
-        return fail(SPAL_ERR_INVALID_ARGUMENT, "gen_banded: null output");
-    if (nrows == 0 || ncols == 0 || per_row == 0 || window == 0 || window > ncols ||
-        per_row > window || per_row > 256)
-        return fail(SPAL_ERR_INVALID_ARGUMENT,
-                    "gen_banded: need 0 < per_row <= min(window, 256), window <= ncols");
-    if (row_begin > row_end || row_end > nrows)
-        return fail(SPAL_ERR_INVALID_ARGUMENT, "gen_banded: bad row range");
-    parallel_for(row_end - row_begin, [&](uint64_t b, uint64_t e, unsigned) {
-        uint64_t cols[256];
-        for (uint64_t local = b; local < e; ++local) {
-            const uint64_t row = row_begin + local;
-            SplitMix rng(seed ^ (ROW_MULT * (row + 1)));
-            // window start: centred on the (scaled) diagonal, clamped into range
-            const uint64_t centre =
-                (uint64_t)(((unsigned __int128)row * ncols) / nrows);
-            uint64_t w0 = centre < window / 2 ? 0 : centre - window / 2;
-            if (w0 > ncols - window) w0 = ncols - window;
-            uint32_t k = 0;
-            while (k < per_row) {
-                const uint64_t c = w0 + rng.next() % window;
-                bool dup = false;
-                for (uint32_t j = 0; j < k; ++j) dup |= (cols[j] == c);
-                if (!dup) cols[k++] = c;
-            }
-            std::sort(cols, cols + per_row);
-            const uint64_t base = local * per_row;
-            rowptr[local] = base;
-            for (uint32_t j = 0; j < per_row; ++j) {
-                colind[base + j] = cols[j];
-                values[base + j] = (T)unit_value(rng.next());
-            }
-        }
-    }, 1u << 12);
-    rowptr[row_end - row_begin] = (row_end - row_begin) * per_row;
-    return SPAL_OK;
-}
-
-template <typename T>
-static int gen_vector(uint64_t n, uint64_t seed, T *x) {
-    if (!x && n) return fail(SPAL_ERR_INVALID_ARGUMENT, "gen_vector: null output");
-    parallel_for(n, [&](uint64_t b, uint64_t e, unsigned) {
-        for (uint64_t j = b; j < e; ++j) x[j] = (T)unit_value(draw_at(seed, j));
-    });
-    return SPAL_OK;
-}
-
-template <typename T>
-static int gen_coo(uint64_t nrows, uint64_t ncols, uint64_t len, uint64_t seed,
-                   uint32_t dup_permille, uint32_t cancel_permille, uint64_t *rows,
-                   uint64_t *cols, T *vals) {
-    if (len && (!rows || !cols || !vals))
-        return fail(SPAL_ERR_INVALID_ARGUMENT, "gen_coo: null output");
-    if (nrows == 0 || ncols == 0 || dup_permille + cancel_permille > 1000)
-        return fail(SPAL_ERR_INVALID_ARGUMENT, "gen_coo: bad shape or rates");
-    // base triplet i uses draws 3i, 3i+1, 3i+2 of the stream
-    auto base_row = [&](uint64_t i) { return draw_at(seed, 3 * i) % nrows; };
-    auto base_col = [&](uint64_t i) { return draw_at(seed, 3 * i + 1) % ncols; };
-    auto base_val = [&](uint64_t i) { return (T)unit_value(draw_at(seed, 3 * i + 2)); };
-    const uint64_t seed2 = mix64(seed ^ 0xA5A5A5A5DEADBEEFull);
-    parallel_for(len, [&](uint64_t b, uint64_t e, unsigned) {
-        for (uint64_t i = b; i < e; ++i) {
-            uint64_t r = base_row(i), c = base_col(i);
-            T v = base_val(i);
-            if (i > 0 && (dup_permille || cancel_permille)) {
-                const uint64_t h = draw_at(seed2, i);
-                const uint32_t t = (uint32_t)(h % 1000);
-                const uint64_t j = (h >> 20) % i;  // an earlier entry's BASE triplet
-                if (t < dup_permille) {
-                    r = base_row(j); c = base_col(j);
-                } else if (t < dup_permille + cancel_permille) {
-                    r = base_row(j); c = base_col(j); v = -base_val(j);
-                }
-            }
-            rows[i] = r; cols[i] = c; vals[i] = v;
-        }
-    });
-    return SPAL_OK;
-}
-
 }  // namespace spal
 
 using namespace spal;
@@ -279,39 +168,6 @@ int spal_partition_rows(const uint64_t *rowptr, uint64_t nrows, uint32_t nparts,
     }
     bounds[nparts] = nrows;
     return SPAL_OK;
-}
-
-int spal_gen_banded_csr_f64(uint64_t nrows, uint64_t ncols, uint32_t per_row, uint64_t window,
-                            uint64_t seed, uint64_t *rowptr, uint64_t *colind, double *values) {
-    return gen_banded<double>(nrows, ncols, per_row, window, seed, 0, nrows, rowptr, colind, values);
-}
-int spal_gen_banded_csr_rows_f64(uint64_t nrows, uint64_t ncols, uint32_t per_row, uint64_t window,
-                                 uint64_t seed, uint64_t row_begin, uint64_t row_end,
-                                 uint64_t *rowptr, uint64_t *colind, double *values) {
-    return gen_banded<double>(nrows, ncols, per_row, window, seed, row_begin, row_end, rowptr,
-                              colind, values);
-}
-int spal_gen_banded_csr_rows_f32(uint64_t nrows, uint64_t ncols, uint32_t per_row, uint64_t window,
-                                 uint64_t seed, uint64_t row_begin, uint64_t row_end,
-                                 uint64_t *rowptr, uint64_t *colind, float *values) {
-    return gen_banded<float>(nrows, ncols, per_row, window, seed, row_begin, row_end, rowptr,
-                             colind, values);
-}
-int spal_gen_banded_csr_f32(uint64_t nrows, uint64_t ncols, uint32_t per_row, uint64_t window,
-                            uint64_t seed, uint64_t *rowptr, uint64_t *colind, float *values) {
-    return gen_banded<float>(nrows, ncols, per_row, window, seed, 0, nrows, rowptr, colind, values);
-}
-int spal_gen_vector_f64(uint64_t n, uint64_t seed, double *x) { return gen_vector(n, seed, x); }
-int spal_gen_vector_f32(uint64_t n, uint64_t seed, float *x) { return gen_vector(n, seed, x); }
-int spal_gen_coo_f64(uint64_t nrows, uint64_t ncols, uint64_t len, uint64_t seed,
-                     uint32_t dup_permille, uint32_t cancel_permille, uint64_t *rows,
-                     uint64_t *cols, double *vals) {
-    return gen_coo<double>(nrows, ncols, len, seed, dup_permille, cancel_permille, rows, cols, vals);
-}
-int spal_gen_coo_f32(uint64_t nrows, uint64_t ncols, uint64_t len, uint64_t seed,
-                     uint32_t dup_permille, uint32_t cancel_permille, uint64_t *rows,
-                     uint64_t *cols, float *vals) {
-    return gen_coo<float>(nrows, ncols, len, seed, dup_permille, cancel_permille, rows, cols, vals);
 }
 
 }  // extern "C"

@@ -1,12 +1,13 @@
-// Host-only parts of libspal_hip (spal_host.cpp) under ASan + UBSan: the
-// constructor invariants, the row partitioner and the generators, driven with
-// edge-case and fuzzed inputs.  Built with g++ (no device code involved).
+// Host-only parts of libspal_hip (spal_host.cpp: the constructor invariants, the row
+// partitioner) and the bench input generators (spal_synth/spal_synth.cpp) under ASan +
+// UBSan, driven with edge-case and fuzzed inputs.  Built with g++ (no device code involved).
 #include <cstdio>
 #include <cstdlib>
 #include <random>
 #include <vector>
 
 #include "spal.h"
+#include "spal_synth.h"
 
 static int failures = 0;
 #define CHECK(c) do { if (!(c)) { printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); ++failures; } } while (0)
@@ -50,22 +51,39 @@ int main() {
         const uint64_t n = 4097;
         std::vector<uint64_t> rp(n + 1), ci(n * 14);
         std::vector<double> va(n * 14);
-        CHECK(spal_gen_banded_csr_f64(n, n, 14, 64, 1, rp.data(), ci.data(), va.data()) == SPAL_OK);
+        CHECK(spal_synth_banded_csr_rows_f64(n, n, 14, 64, 1, 0, n, rp.data(), ci.data(), va.data()) == 0);
         CHECK(spal_csr_validate(n, n, rp.data(), n + 1, ci.data(), n * 14, n * 14, &reason) == SPAL_OK);
-        CHECK(spal_gen_banded_csr_f64(n, n, 14, n, 1, rp.data(), ci.data(), va.data()) == SPAL_OK);       // window == ncols
-        CHECK(spal_gen_banded_csr_f64(n, n, 14, n + 1, 1, rp.data(), ci.data(), va.data()) == SPAL_ERR_INVALID_ARGUMENT);
-        CHECK(spal_gen_banded_csr_f64(n, n, 257, n, 1, rp.data(), ci.data(), va.data()) == SPAL_ERR_INVALID_ARGUMENT);
+        CHECK(spal_synth_banded_csr_rows_f64(n, n, 14, n, 1, 0, n, rp.data(), ci.data(), va.data()) == 0);       // window == ncols
+        CHECK(spal_synth_banded_csr_rows_f64(n, n, 14, n + 1, 1, 0, n, rp.data(), ci.data(), va.data()) != 0);
+        CHECK(spal_synth_banded_csr_rows_f64(n, n, 257, n, 1, 0, n, rp.data(), ci.data(), va.data()) != 0);
         std::vector<uint64_t> srp(101), sci(100 * 14);
         std::vector<float> sva(100 * 14);
-        CHECK(spal_gen_banded_csr_rows_f32(n, n, 14, 64, 1, n - 100, n, srp.data(), sci.data(), sva.data()) == SPAL_OK);
-        CHECK(spal_gen_banded_csr_rows_f32(n, n, 14, 64, 1, n - 100, n + 1, srp.data(), sci.data(), sva.data()) == SPAL_ERR_INVALID_ARGUMENT);
+        CHECK(spal_synth_banded_csr_rows_f32(n, n, 14, 64, 1, n - 100, n, srp.data(), sci.data(), sva.data()) == 0);
+        CHECK(spal_synth_banded_csr_rows_f32(n, n, 14, 64, 1, n - 100, n + 1, srp.data(), sci.data(), sva.data()) != 0);
+        // ragged rows (1 ... 27 entries): a valid CsrMatrix, a slice equals the same rows of the whole
+        std::vector<uint64_t> grp(n + 1);
+        CHECK(spal_synth_ragged_rowptr(n, 9, 0, n, grp.data()) == 0);
+        std::vector<uint64_t> gci(grp[n]);
+        std::vector<double> gva(grp[n]);
+        CHECK(spal_synth_ragged_fill_f64(n, n, 64, 9, 0, n, grp.data(), gci.data(), gva.data()) == 0);
+        CHECK(spal_csr_validate(n, n, grp.data(), n + 1, gci.data(), grp[n], grp[n], &reason) == SPAL_OK);
+        for (uint64_t r = 0; r < n; ++r) CHECK(grp[r + 1] - grp[r] >= 1 && grp[r + 1] - grp[r] <= 27);
+        std::vector<uint64_t> hrp(101);
+        CHECK(spal_synth_ragged_rowptr(n, 9, n - 100, n, hrp.data()) == 0);
+        CHECK(hrp[100] == grp[n] - grp[n - 100]);
+        std::vector<uint64_t> hci(hrp[100]);
+        std::vector<double> hva(hrp[100]);
+        CHECK(spal_synth_ragged_fill_f64(n, n, 64, 9, n - 100, n, hrp.data(), hci.data(), hva.data()) == 0);
+        for (uint64_t i = 0; i < hrp[100]; ++i) CHECK(hci[i] == gci[grp[n - 100] + i] && hva[i] == gva[grp[n - 100] + i]);
+        CHECK(spal_synth_ragged_fill_f64(n, n, 64, 10, 0, n, grp.data(), gci.data(), gva.data()) != 0);   // rowptr of another seed
+        CHECK(spal_synth_ragged_fill_f64(n, n, 26, 9, 0, n, grp.data(), gci.data(), gva.data()) != 0);    // window < 27
         std::vector<uint64_t> r(100000), c(100000);
         std::vector<double> v(100000);
-        CHECK(spal_gen_coo_f64(10, 3, 100000, 5, 10, 1, r.data(), c.data(), v.data()) == SPAL_OK);
+        CHECK(spal_synth_coo_f64(10, 3, 100000, 5, 10, 1, r.data(), c.data(), v.data()) == 0);
         for (size_t i = 0; i < r.size(); ++i) CHECK(r[i] < 10 && c[i] < 3);
         std::vector<float> x(12345);
-        CHECK(spal_gen_vector_f32(x.size(), 3, x.data()) == SPAL_OK);
-        CHECK(spal_gen_vector_f64(0, 3, nullptr) == SPAL_OK);
+        CHECK(spal_synth_vector_f32(x.size(), 3, x.data()) == 0);
+        CHECK(spal_synth_vector_f64(0, 3, nullptr) == 0);
     }
     CHECK(spal_last_error() != nullptr && spal_version() != nullptr);
     printf("host sanitize: %d failure(s)\n", failures);

@@ -29,12 +29,13 @@ def test_cpp_mirror_gpu():
 
 
 def test_host_code_under_asan_ubsan():
-    """spal_host.cpp (validation, partition, generators) compiled with g++
+    """spal_host.cpp (validation, partition) and spal_synth.cpp (generators) compiled with g++
     -fsanitize=address,undefined and driven with edge-case / fuzzed inputs."""
     exe = os.path.join(ROOT, "tests", "cpp", "test_host_sanitize")
     subprocess.check_call(
         ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
          "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+         "-I", os.path.join(ROOT, "spal_synth"), os.path.join(ROOT, "spal_synth", "spal_synth.cpp"),
          os.path.join(ROOT, "spalinalg_amd", "csrc", "spal_host.cpp"),
          os.path.join(ROOT, "tests", "cpp", "test_host_sanitize.cpp"), "-o", exe, "-pthread"])
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1")

@@ -17,6 +17,7 @@ def _worker(rank, world, port, equal, q):
     import torch.distributed as dist
     import oracle
     import spalinalg_amd as sp
+    import spal_synth as synth
     from spalinalg_amd.dist import RowPartitionedSpmv, partition_rows
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -24,7 +25,7 @@ def _worker(rank, world, port, equal, q):
     try:
         n = 3000 if equal else 3001
         if equal:
-            rp, ci, va = sp.synth.banded_csr(n, n, 14, 256, 42)
+            rp, ci, va = synth.banded_csr(n, n, 14, 256, 42)
         else:
             rng = np.random.default_rng(1)          # same on every rank
             lens = rng.integers(0, 30, n)
@@ -40,20 +41,20 @@ def _worker(rank, world, port, equal, q):
             out_local[: y.size].copy_(torch.from_numpy(y))
 
         op = RowPartitionedSpmv(local, bounds, rank, world, torch.float64, "cpu")
-        x = torch.from_numpy(sp.synth.vector(n)) if rank == 0 else torch.zeros(n, dtype=torch.float64)
+        x = torch.from_numpy(synth.vector(n)) if rank == 0 else torch.zeros(n, dtype=torch.float64)
         op.broadcast_x(x)
         y = torch.empty(n, dtype=torch.float64)
         op.spmv(x, y)
-        y_ref = oracle.csr_spmv(rp, ci, va, sp.synth.vector(n))
+        y_ref = oracle.csr_spmv(rp, ci, va, synth.vector(n))
         ok = bool(np.array_equal(y.numpy(), y_ref))
         if equal:
             # scatter of the x windows + gather of the y slices on rank 0 ("end" mode of bench.py)
             lo, hi = int(shard.colind().min()), int(shard.colind().max()) + 1
             needs = op.plan_x_windows(lo, hi)
-            x2 = torch.from_numpy(sp.synth.vector(n)) if rank == 0 else torch.full((n,), np.nan, dtype=torch.float64)
+            x2 = torch.from_numpy(synth.vector(n)) if rank == 0 else torch.full((n,), np.nan, dtype=torch.float64)
             a0, a1 = op.distribute_x(x2, n, needs)
             ok = ok and a0 <= lo and hi <= a1
-            ok = ok and bool(np.array_equal(x2.numpy()[a0:a1], sp.synth.vector(n)[a0:a1]))
+            ok = ok and bool(np.array_equal(x2.numpy()[a0:a1], synth.vector(n)[a0:a1]))
             xs = torch.nan_to_num(x2, nan=0.0)          # columns outside the window are never read
             op.local_only(xs)
             y2 = torch.full((n,), np.nan, dtype=torch.float64)
@@ -90,13 +91,14 @@ def _halo_worker(rank, world, port, q):
     import torch.distributed as dist
     import oracle
     import spalinalg_amd as sp
+    import spal_synth as synth
     from spalinalg_amd.dist import RowPartitionedSpmv, partition_rows
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         n, w = 6000, 512
-        rp, ci, va = sp.synth.banded_csr(n, n, 14, w, 77)
+        rp, ci, va = synth.banded_csr(n, n, 14, w, 77)
         bounds = partition_rows(rp, world)
         a = sp.CsrMatrix(n, n, rp, ci, va)
         r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
@@ -109,7 +111,7 @@ def _halo_worker(rank, world, port, q):
         op = RowPartitionedSpmv(local, bounds, rank, world, torch.float64, "cpu")
         need_lo, need_hi = int(shard.colind().min()), int(shard.colind().max()) + 1
         op.plan_halo(need_lo, need_hi)
-        x0 = sp.synth.vector(n)
+        x0 = synth.vector(n)
         # two products in a row, y feeding back as x: only own slice + halo is ever exchanged
         x = torch.from_numpy(x0.copy())
         y = torch.full((n,), float("nan"), dtype=torch.float64)

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import spalinalg_amd as sp
+import spal_synth as synth
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = json.load(open(os.path.join(HERE, "golden", "generated_cases.json")))["cases"]
@@ -22,7 +23,7 @@ def sha(*arrays):
 
 
 def coo_case(c):
-    return sp.synth.coo(c["nrows"], c["ncols"], c["length"], c["seed"], c["dup_permille"], c["cancel_permille"])
+    return synth.coo(c["nrows"], c["ncols"], c["length"], c["seed"], c["dup_permille"], c["cancel_permille"])
 
 
 def test_oracle_reproduces_generated_goldens(oracle):
@@ -34,12 +35,12 @@ def test_oracle_reproduces_generated_goldens(oracle):
             if "csc_sha256" in c:
                 assert sha(*oracle.coo_to_csc(c["nrows"], c["ncols"], r, cc, v)) == c["csc_sha256"], name
             if "y_sha256" in c:
-                assert sha(oracle.csr_spmv(p, i, w, sp.synth.vector(c["ncols"], c["x_seed"]))) == c["y_sha256"], name
+                assert sha(oracle.csr_spmv(p, i, w, synth.vector(c["ncols"], c["x_seed"]))) == c["y_sha256"], name
         else:
             dt = np.float64 if c["dtype"] == "f64" else np.float32
-            rp, ci, va = sp.synth.banded_csr(c["nrows"], c["ncols"], c["per_row"], c["window"], c["seed"], dtype=dt)
+            rp, ci, va = synth.banded_csr(c["nrows"], c["ncols"], c["per_row"], c["window"], c["seed"], dtype=dt)
             assert sha(rp, ci, va) == c["input_sha256"], name        # the generator is pinned too
-            x = sp.synth.vector(c["ncols"], c["x_seed"], dtype=dt)
+            x = synth.vector(c["ncols"], c["x_seed"], dtype=dt)
             assert sha(oracle.csr_spmv(rp, ci, va, x)) == c["y_sha256"], name
             assert sha(*oracle.transpose(c["nrows"], c["ncols"], rp, ci, va)) == c["csc_sha256"], name
 
@@ -59,14 +60,14 @@ def test_gpu_hits_generated_goldens():
             if "y_sha256" in c:
                 dev = csr.device()
                 dev.set_option("kernel", 2)       # lane-per-row sums: the reference's order
-                y = dev.spmv(sp.synth.vector(c["ncols"], c["x_seed"]))
+                y = dev.spmv(synth.vector(c["ncols"], c["x_seed"]))
                 if dev.describe()["stream_row_fraction"] == 1.0:
                     assert sha(y) == c["y_sha256"], name
         else:
             dt = np.float64 if c["dtype"] == "f64" else np.float32
-            rp, ci, va = sp.synth.banded_csr(c["nrows"], c["ncols"], c["per_row"], c["window"], c["seed"], dtype=dt)
+            rp, ci, va = synth.banded_csr(c["nrows"], c["ncols"], c["per_row"], c["window"], c["seed"], dtype=dt)
             a = sp.CsrMatrix(c["nrows"], c["ncols"], rp, ci, va)
-            x = sp.synth.vector(c["ncols"], c["x_seed"], dtype=dt)
+            x = synth.vector(c["ncols"], c["x_seed"], dtype=dt)
             assert a.device().describe()["kernel"] == "stream"
             assert sha(a * x) == c["y_sha256"], name
             csc = sp.CscMatrix.from_csr(a)

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import spalinalg_amd as sp
+import spal_synth as synth
 from tests.util import assert_spmv_close, random_csr
 
 pytestmark = pytest.mark.gpu
@@ -60,9 +61,9 @@ def test_csc_transposed_kernel_is_bit_identical(oracle):
     """kernel 2 (the default): CSC -> CSR once on the device, then the stream
     kernel: y equals the reference's k-ascending sums bit for bit."""
     n = 200_000
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, 3)
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, 3)
     cp, ri, cv = oracle.transpose(n, n, rp, ci, va)
-    x = sp.synth.vector(n)
+    x = synth.vector(n)
     dev = sp.CscMatrix(n, n, cp, ri, cv).device()
     assert dev.describe()["kernel"] == "transposed_csr"
     y = dev.spmv(x)
@@ -102,7 +103,7 @@ def test_csc_lds_and_global_paths(oracle):
     the oracle, as must the forced global path."""
     rng = np.random.default_rng(8)
     n = 30_000
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, 2048, 21)
+    rp, ci, va = synth.banded_csr(n, n, 14, 2048, 21)
     cp, ri, cv = oracle.transpose(n, n, rp, ci, va)        # CSC of a banded matrix
     cols = [ri[int(cp[k]):int(cp[k + 1])] for k in range(n)]
     vals = [cv[int(cp[k]):int(cp[k + 1])] for k in range(n)]
@@ -111,7 +112,7 @@ def test_csc_lds_and_global_paths(oracle):
         vals[k] = rng.uniform(-1, 1, 3000)
     cp = np.concatenate([[0], np.cumsum([c.size for c in cols])]).astype(np.uint64)
     ri, cv = np.concatenate(cols), np.concatenate(vals)
-    x = sp.synth.vector(n)
+    x = synth.vector(n)
     x[12_000] = np.inf
     m = sp.CscMatrix(n, n, cp, ri, cv)
     rp2, ci2, va2 = oracle.transpose(n, n, cp, ri, cv)      # rows again, for the error bound
@@ -140,9 +141,9 @@ def test_csc_lds_and_global_paths(oracle):
 def test_csc_config4(oracle):
     """BASELINE config 4: CSC of the config-2 matrix, 1M x 1M."""
     n = 1_000_000
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, sp.synth.matrix_seed(2))
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, synth.matrix_seed(2))
     cp, ri, cv = oracle.transpose(n, n, rp, ci, va)
-    x = sp.synth.vector(n)
+    x = synth.vector(n)
     m = sp.CscMatrix(n, n, cp, ri, cv)
     m.device().set_option("kernel", 1)          # the atomic scatter path config 4 names
     y = m * x
@@ -304,11 +305,11 @@ def test_coo_out_of_bounds_panics():
 
 def test_config1_coo_to_csr_then_spmv(oracle):
     """BASELINE config 1: 10k x 10k, 100k random triplets -> CSR -> SpMV."""
-    cfg = sp.synth.CONFIGS[1]
-    r, c, v = sp.synth.coo(cfg["nrows"], cfg["ncols"], cfg["length"], sp.synth.matrix_seed(1))
+    cfg = synth.CONFIGS[1]
+    r, c, v = synth.coo(cfg["nrows"], cfg["ncols"], cfg["length"], synth.matrix_seed(1))
     csr = assemble_and_compare(oracle, cfg["nrows"], cfg["ncols"], r, c, v)
     assert 99_000 < csr.nnz() <= 100_000
-    x = sp.synth.vector(cfg["ncols"])
+    x = synth.vector(cfg["ncols"])
     y = csr * x
     y_ref = oracle.csr_spmv(csr.rowptr(), csr.colind(), csr.values(), x)
     assert_spmv_close(y, y_ref, oracle.csr_abs_bound(csr.rowptr(), csr.colind(), csr.values(), x), 1e-10)
@@ -318,7 +319,7 @@ def test_config5_scaled_assembly(oracle):
     """BASELINE config 5 generator (1 % duplicates, 0.1 % cancelling pairs) at
     2M entries, bit-exact against the oracle."""
     nr = nc = 200_000
-    r, c, v = sp.synth.coo(nr, nc, 2_000_000, sp.synth.matrix_seed(5), 10, 1)
+    r, c, v = synth.coo(nr, nc, 2_000_000, synth.matrix_seed(5), 10, 1)
     csr = assemble_and_compare(oracle, nr, nc, r, c, v)
     assert csr.nnz() < 2_000_000
 
@@ -366,7 +367,7 @@ def test_assembled_handle_plans_like_an_uploaded_one(oracle):
     matrix gets when it is uploaded from the host, and multiply bit-identically."""
     rng = np.random.default_rng(91)
     for n, per_row, window in [(40_000, 14, 2048), (100_000, 5, 600), (3_000, 40, 3_000), (70_001, 9, 70_001)]:
-        rp, ci, va = sp.synth.banded_csr(n, n, per_row, window, 17)
+        rp, ci, va = synth.banded_csr(n, n, per_row, window, 17)
         rows = np.repeat(np.arange(n, dtype=np.uint64), np.diff(rp).astype(np.int64))
         perm = rng.permutation(rows.size)                       # insertion order: shuffled
         coo = sp.CooMatrix.with_triplets(n, n, rows[perm], ci[perm], va[perm])
@@ -380,7 +381,7 @@ def test_assembled_handle_plans_like_an_uploaded_one(oracle):
             assert dg[k] == dr[k], (k, dg, dr)
         gp, gi, gv = got.download()
         assert np.array_equal(gp, rp) and np.array_equal(gi, ci) and np.array_equal(gv, va)
-        x = sp.synth.vector(n)
+        x = synth.vector(n)
         assert np.array_equal(got.spmv(x), ref.spmv(x))
         got.close()
         dcoo.close()
@@ -394,9 +395,9 @@ def test_full_size_config5_properties():
     the result equals the product summed straight from the triplets, and two
     assemblies give identical arrays."""
     torch = pytest.importorskip("torch")
-    cfg = sp.synth.CONFIGS[5]
+    cfg = synth.CONFIGS[5]
     nr, length = cfg["nrows"], cfg["length"]
-    r, c, v = sp.synth.coo(nr, nr, length, sp.synth.matrix_seed(5), cfg["dup_permille"], cfg["cancel_permille"])
+    r, c, v = synth.coo(nr, nr, length, synth.matrix_seed(5), cfg["dup_permille"], cfg["cancel_permille"])
     dcoo = sp.CooMatrix.with_triplets(nr, nr, r, c, v).upload()
     a = dcoo.assemble_csr()
     assert dcoo.describe()["last_route"] == "local_sort"
@@ -412,7 +413,7 @@ def test_full_size_config5_properties():
     assert np.all((d > 0) | row_start[1:])
     assert ci.max() < nr and not np.any(va == 0.0)                          # coo.rs:64
     # the product: straight from the triplets (float64 index_add, another order) vs the kernel
-    x = torch.from_numpy(sp.synth.vector(nr)).cuda()
+    x = torch.from_numpy(synth.vector(nr)).cuda()
     y = a.spmv_torch(x)
     rt, ct, vt = (torch.from_numpy(t.astype(np.int64) if t.dtype != np.float64 else t).cuda() for t in (r, c, v))
     y_direct = torch.zeros(nr, dtype=torch.float64, device="cuda").index_add_(0, rt, vt * x[ct])

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import spalinalg_amd as sp
+import spal_synth as synth
 from tests.util import assert_spmv_close, random_csr
 
 pytestmark = pytest.mark.gpu
@@ -68,8 +69,8 @@ def test_stream_kernel_is_bit_identical_to_the_reference_order(oracle):
     rng = np.random.default_rng(2)
     for dtype in (np.float64, np.float32):
         n = 300_000
-        rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, 11, dtype=dtype)
-        x = sp.synth.vector(n, dtype=dtype)
+        rp, ci, va = synth.banded_csr(n, n, 14, 4096, 11, dtype=dtype)
+        x = synth.vector(n, dtype=dtype)
         dev = sp.CsrMatrix(n, n, rp, ci, va).device()
         d = dev.describe()
         assert d["kernel"] == "stream" and d["stream_row_fraction"] == 1.0 and d["index_bits"] == 16
@@ -143,8 +144,8 @@ def test_stream_kernel_bank_skew_and_8_row_tiles(oracle, per_row, dtype, rpt, sk
     LDS bank otherwise); rows of 65 ... 120 entries stream in tiles of 8 rows.  Both are layout / geometry only:
     every form stays bit-identical to the reference order."""
     n = 40_003
-    rp, ci, va = sp.synth.banded_csr(n, n, per_row, 2048, 40 + per_row, dtype=dtype)
-    x = sp.synth.vector(n, dtype=dtype)
+    rp, ci, va = synth.banded_csr(n, n, per_row, 2048, 40 + per_row, dtype=dtype)
+    x = synth.vector(n, dtype=dtype)
     dev = sp.CsrMatrix(n, n, rp, ci, va).device()
     d = dev.describe()
     assert d["kernel"] == "stream" and d["rows_per_tile"] == rpt and d["skew"] == skew, d
@@ -159,7 +160,7 @@ def test_stream_kernel_bank_skew_and_8_row_tiles(oracle, per_row, dtype, rpt, sk
     dev.set_option("skew", -1)
     assert dev.describe()["skew"] == skew
     # the same rows with columns all over the matrix: x through L2 (32-bit columns), same strips
-    rp, ci, va = sp.synth.banded_csr(n, n, per_row, n, 41 + per_row, dtype=dtype)
+    rp, ci, va = synth.banded_csr(n, n, per_row, n, 41 + per_row, dtype=dtype)
     dev = sp.CsrMatrix(n, n, rp, ci, va).device()
     d = dev.describe()
     assert d["kernel"] == "stream" and d["skew"] == skew and d["lds_row_fraction"] == 0.0, d
@@ -181,7 +182,7 @@ def test_stream_kernel_tall_tiles_several_rows_per_lane(oracle, dtype, lo, hi, r
     key = np.unique(rows * n + cols)
     rp = np.concatenate([[0], np.cumsum(np.bincount(key // n, minlength=n))]).astype(np.uint64)
     ci, va = (key % n).astype(np.uint64), rng.uniform(-1, 1, key.size).astype(dtype)
-    x = sp.synth.vector(n, dtype=dtype)
+    x = synth.vector(n, dtype=dtype)
     dev = sp.CsrMatrix(n, n, rp, ci, va).device()
     d = dev.describe()
     assert d["kernel"] == "stream" and d["rows_per_tile"] == rpt and d["overflow_tiles"] == 0, d
@@ -218,8 +219,8 @@ def test_stream_global_mode_bit_identical(oracle):
     instead (32-bit columns), still summing each row in the reference order."""
     n = 300_000
     for window, dtype in ((20_000, np.float64), (None, np.float64), (30_000, np.float32)):
-        rp, ci, va = sp.synth.banded_csr(n, n, 14, window or n, 5, dtype=dtype)
-        x = sp.synth.vector(n, dtype=dtype)
+        rp, ci, va = synth.banded_csr(n, n, 14, window or n, 5, dtype=dtype)
+        x = synth.vector(n, dtype=dtype)
         dev = sp.CsrMatrix(n, n, rp, ci, va).device()
         d = dev.describe()
         assert d["kernel"] == "stream" and d["stream_row_fraction"] == 1.0, d
@@ -247,7 +248,7 @@ def test_long_rows_read_16_bit_columns(oracle, dtype):
     """rows of hundreds of entries: the vector kernel, a wave per row, with 16-bit window-relative columns where the
     block's x window is in LDS -- the index width changes nothing in the arithmetic."""
     n = 30_011
-    rp, ci, va = sp.synth.banded_csr(n, n, 250, 4096, 77, dtype=dtype)
+    rp, ci, va = synth.banded_csr(n, n, 250, 4096, 77, dtype=dtype)
     rp = rp.astype(np.int64)
     ci, va = list(np.split(ci, rp[1:-1])), list(np.split(va, rp[1:-1]))
     rng = np.random.default_rng(3)
@@ -255,7 +256,7 @@ def test_long_rows_read_16_bit_columns(oracle, dtype):
         ci[r] = np.sort(rng.choice(n, 250, replace=False)).astype(np.uint64)
     rp = np.concatenate([[0], np.cumsum([c.size for c in ci])]).astype(np.uint64)
     ci, va = np.concatenate(ci), np.concatenate(va)
-    x = sp.synth.vector(n, dtype=dtype)
+    x = synth.vector(n, dtype=dtype)
     dev = check(oracle, rp, ci, va, x, n)
     d = dev.describe()
     assert d["kernel"] == "vector" and d["index_bits"] == 16 and 0.9 < d["lds_row_fraction"] < 1.0, d
@@ -274,7 +275,7 @@ def test_stream_kernel_mixed_supertiles(oracle):
     the global-gather mode."""
     rng = np.random.default_rng(4)
     n = 20_000
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, 2048, 13)
+    rp, ci, va = synth.banded_csr(n, n, 14, 2048, 13)
     rp, ci, va = rp.astype(np.int64), list(np.split(ci, rp[1:-1].astype(np.int64))), list(np.split(va, rp[1:-1].astype(np.int64)))
     for r, k, span in [(5000, 3000, 4000), (5001, 1500, 4000), (12_345, 200, n), (19_999, 1100, 3000)]:
         lo = max(0, min(r - span // 2, n - span))
@@ -283,7 +284,7 @@ def test_stream_kernel_mixed_supertiles(oracle):
     lens = np.array([c.size for c in ci])
     rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     ci, va = np.concatenate(ci), np.concatenate(va)
-    x = sp.synth.vector(n)
+    x = synth.vector(n)
     dev = check(oracle, rp, ci, va, x, n, kernel=2)
     d = dev.describe()
     assert d["kernel"] == "stream" and 0.5 < d["stream_row_fraction"] < 1.0 and d["overflow_tiles"] >= 3
@@ -300,7 +301,7 @@ def test_oversized_tiles_go_to_the_overflow_kernel(oracle, dtype, rpt):
     more than 1024 entries or a row of more than 128 (option stream_row_max)."""
     rng = np.random.default_rng(77 + rpt)
     n = 20_011                                   # ragged last super-tile and last tile
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, 2048, 21, dtype=dtype)
+    rp, ci, va = synth.banded_csr(n, n, 14, 2048, 21, dtype=dtype)
     rp = rp.astype(np.int64)
     ci, va = list(np.split(ci, rp[1:-1])), list(np.split(va, rp[1:-1]))
     heavy = [(0, 1200), (63, 1500), (64, 1100), (700, 600), (701, 600), (4096, 3000), (4097 + rpt, 2500),
@@ -313,7 +314,7 @@ def test_oversized_tiles_go_to_the_overflow_kernel(oracle, dtype, rpt):
     lens = np.array([c.size for c in ci])
     rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     ci, va = np.concatenate(ci), np.concatenate(va)
-    x = sp.synth.vector(n, dtype=dtype)
+    x = synth.vector(n, dtype=dtype)
     starts = np.arange(0, n, rpt)
     ends = np.minimum(starts + rpt, n)
     lens = np.diff(rp.astype(np.int64))
@@ -367,13 +368,13 @@ def test_rows_per_block_and_window_fallback(oracle, rows_per_block):
     """banded blocks use the LDS window; a few wide rows force the per-block
     global-gather fallback inside the same launch."""
     nr = nc = 40_000
-    rp, ci, va = sp.synth.banded_csr(nr, nc, 14, 1024, 99)
+    rp, ci, va = synth.banded_csr(nr, nc, 14, 1024, 99)
     rng = np.random.default_rng(3)
     # overwrite the column pattern of rows 10000..10009 with full-width rows
     for r in range(10_000, 10_010):
         lo = int(rp[r])
         ci[lo:lo + 14] = np.sort(rng.choice(nc, 14, replace=False))
-    x = sp.synth.vector(nc)
+    x = synth.vector(nc)
     dev = check(oracle, rp, ci, va, x, nc, kernel=1, rows_per_block=rows_per_block)
     d = dev.describe()
     assert d["rows_per_block"] == rows_per_block and d["kernel"] == "vector"
@@ -383,8 +384,8 @@ def test_nan_inf_in_x_stay_local(oracle):
     """NaN / Inf in x reach exactly the rows that reference them (idle lanes
     and clamped loads must not leak them)."""
     nr = nc = 5000
-    rp, ci, va = sp.synth.banded_csr(nr, nc, 14, 256, 5)
-    x = sp.synth.vector(nc)
+    rp, ci, va = synth.banded_csr(nr, nc, 14, 256, 5)
+    x = synth.vector(nc)
     x[0] = np.nan
     x[2500] = np.inf
     x[4999] = -np.inf
@@ -406,8 +407,8 @@ def test_nan_inf_in_x_stay_local(oracle):
 def test_config2_banded_and_uniform(oracle, dtype, window):
     """BASELINE config 2: 1M x 1M, 14 per row; banded (headline) and uniform."""
     n = 1_000_000
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, window or n, sp.synth.matrix_seed(2), dtype=dtype)
-    x = sp.synth.vector(n, dtype=dtype)
+    rp, ci, va = synth.banded_csr(n, n, 14, window or n, synth.matrix_seed(2), dtype=dtype)
+    x = synth.vector(n, dtype=dtype)
     dev = check(oracle, rp, ci, va, x, n)
     d = dev.describe()
     assert d["lds_x"] == (1 if window else 0)
@@ -426,8 +427,8 @@ def test_dimension_mismatch_panics():
 def test_autotune_keeps_results(oracle):
     torch = pytest.importorskip("torch")
     n = 400_000
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, 9)
-    x = sp.synth.vector(n)
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, 9)
+    x = synth.vector(n)
     dev = sp.CsrMatrix(n, n, rp, ci, va).device()
     xd = torch.from_numpy(x).cuda()
     yd = torch.empty_like(xd)
@@ -435,7 +436,7 @@ def test_autotune_keeps_results(oracle):
     assert all(t > 0 for t in d["autotune_us"]) and d["persistent"] in (0, 1) and d["nt_store"] in (0, 1)
     assert np.array_equal(dev.spmv_torch(xd).cpu().numpy(), oracle.csr_spmv(rp, ci, va, x))
     # a matrix the vector kernel handles: nothing to tune, still fine
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, n, 9)
+    rp, ci, va = synth.banded_csr(n, n, 14, n, 9)
     dev = sp.CsrMatrix(n, n, rp, ci, va).device()
     dev.set_option("kernel", 1)
     assert dev.autotune(xd, yd, iters=2)["autotune_us"] == [0.0] * 4
@@ -445,8 +446,8 @@ def test_device_path_with_torch_stream(oracle):
     """the timed entry point: device pointers + torch's current stream."""
     torch = pytest.importorskip("torch")
     n = 200_000
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, 1234)
-    x = sp.synth.vector(n)
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, 1234)
+    x = synth.vector(n)
     dev = sp.CsrMatrix(n, n, rp, ci, va).device()
     xd = torch.from_numpy(x).cuda()
     s = torch.cuda.Stream()
@@ -467,8 +468,8 @@ def test_concurrent_callers_on_one_handle(oracle):
     torch = pytest.importorskip("torch")
     import threading
     n = 120_000
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, 2048, 77)
-    x = sp.synth.vector(n)
+    rp, ci, va = synth.banded_csr(n, n, 14, 2048, 77)
+    x = synth.vector(n)
     y_ref = oracle.csr_spmv(rp, ci, va, x)
     dev = sp.CsrMatrix(n, n, rp, ci, va).device()
     xd = torch.from_numpy(x).cuda()
@@ -496,7 +497,7 @@ def test_concurrent_callers_on_one_handle(oracle):
     for k, y in results.items():
         assert np.array_equal(y, y_ref), k                    # stream kernel: bit-identical
     # handle churn
-    r, c, v = sp.synth.coo(5_000, 5_000, 60_000, 9)
+    r, c, v = synth.coo(5_000, 5_000, 60_000, 9)
     p0, i0, w0 = oracle.coo_to_csr(5_000, 5_000, r, c, v)
     for _ in range(60):
         d = sp.CooMatrix.with_triplets(5_000, 5_000, r, c, v).upload()
@@ -513,14 +514,14 @@ def test_full_size_config3_properties():
     tests): y for x = e (row sums), linearity, and determinism."""
     torch = pytest.importorskip("torch")
     n = 10_000_000
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, sp.synth.matrix_seed(3))
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, synth.matrix_seed(3))
     dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
     ones = torch.ones(n, dtype=torch.float64, device="cuda")
     y1 = dev.spmv_torch(ones).cpu().numpy()
     rowsum = va.reshape(n, 14).sum(axis=1)
     np.testing.assert_allclose(y1, rowsum, rtol=0, atol=1e-13)
-    x = torch.from_numpy(sp.synth.vector(n)).cuda()
-    z = torch.from_numpy(sp.synth.vector(n, seed=77)).cuda()
+    x = torch.from_numpy(synth.vector(n)).cuda()
+    z = torch.from_numpy(synth.vector(n, seed=77)).cuda()
     ax, az = dev.spmv_torch(x), dev.spmv_torch(z)
     comb = dev.spmv_torch(2.0 * x - 0.5 * z)
     assert torch.allclose(comb, 2.0 * ax - 0.5 * az, rtol=0, atol=1e-12)
@@ -537,8 +538,8 @@ def test_single_process_multi_gpu_context(oracle):
     box only ngpus = 1 can run, which still exercises partition, shard upload,
     the resident buffers and the gather layout; more GPUs than visible is refused."""
     n = 150_000
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, 17)
-    x = sp.synth.vector(n)
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, 17)
+    x = synth.vector(n)
     a = sp.CsrMatrix(n, n, rp, ci, va)
     mg = sp.MultiGpuCsr(a, 1)
     assert mg.partition().tolist() == [0, n]
@@ -651,8 +652,8 @@ def test_paged_x_window_stencils_bit_identical(oracle, dtype):
     # a band of 8192 columns: 36 pages, beyond the two-workgroups-per-CU budget of f64 (24 pages) but
     # inside the one-workgroup-per-CU budget (60), which the planner prefers to x through L2
     n = 120_000
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, 8192, 5, dtype=dtype)
-    x = sp.synth.vector(n, dtype=dtype)
+    rp, ci, va = synth.banded_csr(n, n, 14, 8192, 5, dtype=dtype)
+    x = synth.vector(n, dtype=dtype)
     dev = sp.CsrMatrix(n, n, rp, ci, va).device()
     d = dev.describe()
     assert d["kernel"] == "stream" and d["lds_row_fraction"] == 1.0, d
@@ -663,11 +664,11 @@ def test_paged_x_window_stencils_bit_identical(oracle, dtype):
     assert np.array_equal(dev.spmv(x), y_ref)
     # columns too scattered for any page budget: the stream kernel gathers through L2 instead
     n = 150_000
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, n, 5, dtype=dtype)
+    rp, ci, va = synth.banded_csr(n, n, 14, n, 5, dtype=dtype)
     dev = sp.CsrMatrix(n, n, rp, ci, va).device()
     d = dev.describe()
     assert d["kernel"] == "stream" and d["lds_row_fraction"] == 0.0, d
-    x = sp.synth.vector(n, dtype=dtype)
+    x = synth.vector(n, dtype=dtype)
     assert np.array_equal(dev.spmv(x), oracle.csr_spmv(rp, ci, va, x))
     # two bands far apart + a last page that x ends inside of (ncols = 5 * 256 + 3 beyond the band)
     nr, nc = 30_000, 900_003
@@ -726,9 +727,9 @@ def test_device_entry_point_is_graph_capturable(oracle):
     replayed: here y2 = A (A x) for a small matrix, 8 pairs per graph launch."""
     torch = pytest.importorskip("torch")
     n = 50_000
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, 1024, 19)
+    rp, ci, va = synth.banded_csr(n, n, 14, 1024, 19)
     dev = sp.CsrMatrix(n, n, rp, ci, va).device()
-    x = torch.from_numpy(sp.synth.vector(n)).cuda()
+    x = torch.from_numpy(synth.vector(n)).cuda()
     y1, y2 = torch.empty_like(x), torch.empty_like(x)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())

@@ -14,6 +14,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 
 
 def main():
@@ -25,7 +26,7 @@ def main():
     window = None if "uniform" in flags else int(shape.get("window", 4096))
     dtype = np.float32 if "f32" in flags else np.float64
     rounds, iters = 7, 25
-    rp, ci, va = sp.synth.banded_csr(n, n, per_row, window or n, sp.synth.matrix_seed(3), dtype=dtype)
+    rp, ci, va = synth.banded_csr(n, n, per_row, window or n, synth.matrix_seed(3), dtype=dtype)
     devs = []
     for v in variants:  # one handle per variant: no re-planning inside the timed rounds
         d = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
@@ -33,10 +34,10 @@ def main():
             k, val = kv.split("=")
             d.set_option(k, int(val))
         devs.append(d)
-    x = torch.from_numpy(sp.synth.vector(n, dtype=dtype)).cuda()
+    x = torch.from_numpy(synth.vector(n, dtype=dtype)).cuda()
     y = torch.empty_like(x)
     yref = devs[0].spmv_torch(x).clone()
-    B = sp.synth.spmv_bytes(n * per_row, n, n, n, np.dtype(dtype).itemsize)
+    B = synth.spmv_bytes(n * per_row, n, n, n, np.dtype(dtype).itemsize)
     times = [[] for _ in variants]
     for r in range(rounds):
         for i, d in enumerate(devs):

@@ -9,6 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 
 
 def timeit(fn, iters):
@@ -23,12 +24,12 @@ def timeit(fn, iters):
 
 def main():
     n = 10_000_000
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, sp.synth.matrix_seed(3))
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, synth.matrix_seed(3))
     dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
     for kv in sys.argv[1:]:
         k, v = kv.split("=")
         dev.set_option(k, int(v))
-    xh = torch.from_numpy(sp.synth.vector(n))
+    xh = torch.from_numpy(synth.vector(n))
     slack = 1 << 21
     X = torch.zeros(n + slack, dtype=torch.float64, device="cuda")
     Y = torch.zeros(n + slack, dtype=torch.float64, device="cuda")

@@ -14,6 +14,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 
 
 def timeit(fn, iters, warm=3):
@@ -43,15 +44,15 @@ def main():
     np_dt = np.float64 if args.dtype == "f64" else np.float32
     esz = np.dtype(np_dt).itemsize
     t0 = time.time()
-    rp, ci, va = sp.synth.banded_csr(n, n, args.per_row, args.window or n, sp.synth.matrix_seed(3), dtype=np_dt)
+    rp, ci, va = synth.banded_csr(n, n, args.per_row, args.window or n, synth.matrix_seed(3), dtype=np_dt)
     print(f"generated in {time.time()-t0:.1f}s", flush=True)
     t0 = time.time()
     dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
     print(f"uploaded in {time.time()-t0:.1f}s; default plan {dev.describe()}", flush=True)
-    x = torch.from_numpy(sp.synth.vector(n, dtype=np_dt)).cuda()
+    x = torch.from_numpy(synth.vector(n, dtype=np_dt)).cuda()
     y = torch.empty(n, dtype=x.dtype, device="cuda")
     nnz = n * args.per_row
-    B = sp.synth.spmv_bytes(nnz, n, n, n, esz)
+    B = synth.spmv_bytes(nnz, n, n, n, esz)
     results = []
 
     # ceilings: a pure read (sum) and a copy of as many bytes as the matrix stream

@@ -10,6 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 
 
 def stencil_csr(m, points):
@@ -50,10 +51,10 @@ def main():
     for m, points in ((216, 7), (150, 27)):
         n, rp, ci, va = stencil_csr(m, points)
         dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
-        x = torch.from_numpy(sp.synth.vector(n)).cuda()
+        x = torch.from_numpy(synth.vector(n)).cuda()
         y = torch.empty_like(x)
         nnz = int(rp[-1])
-        B = sp.synth.spmv_bytes(nnz, n, n, n, 8)
+        B = synth.spmv_bytes(nnz, n, n, n, 8)
         for opts in ((), (("persistent", 1),), (("kernel", 1),)):
             for k, v in opts:
                 dev.set_option(k, v)

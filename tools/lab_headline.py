@@ -9,6 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 
 
 def timeit(fn, iters):
@@ -23,9 +24,9 @@ def timeit(fn, iters):
 
 n = 10_000_000
 dt = np.float32 if "f32" in sys.argv[1:] else np.float64
-rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, sp.synth.matrix_seed(3), dtype=dt)
+rp, ci, va = synth.banded_csr(n, n, 14, 4096, synth.matrix_seed(3), dtype=dt)
 dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
-x = torch.from_numpy(sp.synth.vector(n, dtype=dt)).cuda()
+x = torch.from_numpy(synth.vector(n, dtype=dt)).cuda()
 y = torch.empty_like(x)
 for _ in range(150):
     dev.spmv_torch(x, out=y)

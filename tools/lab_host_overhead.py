@@ -10,11 +10,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 
 n = 2048
-rp, ci, va = sp.synth.banded_csr(n, n, 14, 512, 3)
+rp, ci, va = synth.banded_csr(n, n, 14, 512, 3)
 dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
-x = torch.from_numpy(sp.synth.vector(n)).cuda()
+x = torch.from_numpy(synth.vector(n)).cuda()
 y = torch.empty_like(x)
 for name, fn in [("dev.spmv_torch", lambda: dev.spmv_torch(x, out=y)),
                  ("torch.add (reference point)", lambda: torch.add(x, x, out=y))]:

@@ -10,17 +10,18 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 160_000_000
 t0 = time.time()
-rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, 99)
+rp, ci, va = synth.banded_csr(n, n, 14, 4096, 99)
 print(f"generated {n} rows, {int(rp[-1])} entries (> 2^31: {int(rp[-1]) > 2**31}) in {time.time() - t0:.0f} s", flush=True)
 t0 = time.time()
 dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
 print(f"uploaded + planned in {time.time() - t0:.0f} s: {dev.describe()}", flush=True)
 rowsum = va.reshape(n, 14).sum(axis=1)
 ones = torch.ones(n, dtype=torch.float64, device="cuda")
-xr = torch.from_numpy(sp.synth.vector(n)).cuda()
+xr = torch.from_numpy(synth.vector(n)).cuda()
 xh = xr.cpu().numpy()
 rows = np.concatenate([np.arange(0, 2000), np.arange(n - 2000, n), np.random.default_rng(1).integers(0, n, 20000),
                        np.arange((2**31) // 14 - 1000, (2**31) // 14 + 1000), np.arange((2**32 - 2**30) // 14, (2**32 - 2**30) // 14 + 1000)])
@@ -44,6 +45,6 @@ for opts in ((("persistent", 0),), (("persistent", 1),), (("kernel", 1),)):
     e1.record()
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / 5
-    B = sp.synth.spmv_bytes(int(rp[-1]), n, n, n, 8)
+    B = synth.spmv_bytes(int(rp[-1]), n, n, n, 8)
     ones.fill_(1.0)
     print(f"{opts}: row sums ok={ok1}, sampled rows wrong={bad} of {rows.size}, {t:.2f} ms = {100 * B / (t * 1e-3) / 8e12:.1f} % of 8 TB/s", flush=True)

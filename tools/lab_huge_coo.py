@@ -10,11 +10,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 
 length = int(sys.argv[1]) if len(sys.argv) > 1 else 2_300_000_000
 nr = length // 10
 t0 = time.time()
-r, c, v = sp.synth.coo(nr, nr, length, 1234, 10, 1)
+r, c, v = synth.coo(nr, nr, length, 1234, 10, 1)
 print(f"generated {length} triplets (> 2^31: {length > 2**31}) into {nr} x {nr} in {time.time() - t0:.0f} s", flush=True)
 t0 = time.time()
 d = sp.CooMatrix.with_triplets(nr, nr, r, c, v).upload()
@@ -31,7 +32,7 @@ for _ in range(3):
     if _ < 2:
         a.close()
 print(f"assembled: {min(ts) * 1e3:.1f} ms = {length / min(ts) / 1e9:.1f} G entries/s, nnz {nnz} (< len: {nnz < length}), {route}", flush=True)
-x = torch.from_numpy(sp.synth.vector(nr)).cuda()
+x = torch.from_numpy(synth.vector(nr)).cuda()
 y = a.spmv_torch(x)
 chunk = 200_000_000
 y_direct = torch.zeros(nr, dtype=torch.float64, device="cuda")

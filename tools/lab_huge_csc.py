@@ -9,11 +9,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
-rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, 7)
+rp, ci, va = synth.banded_csr(n, n, 14, 4096, 7)
 csr = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
-x = torch.from_numpy(sp.synth.vector(n)).cuda()
+x = torch.from_numpy(synth.vector(n)).cuda()
 y_csr = csr.spmv_torch(x)
 t0 = time.time()
 csc = csr.to_csc()

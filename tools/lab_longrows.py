@@ -8,6 +8,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 from tools.lab_zoo import from_lens, timeit  # noqa: E402
 
 
@@ -21,9 +22,9 @@ def main():
     for per, n, W in cases:
         rp, ci, va = from_lens(np.full(n, per, np.int64), lambda r, p, g: np.clip(r - W // 2 + g.integers(0, W, r.size), 0, n - 1), rng)
         nnz = int(rp[-1])
-        B = sp.synth.spmv_bytes(nnz, n, n, n, 8)
+        B = synth.spmv_bytes(nnz, n, n, n, 8)
         dev = sp.CsrMatrix(n, n, rp, ci, va).device()
-        x = torch.from_numpy(sp.synth.vector(n)).cuda()
+        x = torch.from_numpy(synth.vector(n)).cuda()
         y = torch.empty(n, dtype=torch.float64, device="cuda")
         t = timeit(lambda: dev.spmv_torch(x, out=y))
         d = dev.describe()

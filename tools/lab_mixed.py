@@ -9,10 +9,11 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 from tools.lab_zoo import timeit  # noqa: E402
 
 n = 4_000_000
-rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, 3)
+rp, ci, va = synth.banded_csr(n, n, 14, 4096, 3)
 rng = np.random.default_rng(2)
 for every, heavy in ((0, 0), (20, 3000), (20, 300), (4, 3000), (4, 300), (1, 1500)):
     if every:
@@ -30,7 +31,7 @@ for every, heavy in ((0, 0), (20, 3000), (20, 300), (4, 3000), (4, 300), (1, 150
     else:
         rp2, ci2, va2 = rp, ci, va
     dev = sp.CsrMatrix._trusted(n, n, rp2, ci2, va2).device()
-    x = torch.from_numpy(sp.synth.vector(n)).cuda()
+    x = torch.from_numpy(synth.vector(n)).cuda()
     y = torch.empty(n, dtype=torch.float64, device="cuda")
     out = []
     for pers in (0, 1):

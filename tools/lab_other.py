@@ -10,6 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 
 
 def timeit(fn, iters, warm=3):
@@ -27,14 +28,14 @@ def timeit(fn, iters, warm=3):
 
 def csr_case(name, n, window, dtype, iters=30, opts=()):
     esz = np.dtype(dtype).itemsize
-    rp, ci, va = sp.synth.banded_csr(n, n, 14, window or n, sp.synth.matrix_seed(3), dtype=dtype)
+    rp, ci, va = synth.banded_csr(n, n, 14, window or n, synth.matrix_seed(3), dtype=dtype)
     dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
     for k, v in opts:
         dev.set_option(k, v)
-    x = torch.from_numpy(sp.synth.vector(n, dtype=dtype)).cuda()
+    x = torch.from_numpy(synth.vector(n, dtype=dtype)).cuda()
     y = torch.empty_like(x)
     t = timeit(lambda: dev.spmv_torch(x, out=y), iters)
-    B = sp.synth.spmv_bytes(n * 14, n, n, n, esz)
+    B = synth.spmv_bytes(n * 14, n, n, n, esz)
     d = dev.describe()
     print(f"{name:34s} {t*1e3:9.1f} us {B/t/1e6:8.1f} GB/s {100*B/t/1e6/8000:6.2f} %peak  [{d['kernel']} "
           f"stream={d['stream_row_fraction']} lds={d['lds_x']}]", flush=True)
@@ -56,14 +57,14 @@ def main():
     if "csc" in which:
         import scipy.sparse as sps
         n = 1_000_000
-        rp, ci, va = sp.synth.banded_csr(n, n, 14, 4096, sp.synth.matrix_seed(2))
+        rp, ci, va = synth.banded_csr(n, n, 14, 4096, synth.matrix_seed(2))
         csc = sps.csr_matrix((va, ci.astype(np.int64), rp.astype(np.int64)), shape=(n, n)).tocsc()
         csc.sort_indices()
         cp, ri, cv = csc.indptr.astype(np.uint64), csc.indices.astype(np.uint64), csc.data
         dev = sp.CscMatrix._trusted(n, n, cp, ri, cv).device()
-        x = torch.from_numpy(sp.synth.vector(n)).cuda()
+        x = torch.from_numpy(synth.vector(n)).cuda()
         y = torch.empty_like(x)
-        B = sp.synth.spmv_bytes(n * 14, n, n, n, 8)
+        B = synth.spmv_bytes(n * 14, n, n, n, 8)
         dev.set_option("kernel", 1)
         for lds, flush in ((1, 1), (1, 0), (0, 0)):
             dev.set_option("lds", lds)
@@ -73,7 +74,7 @@ def main():
                   f"{100*B/t/1e6/8000:6.2f} %peak {dev.describe()}", flush=True)
     if "coo" in which:
         for length, nr in ((5_000_000, 500_000), (50_000_000, 5_000_000)):
-            r, c, v = sp.synth.coo(nr, nr, length, sp.synth.matrix_seed(5), 10, 1)
+            r, c, v = synth.coo(nr, nr, length, synth.matrix_seed(5), 10, 1)
             coo = sp.CooMatrix.with_triplets(nr, nr, r, c, v)
             t0 = time.time()
             d = coo.upload()
@@ -89,7 +90,7 @@ def main():
                 plan = csr.describe()
                 csr.close()
             t = min(ts)
-            lb = sp.synth.assembly_bytes(length, nnz, nr)
+            lb = synth.assembly_bytes(length, nnz, nr)
             print(f"cfg5 COO->CSR len={length:>9d} nnz_out={nnz:>9d}: {t*1e3:8.2f} ms  {length/t/1e6:8.1f} Mentries/s "
                   f"lower-bound bytes {lb/1e9:.2f} GB -> {lb/t/1e9:7.1f} GB/s eff ({100*lb/t/8e12:.2f} % of peak); "
                   f"upload {t_up:.2f}s; plan kernel={plan['kernel']}", flush=True)

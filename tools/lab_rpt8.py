@@ -8,6 +8,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 from tools.lab_zoo import timeit  # noqa: E402
 
 
@@ -20,11 +21,11 @@ def main():
     if "mid" in sys.argv[1:]:
         sizes = tuple((k, 3_000_000 if k <= 20 else 1_500_000 if k < 70 else 1_000_000) for k in (17, 20, 24, 33, 40, 48, 70, 81, 100))
     for per_row, n in sizes:
-        rp, ci, va = sp.synth.banded_csr(n, n, per_row, 2048, 7)
+        rp, ci, va = synth.banded_csr(n, n, per_row, 2048, 7)
         nnz = int(rp[-1])
-        B = sp.synth.spmv_bytes(nnz, n, n, n, 8)
+        B = synth.spmv_bytes(nnz, n, n, n, 8)
         dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
-        x = torch.from_numpy(sp.synth.vector(n)).cuda()
+        x = torch.from_numpy(synth.vector(n)).cuda()
         y = torch.empty(n, dtype=torch.float64, device="cuda")
         print(f"band {per_row}/row, W=2048, {n} rows: nnz {nnz}, floor {B/8e12*1e6:.1f} us", flush=True)
         long_opts = ([("kernel", 0)], [("kernel", 2), ("stream_row_max", 256), ("rows_per_tile", 4), ("persistent", 0)],

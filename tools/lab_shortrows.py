@@ -8,6 +8,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 from tools.lab_zoo import from_lens, timeit  # noqa: E402
 
 
@@ -20,9 +21,9 @@ def main():
     for name, lens, fn in cases:
         rp, ci, va = from_lens(lens, fn, rng)
         nnz = int(rp[-1])
-        B = sp.synth.spmv_bytes(nnz, n, n, n, 8)
+        B = synth.spmv_bytes(nnz, n, n, n, 8)
         dev = sp.CsrMatrix(n, n, rp, ci, va).device()
-        x = torch.from_numpy(sp.synth.vector(n)).cuda()
+        x = torch.from_numpy(synth.vector(n)).cuda()
         y = torch.empty(n, dtype=torch.float64, device="cuda")
         print(f"{name}: nnz {nnz}, floor {B/8e12*1e6:.1f} us", flush=True)
         variants = [[("kernel", 0)], [("kernel", 2), ("rows_per_tile", 64), ("persistent", 0)], [("kernel", 2), ("rows_per_tile", 128), ("persistent", 0)], [("kernel", 2), ("rows_per_tile", 256), ("persistent", 0)],

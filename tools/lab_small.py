@@ -9,6 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 
 
 def timeit(fn, iters):
@@ -24,7 +25,7 @@ def timeit(fn, iters):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
     ncols = 10_000_000
-    rp, ci, va = sp.synth.banded_csr(10_000_000, ncols, 14, 4096, sp.synth.matrix_seed(3), rows=(0, n))
+    rp, ci, va = synth.banded_csr(10_000_000, ncols, 14, 4096, synth.matrix_seed(3), rows=(0, n))
     variants = {
         "plain rpt64": [("persistent", 0)],
         "persistent rpt64": [("persistent", 1)],
@@ -43,7 +44,7 @@ def main():
             for k, v in opts:
                 d.set_option(k, v)
             devs[name].append(d)
-    xs = [torch.from_numpy(sp.synth.vector(ncols)).cuda() for _ in range(copies)]
+    xs = [torch.from_numpy(synth.vector(ncols)).cuda() for _ in range(copies)]
     ys = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(copies)]
     res = {k: [] for k in variants}
     for rnd in range(4):
@@ -56,7 +57,7 @@ def main():
                 state["i"] += 1
             timeit(fn, 30)
             res[name].append(timeit(fn, 150))
-    B = sp.synth.spmv_bytes(n * 14, n, n, 0, 8) + 0
+    B = synth.spmv_bytes(n * 14, n, n, 0, 8) + 0
     for name, v in res.items():
         print(f"{name:32s} " + " ".join(f"{t:7.2f}" for t in v) + f"   min {min(v):7.2f} us  {devs[name][0].describe()['blocks']} blocks", flush=True)
 

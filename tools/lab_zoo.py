@@ -9,6 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import spalinalg_amd as sp  # noqa: E402
+import spal_synth as synth  # noqa: E402
 
 
 def timeit(fn, iters=20, warm=3):
@@ -64,13 +65,13 @@ def main():
         rp, ci, va = make()
         ncols = nrows
         dev = sp.CsrMatrix(nrows, ncols, rp, ci, va).device()
-        x = torch.from_numpy(sp.synth.vector(ncols)).cuda()
+        x = torch.from_numpy(synth.vector(ncols)).cuda()
         y = torch.empty(nrows, dtype=torch.float64, device="cuda")
         t = timeit(lambda: dev.spmv_torch(x, out=y))
         plan = dev.autotune(x, y, iters=10)
         t2 = timeit(lambda: dev.spmv_torch(x, out=y))
         nnz = int(rp[-1])
-        B = sp.synth.spmv_bytes(nnz, nrows, nrows, ncols, 8)
+        B = synth.spmv_bytes(nnz, nrows, nrows, ncols, 8)
         d = dev.describe()
         print(f"{name:52s} nnz {nnz:>10d}  {t*1e3:8.1f} us -> autotuned {t2*1e3:8.1f} us = {100*B/(t2*1e-3)/8e12:5.1f} % of 8 TB/s  "
               f"[{d['kernel']} rpt={d['rows_per_tile']} stream={d['stream_row_fraction']:.2f} lds={d['lds_row_fraction']:.2f} "
