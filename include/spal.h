@@ -234,15 +234,26 @@ int spal_coo_to_csc_f32(int device, uint64_t nrows, uint64_t ncols, uint64_t len
                         const float *vals, spal_csc_t *out);
 
 /* ---- row-partitioned y = A * x over the GPUs of one node, from one process ---
- * (SURVEY.md section 8e).  Rows are cut into contiguous ranges with balanced
- * stored entries; every GPU holds its range and a full x.  Exchange steps:
- * ncclBroadcast of x from GPU 0, local kernels, ncclAllGather of the y slices
- * (RCCL over xGMI, loaded lazily; ngpus == 1 needs no RCCL).  The product of a
+ * (SURVEY.md sections 8e, 8f-4).  Rows are cut into contiguous ranges with
+ * balanced stored entries; every GPU holds its range and a full-length x buffer of
+ * which it reads only its WINDOW, the columns its rows store.  The product of a
  * range is the same kernel as the single-GPU path, so results are identical.
- * devices == NULL means GPUs 0 .. ngpus-1. */
+ * Exchange steps (RCCL over xGMI, loaded lazily; ngpus == 1 needs no RCCL):
+ *   x: spal_mg_csr_broadcast_x (ncclBroadcast of all of x from GPU 0) or
+ *      spal_mg_csr_scatter_x (grouped ncclSend/ncclRecv: every GPU receives its
+ *      window only);
+ *   y: spal_mg_csr_gather_y (slices back to back into GPU 0's y, unequal sizes) or
+ *      spal_mg_csr_spmv_resident (kernels + ncclAllGather: all of y on every GPU);
+ *   iterative use: spal_mg_csr_spmv_halo (per step every GPU receives only the
+ *      entries of y its rows read as columns).
+ * devices == NULL means GPUs 0 .. ngpus-1.  transport: 0 = RCCL, 1 = peer copies
+ * (hipMemcpyPeerAsync ordered by events; also accepts a device list with repeats,
+ * i.e. several shards on one GPU), -1 = RCCL unless the list has repeats. */
 int spal_mg_create(int ngpus, const int *devices, spal_mg_t *out);
+int spal_mg_create_transport(int ngpus, const int *devices, int transport, spal_mg_t *out);
 int spal_mg_destroy(spal_mg_t ctx);
 int spal_mg_device_count(spal_mg_t ctx, int *ngpus);
+int spal_mg_transport(spal_mg_t ctx, int *transport);
 int spal_mg_csr_create_f64(spal_mg_t ctx, uint64_t nrows, uint64_t ncols,
                            const uint64_t *rowptr, uint64_t rowptr_len,
                            const uint64_t *colind, uint64_t colind_len,
@@ -256,20 +267,42 @@ int spal_mg_csr_create_f32(spal_mg_t ctx, uint64_t nrows, uint64_t ncols,
 int spal_mg_csr_destroy(spal_mg_csr_t a);
 /* the row boundaries in use: ngpus + 1 entries */
 int spal_mg_csr_partition(spal_mg_csr_t a, uint64_t *bounds);
-/* host vectors: H2D x to GPU 0, broadcast, multiply, all-gather, D2H y */
+/* per GPU (ngpus entries each): its rows store columns in [need_lo, need_hi) only */
+int spal_mg_csr_windows(spal_mg_csr_t a, uint64_t *need_lo, uint64_t *need_hi);
+/* bytes one scatter_x / gather_y / halo exchange moves between GPUs (any may be NULL) */
+int spal_mg_csr_exchange_bytes(spal_mg_csr_t a, uint64_t *x_scatter, uint64_t *y_gather,
+                               uint64_t *halo);
+/* host vectors: H2D x to GPU 0, x windows scattered (broadcast when the windows
+ * cover most of x), local kernels, y gathered on GPU 0, D2H y */
 int spal_mg_csr_spmv_f64(spal_mg_csr_t a, const double *x, uint64_t x_len,
                          double *y, uint64_t y_len);
 int spal_mg_csr_spmv_f32(spal_mg_csr_t a, const float *x, uint64_t x_len,
                          float *y, uint64_t y_len);
-/* resident (timed) path: write x into GPU 0's buffer (x_root), broadcast it
- * once, then any number of spmv_resident (kernels + all-gather, asynchronous
- * on the context's streams); synchronize; GPU 0's gathered y is at y_root as
- * ngpus slices of slice_stride elements (slice g holds rows bounds[g] ..). */
+/* resident (timed) path, everything asynchronous on the context's per-GPU
+ * streams until spal_mg_csr_synchronize:
+ *   write x into GPU 0's buffer (x_root; the pointer changes with every
+ *   spmv_halo), then broadcast_x or scatter_x once;
+ *   spmv_local any number of times (kernels only), gather_y: GPU 0's y (nrows
+ *   elements, y_gathered) holds the result;
+ *   or spmv_resident (kernels + all-gather): GPU 0's copy is at y_root as
+ *   ngpus slices of slice_stride elements (slice g holds rows bounds[g] ..);
+ *   or, square matrices, spmv_halo any number of times (x <- A * x with the halo
+ *   exchange), then gather_y. */
 int spal_mg_csr_x_root(spal_mg_csr_t a, void **x_dev);
 int spal_mg_csr_broadcast_x(spal_mg_csr_t a);
+int spal_mg_csr_scatter_x(spal_mg_csr_t a);
+int spal_mg_csr_spmv_local(spal_mg_csr_t a);
+int spal_mg_csr_gather_y(spal_mg_csr_t a);
+int spal_mg_csr_y_gathered(spal_mg_csr_t a, void **y_dev);
+int spal_mg_csr_spmv_halo(spal_mg_csr_t a);
 int spal_mg_csr_spmv_resident(spal_mg_csr_t a);
 int spal_mg_csr_y_root(spal_mg_csr_t a, void **y_dev, uint64_t *slice_stride);
 int spal_mg_csr_synchronize(spal_mg_csr_t a);
+/* HIP-event durations (ms, the longest over the GPUs) of the LAST x distribution
+ * (broadcast_x / scatter_x), local kernels, halo exchange and y collection
+ * (gather_y / the all-gather): ms[0..3]; -1 for a phase that has not run.
+ * Synchronises. */
+int spal_mg_csr_timing(spal_mg_csr_t a, double *ms);
 
 /* ---- device memory helpers for callers without a HIP binding of their own
  * (the Rust shim, ctypes tests, the C++ tools). ---------------------------- */

@@ -126,10 +126,12 @@ __device__ __forceinline__ void stage_window(T *xw, const T *__restrict__ x, uin
 //   else      : page ids from pages[first ... first + npages), at most 64
 constexpr uint32_t kPageShift = 8;
 constexpr uint32_t kPageCols = 1u << kPageShift;
+// ring > 0 (contiguous runs only): the window is a ring of `ring` pages, page p at slot p % ring -- the layout the
+// sliding kernel (csr_slide.hpp) keeps across steps; col16 is encoded for it (csr_encode_col16).
 template <typename T, int BLOCK>
 __device__ __forceinline__ void stage_pages(T *xw, const T *__restrict__ x,
                                             const uint32_t *__restrict__ pages, uint32_t first,
-                                            uint32_t npages, bool contiguous, uint32_t ncols) {
+                                            uint32_t npages, bool contiguous, uint32_t ncols, uint32_t ring = 0u) {
     static_assert(BLOCK == 256, "one page of 256 columns per pass of the scalar path");
     constexpr uint32_t V = 16 / sizeof(T);      // elements per 16-byte load
     constexpr uint32_t VP = kPageCols / V;      // 16-byte vectors per page: 128 (f64) / 64 (f32)
@@ -159,10 +161,12 @@ __device__ __forceinline__ void stage_pages(T *xw, const T *__restrict__ x,
             for (uint32_t k = 0; k < K; ++k) {
                 const uint32_t i = i0 + k * BLOCK;
                 if (i < total) {
-                    d4[i] = t[k];
+                    // where the vector goes: slot i / VP, or the ring slot of its page
+                    const uint32_t at = (contiguous && ring) ? ((first + i / VP) % ring) * VP + i % VP : i;
+                    d4[at] = t[k];
                     if (e[k] > last_full) {   // at / past the end of x (last page only): columns one by one
 #pragma unroll
-                        for (uint32_t q = 0; q < V; ++q) xw[i * V + q] = e[k] + q < ncols ? x[e[k] + q] : T(0);
+                        for (uint32_t q = 0; q < V; ++q) xw[at * V + q] = e[k] + q < ncols ? x[e[k] + q] : T(0);
                     }
                 }
             }
@@ -171,7 +175,8 @@ __device__ __forceinline__ void stage_pages(T *xw, const T *__restrict__ x,
         for (uint32_t s0 = 0; s0 < npages; ++s0) {
             const uint32_t pid = __builtin_amdgcn_readlane(pid_lane, s0);
             const uint32_t e = pid * kPageCols + threadIdx.x;
-            xw[s0 * kPageCols + threadIdx.x] = e < ncols ? x[e] : T(0);
+            const uint32_t sl = (contiguous && ring) ? pid % ring : s0;
+            xw[sl * kPageCols + threadIdx.x] = e < ncols ? x[e] : T(0);
         }
     }
 }
@@ -438,6 +443,16 @@ __device__ __forceinline__ uint32_t strip_pos(uint32_t e) { return SKEW ? e + (e
 constexpr int kStreamPad = 256;  // device arrays are over-allocated by this many entries
 
 
+// Ablation builds only (-DSPAL_DIAG, tools/build_variant.sh; never in the shipped library): bits of the kernels'
+// `flags` argument switch parts of the stream kernel off so that their share of the time can be measured
+// (results are then WRONG): bit 8 lanes read the product strip at conflict-free addresses, bit 9 the x
+// window is not staged, bit 10 no row sums (a lane stores one product).
+#ifdef SPAL_DIAG
+#define SPAL_DIAG_ON(flags, bit) ((((flags) >> (bit)) & 1u) != 0u)
+#else
+#define SPAL_DIAG_ON(flags, bit) false
+#endif
+
 template <typename T> struct Pair;
 template <> struct Pair<double> { using type = __attribute__((ext_vector_type(2))) double; };
 template <> struct Pair<float> { using type = __attribute__((ext_vector_type(2))) float; };
@@ -456,6 +471,9 @@ __device__ __forceinline__ bool stream_tile_overflows(uint32_t b, uint32_t e) {
 // would keep the other 63 waiting): a bit per tile of the super-tile, packed into the descriptor --
 // desc.w = contiguous | bits 0..15 << 16, desc.z = mode | bits 16..31 << 16.
 __device__ __forceinline__ uint32_t desc_mode(const uint4 &d) { return d.z & 0xffffu; }
+// stream modes: desc.y = pages of the window (at most 64) | ulen << 8, ulen = 1 + the length every row of the
+// super-tile has, or 0 when they differ (stream_row_bounds)
+__device__ __forceinline__ uint32_t desc_ulen(const uint4 &d) { return d.y >> 8; }
 __device__ __forceinline__ uint32_t desc_skip_bits(const uint4 &d) { return (d.w >> 16) | (d.z & 0xffff0000u); }
 // the bits of one wave's TPW tiles; zero for almost every wave, which then runs the tile loop compiled
 // without the test
@@ -524,12 +542,43 @@ struct StreamTile {
     uint32_t steps;            // 128-entry steps that hold entries of the tile; wave-uniform
 };
 
+// The row bounds a lane needs for its sums.  ulen == 0: from rowptr (two loads per lane and tile; both
+// unconditional: lanes past the tile's last row read rowptr[rlast] twice, i.e. an empty row -- no select,
+// hence no wait here).  ulen > 0: the plan found every row of the super-tile to hold exactly ulen - 1 entries
+// (structured / banded matrices): the bounds follow from the tile's first entry b, and rowptr -- 4 bytes per
+// row, 2 % of config 3's traffic -- is not read at all.
+template <typename Tile, int RPT>
+__device__ __forceinline__ void stream_row_bounds(Tile &t, const uint32_t *__restrict__ rowptr, uint32_t row0,
+                                                  uint32_t rlast, uint32_t b, uint32_t lane, uint32_t ulen) {
+    if (ulen) {   // wave-uniform
+        const uint32_t len = ulen - 1u, nrt = rlast - row0;
+        if constexpr (RPT > 64) {
+            constexpr uint32_t RPL = RPT / 64;
+#pragma unroll
+            for (uint32_t i = 0; i <= RPL; ++i) t.rpl[i] = b + min(RPL * lane + i, nrt) * len;
+        } else {
+            t.rp0 = b + min(lane, nrt) * len;
+            t.rp1 = b + min(lane + 1u, nrt) * len;
+        }
+        return;
+    }
+    if constexpr (RPT > 64) {   // rows of very few entries: lane l owns RPT / 64 adjacent rows
+        constexpr uint32_t RPL = RPT / 64;
+#pragma unroll
+        for (uint32_t i = 0; i <= RPL; ++i) t.rpl[i] = rowptr[min(row0 + RPL * lane + i, rlast)];
+    } else {
+        t.rp0 = rowptr[min(row0 + lane, rlast)];
+        t.rp1 = rowptr[min(row0 + lane + 1, rlast)];
+    }
+}
+
 // b, e: the tile's entry range [rowptr[row0], rowptr[last row + 1]), wave-uniform
 template <typename T, int RPT>
 __device__ __forceinline__ void stream_load(StreamTile<T> &t, const uint32_t *__restrict__ rowptr,
                                             const uint16_t *__restrict__ col16,
                                             const T *__restrict__ vals, uint32_t row0,
-                                            uint32_t row1, uint32_t b, uint32_t e, uint32_t lane) {
+                                            uint32_t row1, uint32_t b, uint32_t e, uint32_t lane,
+                                            uint32_t ulen = 0u) {
     using pair_t = typename Pair<T>::type;
     const uint32_t rlast = min(row0 + (uint32_t)RPT, row1);
     t.start = b & ~1u;
@@ -543,23 +592,15 @@ __device__ __forceinline__ void stream_load(StreamTile<T> &t, const uint32_t *__
             t.c[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(col16 + e0 + j * 128));
         }
     }
-    // ... then this lane's row bounds (needed only by the reduction).  Both
-    // loads are unconditional: lanes past the tile's last row read
-    // rowptr[rlast] twice, i.e. an empty row -- no select, hence no wait here.
-    if constexpr (RPT > 64) {   // rows of very few entries: lane l owns RPT / 64 adjacent rows
-        constexpr uint32_t RPL = RPT / 64;
-#pragma unroll
-        for (uint32_t i = 0; i <= RPL; ++i) t.rpl[i] = rowptr[min(row0 + RPL * lane + i, rlast)];
-    } else {
-        t.rp0 = rowptr[min(row0 + lane, rlast)];
-        t.rp1 = rowptr[min(row0 + lane + 1, rlast)];
-    }
+    // ... then this lane's row bounds (needed only by the reduction)
+    stream_row_bounds<StreamTile<T>, RPT>(t, rowptr, row0, rlast, b, lane, ulen);
 }
 
 template <typename T, int RPT, bool SKEW>
 __device__ __forceinline__ void stream_compute(const StreamTile<T> &t, const T *xw, uint32_t wmax,
                                                T *prod, T *__restrict__ y, uint32_t row0,
-                                               uint32_t row1, uint32_t lane, bool nt_store = false) {
+                                               uint32_t row1, uint32_t lane, bool nt_store = false,
+                                               uint32_t flags = 0u) {
     using pair_t = typename Pair<T>::type;
 #pragma unroll
     for (int j = 0; j < kStreamSteps; ++j) {
@@ -584,6 +625,19 @@ __device__ __forceinline__ void stream_compute(const StreamTile<T> &t, const T *
     // LDS executes a wave's instructions in order, only the compiler must not
     // move the reads above the writes
     __builtin_amdgcn_wave_barrier();
+#ifdef SPAL_DIAG
+    if (SPAL_DIAG_ON(flags, 8) || SPAL_DIAG_ON(flags, 10)) {   // ablation: see SPAL_DIAG_ON
+        T acc = prod[lane];
+        if (SPAL_DIAG_ON(flags, 8)) {
+            const uint32_t len = t.rp1 - t.rp0;
+            for (uint32_t k = 1; k < len; ++k) acc = acc + prod[(k * 64u + lane) & (uint32_t)(kStreamTileNnz - 1)];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (row0 + lane < min(row0 + (uint32_t)RPT, row1)) y[row0 + lane] = acc;
+        return;
+    }
+#endif
+    (void)flags;
     strip_sums_to_y<T, RPT, SKEW>(t, prod, y, row0, row1, lane, nt_store);
 }
 
@@ -603,7 +657,8 @@ template <typename T, int RPT>
 __device__ __forceinline__ void stream_load_g(StreamTileG<T> &t, const uint32_t *__restrict__ rowptr,
                                               const uint32_t *__restrict__ colind,
                                               const T *__restrict__ vals, uint32_t row0,
-                                              uint32_t row1, uint32_t b, uint32_t e, uint32_t lane) {
+                                              uint32_t row1, uint32_t b, uint32_t e, uint32_t lane,
+                                              uint32_t ulen = 0u) {
     using pair_t = typename Pair<T>::type;
     const uint32_t rlast = min(row0 + (uint32_t)RPT, row1);
     t.start = b & ~1u;
@@ -617,14 +672,7 @@ __device__ __forceinline__ void stream_load_g(StreamTileG<T> &t, const uint32_t 
                 reinterpret_cast<const typename StreamTileG<T>::u32x2 *>(colind + e0 + j * 128));
         }
     }
-    if constexpr (RPT > 64) {   // rows of very few entries: lane l owns RPT / 64 adjacent rows
-        constexpr uint32_t RPL = RPT / 64;
-#pragma unroll
-        for (uint32_t i = 0; i <= RPL; ++i) t.rpl[i] = rowptr[min(row0 + RPL * lane + i, rlast)];
-    } else {
-        t.rp0 = rowptr[min(row0 + lane, rlast)];
-        t.rp1 = rowptr[min(row0 + lane + 1, rlast)];
-    }
+    stream_row_bounds<StreamTileG<T>, RPT>(t, rowptr, row0, rlast, b, lane, ulen);
 }
 
 template <typename T, int RPT, bool SKEW>
@@ -667,7 +715,8 @@ __device__ __forceinline__ void stream_global_super_tile(const uint32_t *__restr
                                                          const T *__restrict__ vals,
                                                          const T *__restrict__ x, T *__restrict__ y,
                                                          T *prod, uint32_t row0, uint32_t row1,
-                                                         uint32_t ncols, bool nt_store, uint32_t skip_bits) {
+                                                         uint32_t ncols, bool nt_store, uint32_t skip_bits,
+                                                         uint32_t ulen) {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = threadIdx.x / kWave;
     const uint32_t wrow = row0 + wave * (TPW * (uint32_t)RPT);
@@ -677,7 +726,7 @@ __device__ __forceinline__ void stream_global_super_tile(const uint32_t *__restr
 #pragma unroll
     for (int k = 0; k <= TPW; ++k) tb[k] = __builtin_amdgcn_readlane(tb_lane, k);
     StreamTileG<T> cur, nxt;
-    stream_load_g<T, RPT>(cur, rowptr, colind, vals, wrow, row1, tb[0], tb[1], lane);
+    stream_load_g<T, RPT>(cur, rowptr, colind, vals, wrow, row1, tb[0], tb[1], lane, ulen);
     const uint32_t ovmask = wave_skip_mask<TPW>(skip_bits, wave);
     auto tiles = [&](auto ov) {
         constexpr bool OV = decltype(ov)::value;
@@ -688,7 +737,7 @@ __device__ __forceinline__ void stream_global_super_tile(const uint32_t *__restr
             const uint32_t rn = r0 + (uint32_t)RPT;
             const bool more = (k + 1 < TPW) && rn < row1;
             if (more) stream_load_g<T, RPT>(nxt, rowptr, colind, vals, rn, row1, tb[k + 1],
-                                            tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
+                                            tb[k + 2 <= TPW ? k + 2 : k + 1], lane, ulen);
             if (!OV || !((ovmask >> k) & 1u))  // oversized tiles: csr_spmv_overflow
                 stream_compute_g<T, RPT, SKEW>(cur, x, ncols - 1, prod, y, r0, row1, lane, nt_store);
             if (more) cur = nxt;
@@ -700,12 +749,15 @@ __device__ __forceinline__ void stream_global_super_tile(const uint32_t *__restr
 
 // desc[b] = Stream: {first page id or offset into pages[], number of pages, mode, 1 if the pages are a
 // contiguous run}; VectorLds: {window base column, window length, mode, 0}
-template <typename T, int L, int U, bool USE_DPP, int TPW, int RPT, bool SKEW = false>
+// PF: tiles of loads a wave keeps in flight ahead of the one it is working on (1 or 2).  Two workgroups per CU are
+// 8 waves; with one tile (9 KB) ahead each, a CU has ~70 KB of loads in flight, about what it takes to cover the HBM
+// latency at full rate and nothing to spare while a wave sits in its row sums; two tiles ahead cost 40 more registers.
+template <typename T, int L, int U, bool USE_DPP, int TPW, int RPT, bool SKEW = false, int PF = 1>
 __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
     const uint16_t *__restrict__ col16, const T *__restrict__ vals, const T *__restrict__ x,
     T *__restrict__ y, const uint4 *__restrict__ desc, const uint32_t *__restrict__ pages, uint32_t nrows,
-    uint32_t ncols, uint32_t nnz, uint32_t nblocks, uint32_t per_xcd, uint32_t flags) {
+    uint32_t ncols, uint32_t nnz, uint32_t nblocks, uint32_t per_xcd, uint32_t flags, uint32_t ring) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
     const bool nt_store = flags & 1u;
     // [ products: 4 waves x kStreamTileNnz ][ x window ]
@@ -723,6 +775,8 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     d.w &= 1u;
 
     if (d.z == kModeStream) {
+        const uint32_t ulen = desc_ulen(d);
+        d.y &= 0xffu;
         const uint32_t lane = threadIdx.x & (kWave - 1);
         const uint32_t wave = threadIdx.x / kWave;
         T *prod = prod_all + wave * stream_strip<SKEW>();
@@ -734,13 +788,19 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
         uint32_t tb[TPW + 1];
 #pragma unroll
         for (int k = 0; k <= TPW; ++k) tb[k] = __builtin_amdgcn_readlane(tb_lane, k);
-        StreamTile<T> cur, nxt;
+        constexpr int NB = PF + 1;      // tiles a wave holds: the one it works on + PF in flight
+        StreamTile<T> t[NB];
         const bool has0 = wrow < row1;  // wave-uniform
-        if (has0) stream_load<T, RPT>(cur, rowptr, col16, vals, wrow, row1, tb[0], tb[1], lane);  // overlaps the staging
-        stage_pages<T, kStreamBlock>(xw, x, pages, d.x, d.y, d.w != 0u, ncols);   // d = {first, npages, mode, contiguous}
+        // the first PF tiles' loads overlap the staging
+#pragma unroll
+        for (int q = 0; q < PF && q < TPW; ++q)
+            if (wrow + q * (uint32_t)RPT < row1)
+                stream_load<T, RPT>(t[q % NB], rowptr, col16, vals, wrow + q * (uint32_t)RPT, row1, tb[q], tb[q + 1], lane, ulen);
+        if (!SPAL_DIAG_ON(flags, 9))
+            stage_pages<T, kStreamBlock>(xw, x, pages, d.x, d.y, d.w != 0u, ncols, ring);   // d = {first, npages, mode, contiguous}
         __syncthreads();
         if (!has0) return;
-        const uint32_t wmax = d.y * kPageCols - 1u;
+        const uint32_t wmax = ((d.w && ring) ? ring : d.y) * kPageCols - 1u;
         const uint32_t ovmask = wave_skip_mask<TPW>(skip_bits, wave);
         auto tiles = [&](auto ov) {
             constexpr bool OV = decltype(ov)::value;
@@ -748,12 +808,12 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
             for (int k = 0; k < TPW; ++k) {
                 const uint32_t r0 = wrow + k * (uint32_t)RPT;
                 if (r0 >= row1) break;  // wave-uniform
-                const uint32_t rn = r0 + (uint32_t)RPT;
-                const bool more = (k + 1 < TPW) && rn < row1;
-                if (more) stream_load<T, RPT>(nxt, rowptr, col16, vals, rn, row1, tb[k + 1], tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
+                const int kn = k + PF < TPW ? k + PF : TPW - 1;   // the tile PF ahead, if the wave has one
+                const uint32_t rn = wrow + kn * (uint32_t)RPT;
+                if (k + PF < TPW && rn < row1)
+                    stream_load<T, RPT>(t[kn % NB], rowptr, col16, vals, rn, row1, tb[kn], tb[kn + 1], lane, ulen);
                 if (!OV || !((ovmask >> k) & 1u))  // oversized tiles: csr_spmv_overflow
-                    stream_compute<T, RPT, SKEW>(cur, xw, wmax, prod, y, r0, row1, lane, nt_store);
-                if (more) cur = nxt;
+                    stream_compute<T, RPT, SKEW>(t[k % NB], xw, wmax, prod, y, r0, row1, lane, nt_store, flags);
             }
         };
         if (ovmask == 0u) tiles(std::false_type{});
@@ -763,7 +823,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     if (d.z == kModeStreamGlobal) {
         stream_global_super_tile<T, TPW, RPT, SKEW>(rowptr, colind, vals, x, y,
                                               prod_all + (threadIdx.x / kWave) * stream_strip<SKEW>(), row0,
-                                              row1, ncols, nt_store, skip_bits);
+                                              row1, ncols, nt_store, skip_bits, desc_ulen(d));
         return;
     }
     const uint32_t last_nz = nnz - 1;
@@ -793,7 +853,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
     const uint16_t *__restrict__ col16, const T *__restrict__ vals, const T *__restrict__ x,
     T *__restrict__ y, const uint4 *__restrict__ desc, const uint32_t *__restrict__ pages, uint32_t nrows,
-    uint32_t ncols, uint32_t nnz, uint32_t nblocks, uint32_t per_xcd, uint32_t chunk, uint32_t flags) {
+    uint32_t ncols, uint32_t nnz, uint32_t nblocks, uint32_t per_xcd, uint32_t chunk, uint32_t flags, uint32_t ring) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
     const bool nt_store = flags & 1u;
     T *prod_all = reinterpret_cast<T *>(spal_smem);
@@ -830,20 +890,24 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
         d.z = desc_mode(d);
         d.w &= 1u;
         // the next super-tile's boundaries: asked for now, needed at this one's last tile
-        const bool next_stream = (s + 1 < s_end) && desc_mode(desc[s + 1]) == kModeStream;
+        const uint4 d_next = desc[min(s + 1, s_end - 1)];
+        const bool next_stream = (s + 1 < s_end) && desc_mode(d_next) == kModeStream;
+        const uint32_t ulen_next = desc_ulen(d_next);
         const uint32_t tbl_next = (s + 1 < s_end) ? bounds_lane(s + 1) : 0u;
 
+        const uint32_t ulen = desc_ulen(d);   // (stream modes)
         if (d.z == kModeStream) {
+            d.y &= 0xffu;
             uint32_t tb[TPW + 1];
 #pragma unroll
             for (int k = 0; k <= TPW; ++k) tb[k] = __builtin_amdgcn_readlane(tbl, k);
             const uint32_t wrow = row0 + wave * (TPW * (uint32_t)RPT);
             const bool has0 = wrow < row1;  // wave-uniform
-            if (has0 && !cur_valid) stream_load<T, RPT>(cur, rowptr, col16, vals, wrow, row1, tb[0], tb[1], lane);
+            if (has0 && !cur_valid) stream_load<T, RPT>(cur, rowptr, col16, vals, wrow, row1, tb[0], tb[1], lane, ulen);
             __syncthreads();  // every wave is done with the previous window
-            stage_pages<T, kStreamBlock>(xw, x, pages, d.x, d.y, d.w != 0u, ncols);
+            stage_pages<T, kStreamBlock>(xw, x, pages, d.x, d.y, d.w != 0u, ncols, ring);
             __syncthreads();
-            const uint32_t wmax = d.y * kPageCols - 1u;
+            const uint32_t wmax = ((d.w && ring) ? ring : d.y) * kPageCols - 1u;
             bool fetched_next = false;
             if (has0) {
                 const uint32_t ovmask = wave_skip_mask<TPW>(skip_bits, wave);
@@ -857,7 +921,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
                         const bool more = (k + 1 < TPW) && rn < row1;
                         if (more) {
                             stream_load<T, RPT>(nxt, rowptr, col16, vals, rn, row1, tb[k + 1],
-                                           tb[k + 2 <= TPW ? k + 2 : k + 1], lane);
+                                           tb[k + 2 <= TPW ? k + 2 : k + 1], lane, ulen);
                         } else if (next_stream) {
                             // last tile of this super-tile: start on the next one's first tile
                             const uint32_t nrow0 = (s + 1) * kRows, nrow1 = min(nrow0 + kRows, nrows);
@@ -865,7 +929,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
                             if (nwrow < nrow1) {
                                 const uint32_t b0 = __builtin_amdgcn_readlane(tbl_next, 0);
                                 const uint32_t b1 = __builtin_amdgcn_readlane(tbl_next, 1);
-                                stream_load<T, RPT>(nxt, rowptr, col16, vals, nwrow, nrow1, b0, b1, lane);
+                                stream_load<T, RPT>(nxt, rowptr, col16, vals, nwrow, nrow1, b0, b1, lane, ulen_next);
                                 fetched_next = true;
                             }
                         }
@@ -881,7 +945,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
         } else if (d.z == kModeStreamGlobal) {
             cur_valid = false;   // (no window involved: no barrier needed)
             stream_global_super_tile<T, TPW, RPT, SKEW>(rowptr, colind, vals, x, y, prod, row0, row1, ncols,
-                                                  nt_store, skip_bits);
+                                                  nt_store, skip_bits, ulen);
         } else {
             cur_valid = false;
             __syncthreads();

@@ -1,6 +1,7 @@
 // spal_csr.hip -- CSR handle: create / plan / launch / download.
 // C ABI entry points documented in include/spal.h.
 #include "csr_kernels.hpp"
+#include "csr_slide.hpp"
 #include "spal_internal.hpp"
 
 namespace spal {
@@ -215,7 +216,8 @@ static constexpr uint32_t kStreamWindowBytesSkew = 44 * 1024;
 // (band of 8192 columns, f64: 463 / 392 us against 722 us)
 static constexpr uint32_t kStreamBigWindowBytes = 120 * 1024;
 
-// One workgroup per super-tile: chk[b] = {skip bits, cost, entries, rows a multiple of 128 bytes long}.
+// One workgroup per super-tile: chk[b] = {skip bits, cost, entries, rows a multiple of 128 bytes long | ulen << 16},
+// ulen = 1 + the length of every row of the super-tile when they are all equal (and below 4095), else 0.
 //  - skip: a bit per tile that the stream kernels must leave to csr_spmv_overflow -- it holds more entries
 //    than the product strip, or a row of more than row_max entries (the stream kernels sum a row per lane:
 //    such a row keeps 63 lanes waiting, 25 cycles per entry);
@@ -230,16 +232,18 @@ __global__ __launch_bounds__(256) void csr_stream_check(const uint32_t *__restri
                                                         uint32_t row_max, uint32_t quantum,
                                                         uint4 *__restrict__ chk) {
     __shared__ uint32_t s_long[32];
-    __shared__ uint32_t s_aligned;
+    __shared__ uint32_t s_aligned, s_ragged;
     const uint32_t t = threadIdx.x, b = blockIdx.x;
     const uint32_t row0 = b * R, row1 = min(row0 + R, nrows);
     if (t < 32) s_long[t] = 0u;
-    if (t == 0) s_aligned = 0u;
+    if (t == 0) { s_aligned = 0u; s_ragged = 0u; }
     __syncthreads();
+    const uint32_t len0 = rowptr[row0 + 1] - rowptr[row0];
     uint32_t aligned = 0;   // rows a non-zero multiple of `quantum` entries (128 bytes) long: see SKEW in csr_kernels.hpp
     for (uint32_t r = row0 + t; r < row1; r += 256) {
         const uint32_t len = rowptr[r + 1] - rowptr[r];
         if (len > row_max) s_long[(r - row0) / rpt] = 1u;   // (same value from every writer)
+        if (len != len0) s_ragged = 1u;
         aligned += (len != 0u && len % quantum == 0u) ? 1u : 0u;
     }
 #pragma unroll
@@ -260,7 +264,10 @@ __global__ __launch_bounds__(256) void csr_stream_check(const uint32_t *__restri
         const uint64_t m = __ballot(bad);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cost += (uint32_t)__shfl_xor((int)cost, o, 64);
-        if (t == 0) chk[b] = make_uint4((uint32_t)m, cost, rowptr[row1] - rowptr[row0], s_aligned);
+        if (t == 0) {
+            const uint32_t ulen = (s_ragged == 0u && len0 < 4095u) ? len0 + 1u : 0u;
+            chk[b] = make_uint4((uint32_t)m, cost, rowptr[row1] - rowptr[row0], s_aligned | (ulen << 16));
+        }
     }
 }
 
@@ -411,13 +418,21 @@ __global__ __launch_bounds__(256) void csr_encode_col16(const uint32_t *__restri
                                                         const uint4 *__restrict__ desc,
                                                         const uint32_t *__restrict__ pages,
                                                         uint16_t *__restrict__ col16,
-                                                        uint32_t nrows, uint32_t R) {
+                                                        uint32_t nrows, uint32_t R, uint32_t ring) {
     __shared__ uint32_t s_pg[64];
-    const uint4 d = desc[blockIdx.x];   // Stream: {first page / offset, npages, mode, contiguous}
+    uint4 d = desc[blockIdx.x];   // Stream: {first page / offset, npages | ulen << 8, mode, contiguous}
     if (desc_mode(d) != kModeStream) return;
+    d.y &= 0xffu;
     const uint32_t row0 = blockIdx.x * R, row1 = min(row0 + R, nrows);
     const uint32_t p0 = rowptr[row0], p1 = rowptr[row1];
     if (d.w & 1u) {   // contiguous run of pages starting at page d.x
+        if (ring) {   // the window is a ring: slot = page % ring (csr_slide.hpp)
+            for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256) {
+                const uint32_t c = colind[p];
+                col16[p] = (uint16_t)((((c >> kPageShift) % ring) << kPageShift) | (c & (kPageCols - 1u)));
+            }
+            return;
+        }
         const uint32_t base = d.x << kPageShift;
         for (uint32_t p = p0 + threadIdx.x; p < p1; p += 256) col16[p] = (uint16_t)(colind[p] - base);
         return;
@@ -433,6 +448,123 @@ __global__ __launch_bounds__(256) void csr_encode_col16(const uint32_t *__restri
         }
         col16[p] = (uint16_t)(lo * kPageCols + (c & (kPageCols - 1u)));
     }
+}
+
+// ---- plan of the sliding-window kernel (csr_slide.hpp) -----------------------------------------------------
+// One workgroup per STEP of SR = 4 * rpt rows (SR <= 256: a row per thread): out[i] = {first column, one past the
+// last column (0: the step stores nothing), 1 + the length of every row if they are all equal else 0, the most
+// 128-entry steps one of its four tiles needs}.
+__global__ __launch_bounds__(256) void csr_slide_scan(const uint32_t *__restrict__ rowptr,
+                                                      const uint32_t *__restrict__ colind, uint32_t nrows,
+                                                      uint32_t rpt, uint4 *__restrict__ out) {
+    __shared__ uint32_t s_min, s_max, s_ragged, s_steps;
+    const uint32_t t = threadIdx.x, SR = 4u * rpt;
+    if (t == 0) { s_min = 0xffffffffu; s_max = 0u; s_ragged = 0u; s_steps = 0u; }
+    __syncthreads();
+    const uint32_t row0 = blockIdx.x * SR, row1 = min(row0 + SR, nrows);
+    const uint32_t len0 = rowptr[row0 + 1] - rowptr[row0];
+    if (row0 + t < row1 && t < SR) {
+        const uint32_t a0 = rowptr[row0 + t], a1 = rowptr[row0 + t + 1];
+        if (a0 < a1) {
+            atomicMin(&s_min, colind[a0]);
+            atomicMax(&s_max, colind[a1 - 1] + 1u);
+        }
+        if (a1 - a0 != len0) s_ragged = 1u;
+    }
+    if (t < 4u && row0 + t * rpt < row1) {
+        const uint32_t b = rowptr[row0 + t * rpt], e = rowptr[min(row0 + (t + 1u) * rpt, row1)];
+        atomicMax(&s_steps, (e - (b & ~1u) + 127u) >> 7);
+    }
+    __syncthreads();
+    if (t == 0) out[blockIdx.x] = make_uint4(s_min, s_max, (s_ragged == 0u && len0 < 4095u) ? len0 + 1u : 0u, s_steps);
+}
+
+// Decides whether the sliding kernel can run this stream plan and, if so, builds its step descriptors.
+// desc / skip: the chosen stream plan's super-tiles (R rows each, 16 tiles of rpt rows); super_pages: the most
+// pages one of them stages (the one-super-tile-per-workgroup kernels read the same ring).
+static int slide_plan(spal_csr *a, uint32_t R, uint32_t rpt, const std::vector<uint4> &desc,
+                      const std::vector<uint32_t> &skip, uint32_t super_pages) {
+    CsrPlan &p = a->plan;
+    p.slide = 0;
+    p.ring_pages = 0;
+    if (a->d_sdesc) { SPAL_HIP_TRY(dev_free(a->d_sdesc)); a->d_sdesc = nullptr; }
+    const uint32_t V = 16u / (uint32_t)a->elem_size;
+    if (p.slide_user == 0 || p.tiles_per_wave != 4 || rpt > 64u || p.skew || a->ncols < kPageCols || a->nnz == 0) return SPAL_OK;
+    for (const uint4 &d : desc)
+        if (d.z != kModeStream || !(d.w & 1u)) return SPAL_OK;   // a page list, x through L2, vector rows: not a band
+    const uint32_t SR = 4u * rpt;
+    const uint32_t nsteps = (uint32_t)((a->nrows + SR - 1) / SR);
+    uint4 *d_scan = nullptr;
+    SPAL_HIP_TRY(dev_alloc((void **)&d_scan, (size_t)nsteps * sizeof(uint4)));
+    hipLaunchKernelGGL(csr_slide_scan, dim3(nsteps), dim3(256), 0, a->stream, a->d_rowptr, a->d_colind,
+                       (uint32_t)a->nrows, rpt, d_scan);
+    std::vector<uint4> scan(nsteps);
+    hipError_t e = hipMemcpyAsync(scan.data(), d_scan, (size_t)nsteps * sizeof(uint4), hipMemcpyDeviceToHost, a->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
+    (void)dev_free(d_scan);
+    SPAL_HIP_TRY(e);
+    // windows: a step that stores nothing keeps its predecessor's window (nothing enters)
+    std::vector<uint2> sd(nsteps);
+    uint32_t S = 1, ulen = scan[0].z;
+    bool uni = true;
+    uint32_t pf = 0, pn = 1;
+    for (uint32_t i = 0; i < nsteps; ++i) {
+        if (scan[i].y) {
+            pf = scan[i].x >> kPageShift;
+            pn = ((scan[i].y - 1u) >> kPageShift) - pf + 1u;
+        }
+        sd[i] = make_uint2(pf, pn);
+        uni = uni && scan[i].z != 0u && scan[i].z == ulen;
+        // tiles the stream kernels skip (csr_spmv_overflow) do not bound S
+        const uint32_t tile0 = i * 4u;
+        uint32_t sk = 0;
+        for (uint32_t w = 0; w < 4u; ++w) {
+            const uint32_t tl = tile0 + w, b = tl / 16u;
+            if (b < skip.size() && ((skip[b] >> (tl % 16u)) & 1u)) sk |= 1u << w;
+        }
+        sd[i].y |= sk << 8;
+        if (sk != 0xfu) S = std::max(S, scan[i].w);
+    }
+    if (S > (uint32_t)kStreamSteps) {
+        // an unskipped tile of more than 1024 entries cannot be: stream_tile_overflows marks those.  (A step whose
+        // tiles are partly skipped reports the largest of all four: clamp, the skipped ones are not computed.)
+        S = (uint32_t)kStreamSteps;
+    }
+    // ring size: what the largest super-tile stages, and room for the pages that enter with the next step
+    const uint32_t page_bytes = kPageCols * (uint32_t)a->elem_size;
+    const uint32_t strips = (uint32_t)kStreamWaves * (uint32_t)stream_strip<false>() * (uint32_t)a->elem_size;
+    const uint32_t cap2 = (80u * 1024u - strips) / page_bytes;            // two workgroups per CU
+    const uint32_t cap1 = std::min<uint32_t>(255u, (160u * 1024u - strips) / page_bytes);   // one
+    uint32_t want = super_pages;
+    for (uint32_t i = 0; i + 1 < nsteps; ++i) {
+        const uint32_t lo = std::min(sd[i].x, sd[i + 1].x);
+        const uint32_t hi = std::max(sd[i].x + (sd[i].y & 0xffu), sd[i + 1].x + (sd[i + 1].y & 0xffu));
+        want = std::max(want, hi - lo);
+    }
+    const uint32_t NP = want <= cap2 ? want : std::min(want, std::max(cap1, super_pages));
+    if (NP < super_pages || NP > 255u) return SPAL_OK;   // (cannot be: super_pages fits the budget it was planned for)
+    // which steps' entering pages are prefetched
+    const uint32_t safe_cols = (uint32_t)(a->ncols / V) * V;   // below this column, x is made of whole 16-byte vectors
+    const uint32_t VP = kPageCols / V;
+    for (uint32_t i = 1; i < nsteps; ++i) {
+        const uint32_t f0 = sd[i - 1].x, e0 = f0 + (sd[i - 1].y & 0xffu), f1 = sd[i].x, e1 = f1 + (sd[i].y & 0xffu);
+        const uint32_t lo = std::min(f0, f1), hi = std::max(e0, e1);
+        uint32_t entering = 0;
+        if (f0 >= e1 || e0 <= f1) entering = e1 - f1;
+        else entering = (f1 < f0 ? f0 - f1 : 0u) + (e1 > e0 ? e1 - e0 : 0u);
+        const bool whole = (uint64_t)e1 * kPageCols <= safe_cols;
+        if (hi - lo <= NP && entering * VP <= kSlideAsyncVecs * (uint32_t)kStreamBlock && whole) sd[i].y |= kSlideAsync;
+    }
+    SPAL_HIP_TRY(dev_alloc((void **)&a->d_sdesc, (size_t)nsteps * sizeof(uint2)));
+    SPAL_HIP_TRY(hipMemcpyAsync(a->d_sdesc, sd.data(), (size_t)nsteps * sizeof(uint2), hipMemcpyHostToDevice, a->stream));
+    SPAL_HIP_TRY(hipStreamSynchronize(a->stream));   // `sd` goes out of scope
+    p.slide = 1;
+    p.ring_pages = (int)NP;
+    p.slide_steps = nsteps;
+    p.slide_S = (int)S;
+    p.slide_uniform = (uni && ulen != 0u) ? (int)ulen : 0;
+    (void)R;
+    return SPAL_OK;
 }
 
 static int pick_lanes(double mean_row) {
@@ -516,7 +648,7 @@ static hipError_t launch_vec_unroll(const spal_csr *a, const void *x, void *y, h
 }
 
 // stream kernel; its vector fallback for non-streamable super-tiles uses U = 2
-template <typename T, int TPW, int RPT, bool SKEW = false>
+template <typename T, int TPW, int RPT, bool SKEW = false, int PF = 1>
 static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     // the in-kernel vector fallback takes super-tiles with a tile of more than 1024 entries, i.e. with heavy
     // rows: a wave per row, four (colind, value) pairs per lane in flight (any geometry is correct)
@@ -524,14 +656,14 @@ static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, h
     const CsrPlan &p = a->plan;
     const uint32_t per_xcd = (p.nblocks + 7) / 8;
     const size_t lds = ((size_t)kStreamWaves * stream_strip<SKEW>() + p.lds_entries) * sizeof(T);
-    auto kern = csr_spmv_stream<T, L, 1, true, TPW, RPT, SKEW>;
+    auto kern = csr_spmv_stream<T, L, 1, true, TPW, RPT, SKEW, PF>;
     static std::atomic<uint64_t> configured{0};
     hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
                        a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc, a->d_pages,
                        (uint32_t)a->nrows, (uint32_t)a->ncols, (uint32_t)a->nnz, p.nblocks, per_xcd,
-                       (uint32_t)(p.nt_store ? 1 : 0));
+                       (uint32_t)(p.nt_store ? 1 : 0) | (uint32_t)p.diag, (uint32_t)p.ring_pages);
     return hipGetLastError();
 }
 
@@ -559,7 +691,7 @@ static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, voi
     hipLaunchKernelGGL(kern, dim3(used * 8), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
                        a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc, a->d_pages,
                        (uint32_t)a->nrows, (uint32_t)a->ncols, (uint32_t)a->nnz, p.nblocks, per_xcd, chunk,
-                       (uint32_t)(p.nt_store ? 1 : 0));
+                       (uint32_t)(p.nt_store ? 1 : 0), (uint32_t)p.ring_pages);
     return hipGetLastError();
 }
 
@@ -585,7 +717,15 @@ static hipError_t launch_stream(const spal_csr *a, const void *x, void *y, hipSt
 template <typename T>
 static hipError_t launch_stream_main(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     const CsrPlan &p = a->plan;
+    // the sliding-window kernel (its page loads are 16-byte vectors of x)
+    if (p.slide && p.slide_on && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) return launch_slide(a, x, y, st);
     if (p.tiles_per_wave == 8) return launch_stream_tpw<T, 8, 64>(a, x, y, st);  // (64-row tiles only)
+    // two tiles of loads ahead: instantiated for the plain form of the 64- / 32- / 16-row tiles without skew
+    if (p.prefetch == 2 && !p.persistent && !p.skew) {
+        if (p.rows_per_tile == 64) return launch_stream_tpw<T, 4, 64, false, 2>(a, x, y, st);
+        if (p.rows_per_tile == 32) return launch_stream_tpw<T, 4, 32, false, 2>(a, x, y, st);
+        if (p.rows_per_tile == 16) return launch_stream_tpw<T, 4, 16, false, 2>(a, x, y, st);
+    }
 #define SPAL_STREAM_CASE(RPT, SKEW) \
     case RPT: return p.persistent ? launch_stream_persistent<T, (RPT > 128 ? 1 : RPT > 64 ? 2 : 4), RPT, SKEW>(a, x, y, st) \
                                   : launch_stream_tpw<T, (RPT > 128 ? 1 : RPT > 64 ? 2 : 4), RPT, SKEW>(a, x, y, st);
@@ -725,7 +865,7 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
     SPAL_HIP_TRY(e);
     if (decide_skew) {   // skewed product strips when most rows are a multiple of 128 bytes long (16 f64 / 32 f32 entries)
         uint64_t aligned = 0;
-        for (uint32_t b = 0; b < nb; ++b) aligned += chk[b].w;
+        for (uint32_t b = 0; b < nb; ++b) aligned += chk[b].w & 0xffffu;
         a->plan.skew = 2 * aligned > a->nrows ? 1 : 0;
         small_cap = small_pages();   // (the page kernel above ran with the budget of the previous setting: at worst
                                      //  a super-tile of 23 or 24 pages gathers x through L2)
@@ -784,6 +924,10 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
             cap = std::max(cap, len);
         }
     }
+    // super-tiles whose rows all have the same length: the kernels derive the row bounds and do not read rowptr
+    if (a->plan.uniform_rows)
+        for (uint32_t b = 0; b < nb; ++b)
+            if (desc[b].z == kModeStream || desc[b].z == kModeStreamGlobal) desc[b].y |= (chk[b].w >> 16) << 8;
     // what the caller ranks tile heights by: the share of rows whose TILE streams (the marked tiles of a
     // super-tile in a stream mode are left to csr_spmv_overflow)
     {
@@ -829,6 +973,8 @@ int csr_plan_build(spal_csr *a) {
     }
     p.stream_row_fraction = 0.0;
     p.vec_col16 = 0;
+    p.slide = 0;
+    p.ring_pages = 0;
     if (a->nnz == 0) {
         p.kernel = 1;
         p.rows_per_block = 1024;
@@ -897,6 +1043,11 @@ int csr_plan_build(spal_csr *a) {
                 if (best_desc[b].z == kModeVectorLds || best_desc[b].z == kModeStream)
                     lds_rows += std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
             p.lds_row_fraction = (double)lds_rows / (double)a->nrows;
+            uint64_t uni_rows = 0;
+            for (uint32_t b = 0; b < p.nblocks; ++b)
+                if ((best_desc[b].z == kModeStream || best_desc[b].z == kModeStreamGlobal) && (best_desc[b].y >> 8))
+                    uni_rows += std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
+            p.uniform_row_fraction = (double)uni_rows / (double)a->nrows;
             SPAL_HIP_TRY(dev_alloc((void **)&a->d_desc, (size_t)p.nblocks * sizeof(uint4)));
             std::vector<uint4> packed(best_desc);   // + the tiles to skip (see desc_skip_bits)
             for (uint32_t b = 0; b < p.nblocks; ++b) {
@@ -906,6 +1057,9 @@ int csr_plan_build(spal_csr *a) {
             SPAL_HIP_TRY(hipMemcpyAsync(a->d_desc, packed.data(), (size_t)p.nblocks * sizeof(uint4),
                                         hipMemcpyHostToDevice, a->stream));
             SPAL_HIP_TRY(hipStreamSynchronize(a->stream));   // `packed` goes out of scope
+            // bands and the like: the sliding-window kernel (csr_slide.hpp) and its ring-addressed window
+            SPAL_TRY(slide_plan(a, R, (uint32_t)best_rpt, best_desc, best_skip, best_cap / kPageCols));
+            if (p.ring_pages) p.lds_entries = (uint32_t)p.ring_pages * kPageCols;
             // 16-bit columns only where some super-tile reads them (a matrix whose columns are scattered
             // everywhere streams with the 32-bit ones: no 2 B/entry array to allocate and clear)
             bool any_stream = false;
@@ -916,7 +1070,8 @@ int csr_plan_build(spal_csr *a) {
                     SPAL_HIP_TRY(hipMemsetAsync(a->d_col16, 0, (size_t)a->cap_entries * sizeof(uint16_t), a->stream));
                 }
                 hipLaunchKernelGGL(csr_encode_col16, dim3(p.nblocks), dim3(256), 0, a->stream, a->d_rowptr,
-                                   a->d_colind, a->d_desc, a->d_pages, a->d_col16, (uint32_t)a->nrows, R);
+                                   a->d_colind, a->d_desc, a->d_pages, a->d_col16, (uint32_t)a->nrows, R,
+                                   (uint32_t)p.ring_pages);
                 SPAL_HIP_TRY(hipGetLastError());
             }
             if (best_over) {   // the tiles the stream kernels skip: listed for csr_spmv_overflow
@@ -1049,6 +1204,7 @@ static void csr_free(spal_csr *a) {
     (void)dev_free(a->d_col16);
     (void)dev_free(a->d_pages);
     (void)dev_free(a->d_ovtiles);
+    (void)dev_free(a->d_sdesc);
     (void)dev_free(a->d_x);
     (void)dev_free(a->d_y);
     stream_release(a->stream);
@@ -1407,10 +1563,40 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         if (value == 0) p.user_rows_per_tile = false;
         else if (value != 256 && value != 128 && value != 64 && value != 32 && value != 24 && value != 16 && value != 12 && value != 8)
             return fail(SPAL_ERR_INVALID_ARGUMENT, "rows_per_tile must be 0 (auto), 256, 128, 64, 32, 24, 16, 12 or 8");
+        else if (p.tiles_per_wave == 8 && value != 64)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "rows_per_tile must be 64 (or 0 = auto) while tiles_per_wave = 8");
         else { p.rows_per_tile = (int)value; p.user_rows_per_tile = true; }
     } else if (!strcmp(key, "tiles_per_wave")) {
         if (value != 4 && value != 8) return fail(SPAL_ERR_INVALID_ARGUMENT, "tiles_per_wave must be 4 or 8");
+        // the 8-tile form exists for 64-row tiles only (launch_stream_main): a plan built for another tile height
+        // and launched with it would read descriptors of other rows
+        if (value == 8 && p.user_rows_per_tile && p.rows_per_tile != 64)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "tiles_per_wave = 8 needs rows_per_tile = 64 (or 0 = auto)");
         p.tiles_per_wave = (int)value;
+    } else if (!strcmp(key, "slide")) {
+        // the sliding-window kernel for band-like plans: -1 = use it where the plan allows (default), 0 = never
+        // (the plan then keeps the window-relative col16 of the one-super-tile-per-workgroup kernels), 1 = as -1;
+        // "slide_on" 0 keeps the ring plan but launches the one-super-tile-per-workgroup kernels on it (A/B)
+        if (value < -1 || value > 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "slide must be -1 (auto), 0 or 1");
+        p.slide_user = (int)value;
+    } else if (!strcmp(key, "slide_on")) {
+        if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "slide_on must be 0 or 1");
+        p.slide_on = (int)value;
+    } else if (!strcmp(key, "uniform_rows")) {
+        // stream kernel: super-tiles whose rows all have one length do not read rowptr (default 1)
+        if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "uniform_rows must be 0 or 1");
+        p.uniform_rows = (int)value;
+    } else if (!strcmp(key, "prefetch")) {
+        // stream kernel: tiles of loads ahead of the one being summed
+        if (value != 1 && value != 2) return fail(SPAL_ERR_INVALID_ARGUMENT, "prefetch must be 1 or 2");
+        p.prefetch = (int)value;
+    } else if (!strcmp(key, "diag")) {
+#ifdef SPAL_DIAG
+        if (value < 0 || value > 0xffff || (value & 0xff)) return fail(SPAL_ERR_INVALID_ARGUMENT, "diag: bits 8 ... 15 only");
+        p.diag = (int)value;
+#else
+        return fail(SPAL_ERR_INVALID_ARGUMENT, "diag: this library is not an ablation build (-DSPAL_DIAG)");
+#endif
     } else if (!strcmp(key, "threads")) {
         if (value == 0) p.user_threads = false;
         else if (value != 512 && value != 1024)
@@ -1439,7 +1625,8 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "\"index_bits\": %d, \"kernel\": \"%s\", \"lanes_per_row\": %d, \"unroll\": %d, "
              "\"rows_per_block\": %d, \"rows_per_tile\": %d, \"blocks\": %u, \"threads_per_block\": %d, \"lds_x\": %d, "
              "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f, "
-             "\"overflow_tiles\": %u, \"skew\": %d, \"persistent\": %d, \"nt_store\": %d, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f]}",
+             "\"overflow_tiles\": %u, \"skew\": %d, \"persistent\": %d, \"nt_store\": %d, \"uniform_row_fraction\": %.4f, "
+             "\"prefetch\": %d, \"slide\": %d, \"ring_pages\": %d, \"tile_steps\": %d, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f], \"addr\": [\"%llx\", \"%llx\", \"%llx\"]}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, (p.kernel == 2 || p.vec_col16) ? 16 : 32,
              p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
@@ -1447,8 +1634,12 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              (unsigned long long)p.lds_entries * (unsigned long long)a->elem_size, p.lds_row_fraction,
              p.stream_row_fraction, p.kernel == 2 ? a->n_ovtiles : 0u, (p.kernel == 2 && p.skew) ? 1 : 0,
              (p.kernel == 2 && p.persistent && p.tiles_per_wave == 4) ? 1 : 0,
-             (p.kernel == 2 && p.nt_store) ? 1 : 0, (double)a->tuned_us[0], (double)a->tuned_us[1],
-             (double)a->tuned_us[2], (double)a->tuned_us[3]);
+             (p.kernel == 2 && p.nt_store) ? 1 : 0, p.kernel == 2 ? p.uniform_row_fraction : 0.0,
+             p.kernel == 2 ? p.prefetch : 0, (p.kernel == 2 && p.slide && p.slide_on) ? 1 : 0,
+             p.kernel == 2 ? p.ring_pages : 0, (p.kernel == 2 && p.slide) ? p.slide_S : 0,
+             (double)a->tuned_us[0], (double)a->tuned_us[1],
+             (double)a->tuned_us[2], (double)a->tuned_us[3], (unsigned long long)(uintptr_t)a->d_values,
+             (unsigned long long)(uintptr_t)a->d_col16, (unsigned long long)(uintptr_t)a->d_rowptr);
     return SPAL_OK;
 }
 

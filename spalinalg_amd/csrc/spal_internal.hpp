@@ -103,6 +103,17 @@ struct CsrPlan {
     int stream_row_max = 128; // stream kernel: tiles with a longer row go to the overflow kernel (a lane sums a row)
     int window_pages = 0;    // stream kernel: page budget of a super-tile's LDS x window (0 = automatic)
     int stream_global = 1;   // stream kernel: super-tiles whose pages exceed the LDS budget gather x from global
+    int uniform_rows = 1;    // stream kernel: super-tiles whose rows all have one length do not read rowptr
+    int prefetch = 1;        // stream kernel: tiles of loads a wave keeps in flight ahead of the one it works on (1 or 2)
+    // the sliding-window kernel (csr_slide.hpp): band-like stream plans
+    int slide_user = -1;     // -1 auto, 0 never
+    int slide_on = 1;        // launch it (0: the one-super-tile-per-workgroup kernels on the same ring plan)
+    int slide = 0;           // the plan is eligible and built for it
+    int ring_pages = 0;      // the LDS x window is a ring of this many pages (col16 = (page % ring) * 256 + column in page)
+    uint32_t slide_steps = 0;  // steps of 4 * rows_per_tile rows
+    int slide_S = 0;         // 128-entry steps of the largest streamed tile: every tile issues that many loads
+    int slide_uniform = 0;   // 1 + the length of every row when all streamed rows have one length (rowptr is not read), else 0
+    int diag = 0;            // ablation builds (-DSPAL_DIAG) only: parts of the stream kernel switched off
     int persistent_blocks = 0;    // its grid; 0 = what the device holds at once (LDS per workgroup decides: f64 band 512)
     int rows_per_block = 0;  // R
     int lds_x = 0;           // stage the block's x window in LDS
@@ -110,6 +121,7 @@ struct CsrPlan {
     uint32_t nblocks = 0;
     double lds_row_fraction = 0.0;  // rows whose block window fits
     double stream_row_fraction = 0.0;  // rows handled by the stream path (kernel 2)
+    double uniform_row_fraction = 0.0; // rows in super-tiles that do not read rowptr (all rows one length)
     bool user_rows_per_block = false, user_lanes = false, user_lds = false,
          user_unroll = false, user_threads = false, user_rows_per_tile = false;
 };
@@ -138,6 +150,7 @@ struct spal_csr {
     uint32_t *d_ovtiles = nullptr; // [count][first rows of the n_ovtiles tiles the stream kernels skip (csr_spmv_overflow)]
     uint32_t n_ovtiles = 0;
     uint32_t *d_pages = nullptr;   // blocks * page budget: ascending page ids of super-tiles whose pages are not one run
+    uint2 *d_sdesc = nullptr;      // sliding kernel: per step {first page, pages | skip << 8 | flags << 16}
     uint4 *d_desc = nullptr;       // per row block: Stream {first page / offset into d_pages, pages, mode, contiguous};
                                    // VectorLds {window base column, window length, mode, 0}
     uint64_t cap_entries = 0;      // allocated entries of d_colind / d_values (>= nnz + pad)
@@ -196,6 +209,8 @@ namespace spal {
 // implemented in spal_csr.hip
 int csr_plan_build(spal_csr *a);
 int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream);
+// implemented in spal_csr_slide.hip: the sliding-window kernel for a plan with plan.slide set
+hipError_t launch_slide(const spal_csr *a, const void *x, void *y, hipStream_t st);
 // builds a handle around device arrays it takes ownership of (used by the COO
 // assembly, which produces CSR directly on the device)
 // (cap_entries = allocated entries of d_colind / d_values; re-allocated with

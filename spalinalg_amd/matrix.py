@@ -216,14 +216,23 @@ class DeviceCoo:
 
 class MultiGpuCsr:
     """A CsrMatrix partitioned by rows over `ngpus` GPUs of this node, driven
-    from this one process (C ABI spal_mg_*: RCCL broadcast of x, local kernels,
-    all-gather of y)."""
+    from this one process (C ABI spal_mg_*): every GPU reads
+    only its window of x (scatter_x; broadcast_x sends all of it), local
+    kernels, y slices gathered on GPU 0 (gather_y) or all-gathered
+    (spmv_resident), per-step halo exchange for iterative use (spmv_halo).
 
-    def __init__(self, csr: "CsrMatrix", ngpus: int, devices=None):
+    transport: "rccl" (grouped ncclSend/ncclRecv over xGMI), "copy" (peer
+    copies ordered by events; also takes a device list with repeats, i.e.
+    several shards on one GPU) or None = rccl unless `devices` repeats."""
+
+    PHASES = ("x_distribution", "compute", "halo", "y_collection")
+
+    def __init__(self, csr: "CsrMatrix", ngpus: int, devices=None, transport=None):
         self.dtype = csr.dtype
         self._ctx, self._h = vp(), vp()
         dev = (C.c_int * ngpus)(*devices) if devices is not None else None
-        check(_ffi.lib().spal_mg_create(C.c_int(ngpus), dev, C.byref(self._ctx)))
+        tr = {None: -1, "rccl": 0, "copy": 1}[transport]
+        check(_ffi.lib().spal_mg_create_transport(C.c_int(ngpus), dev, C.c_int(tr), C.byref(self._ctx)))
         try:
             check(getattr(_ffi.lib(), f"spal_mg_csr_create_{_sfx(self.dtype)}")(
                 self._ctx, u64(csr.nrows()), u64(csr.ncols()), _p(csr.rowptr()), u64(csr.rowptr().size),
@@ -234,17 +243,80 @@ class MultiGpuCsr:
             self._ctx = None
             raise
         self.nrows, self.ncols, self.ngpus = csr.nrows(), csr.ncols(), ngpus
+        t = C.c_int(0)
+        check(_ffi.lib().spal_mg_transport(self._ctx, C.byref(t)))
+        self.transport = "rccl" if t.value == 0 else "copy"
+        self.root_device = devices[0] if devices is not None else 0
 
     def partition(self) -> np.ndarray:
         b = np.empty(self.ngpus + 1, dtype=np.uint64)
         check(_ffi.lib().spal_mg_csr_partition(self._h, _p(b)))
         return b
 
+    def windows(self):
+        """per GPU: its rows store columns in [need_lo[g], need_hi[g]) only"""
+        lo, hi = np.empty(self.ngpus, dtype=np.uint64), np.empty(self.ngpus, dtype=np.uint64)
+        check(_ffi.lib().spal_mg_csr_windows(self._h, _p(lo), _p(hi)))
+        return lo, hi
+
+    def exchange_bytes(self) -> dict:
+        x, y, h = u64(), u64(), u64()
+        check(_ffi.lib().spal_mg_csr_exchange_bytes(self._h, C.byref(x), C.byref(y), C.byref(h)))
+        return {"x_scatter": x.value, "y_gather": y.value, "halo": h.value}
+
     def spmv(self, x) -> np.ndarray:
         x = np.ascontiguousarray(x, dtype=self.dtype)
         y = np.empty(self.nrows, dtype=self.dtype)
         check(getattr(_ffi.lib(), f"spal_mg_csr_spmv_{_sfx(self.dtype)}")(self._h, _p(x), u64(x.size), _p(y), u64(y.size)))
         return y
+
+    # ---- resident path (asynchronous on the context's streams until synchronize) ----
+    def _call(self, name):
+        check(getattr(_ffi.lib(), f"spal_mg_csr_{name}")(self._h))
+
+    def set_x(self, x) -> None:
+        """host vector -> GPU 0's x buffer (synchronous copy)"""
+        x = np.ascontiguousarray(x, dtype=self.dtype)
+        if x.size != self.ncols:
+            raise Panic(_ffi.SPAL_ERR_INVALID_ARGUMENT, f"assertion failed: ncols == x.len() (left: {self.ncols}, right: {x.size})")
+        ptr = vp()
+        self.synchronize()
+        check(_ffi.lib().spal_mg_csr_x_root(self._h, C.byref(ptr)))
+        check(_ffi.lib().spal_memcpy_h2d(C.c_int(self.root_device), ptr, _p(x), C.c_size_t(x.nbytes)))
+
+    def broadcast_x(self): self._call("broadcast_x")
+    def scatter_x(self): self._call("scatter_x")
+    def spmv_local(self): self._call("spmv_local")
+    def gather_y(self): self._call("gather_y")
+    def spmv_halo(self): self._call("spmv_halo")
+    def spmv_resident(self): self._call("spmv_resident")
+    def synchronize(self): self._call("synchronize")
+
+    def y_gathered(self) -> np.ndarray:
+        """GPU 0's y after gather_y (synchronises)"""
+        self.synchronize()
+        ptr = vp()
+        check(_ffi.lib().spal_mg_csr_y_gathered(self._h, C.byref(ptr)))
+        y = np.empty(self.nrows, dtype=self.dtype)
+        check(_ffi.lib().spal_memcpy_d2h(C.c_int(self.root_device), _p(y), ptr, C.c_size_t(y.nbytes)))
+        return y
+
+    def y_allgathered(self) -> np.ndarray:
+        """GPU 0's copy of the all-gathered y after spmv_resident (synchronises)"""
+        self.synchronize()
+        ptr, stride = vp(), u64()
+        check(_ffi.lib().spal_mg_csr_y_root(self._h, C.byref(ptr), C.byref(stride)))
+        pad = np.empty(self.ngpus * stride.value, dtype=self.dtype)
+        check(_ffi.lib().spal_memcpy_d2h(C.c_int(self.root_device), _p(pad), ptr, C.c_size_t(pad.nbytes)))
+        b = self.partition().astype(np.int64)
+        return np.concatenate([pad[g * stride.value: g * stride.value + (b[g + 1] - b[g])] for g in range(self.ngpus)])
+
+    def timing(self) -> dict:
+        """HIP-event durations (ms, longest over the GPUs) of the last x distribution, local kernels,
+        halo exchange and y collection; None for a phase that has not run.  Synchronises."""
+        ms = (C.c_double * 4)()
+        check(_ffi.lib().spal_mg_csr_timing(self._h, ms))
+        return {k: (None if ms[i] < 0 else ms[i]) for i, k in enumerate(self.PHASES)}
 
     def close(self):
         if getattr(self, "_h", None):

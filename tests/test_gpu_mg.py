@@ -1,0 +1,158 @@
+"""The row-partitioned product from ONE process through the C ABI (spal_mg_*):
+x windows scattered from GPU 0, local kernels, y gathered on GPU 0, all-gather, per-step halo
+exchange -- against the CPU oracle, bit for bit on the stream path.
+
+Two ways to reach N > 1 shards:
+ * `virtual`: the copy transport with a device list that repeats GPU 0 -- several shards, each with its
+   own stream, on the one GPU of a gpurun box.  Exercises the partition, the window / halo planner, the
+   message lists and the event ordering between streams; runs wherever one GPU is visible.
+ * `real`: ngpus distinct GPUs, RCCL (grouped ncclSend / ncclRecv, ncclBroadcast, ncclAllGather) and the
+   peer-copy transport.  Collected everywhere, skipped unless that many GPUs are visible: the first
+   multi-GPU box runs them as tests before any benchmark does.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import spalinalg_amd as sp
+import spal_synth as synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ngpu():
+    try:
+        return sp.device_count()
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+def need_gpus(n):
+    return pytest.mark.skipif(_ngpu() < n, reason=f"needs {n} GPUs, {_ngpu()} visible")
+
+
+def banded(n, dtype=np.float64, window=4096, seed=17):
+    rp, ci, va = synth.banded_csr(n, n, 14, window, seed, dtype=dtype)
+    return sp.CsrMatrix(n, n, rp, ci, va), synth.vector(n, dtype=dtype)
+
+
+def check_all_paths(mg, a, x, oracle):
+    """every exchange path of one handle against the oracle (bit-identical: the shards run the stream kernel)"""
+    rp, ci, va = a.rowptr(), a.colind(), a.values()
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    bits = np.uint64 if a.dtype == np.float64 else np.uint32
+    G = mg.ngpus
+    b = mg.partition().astype(np.int64)
+    assert b[0] == 0 and b[-1] == a.nrows() and np.all(np.diff(b) > 0)
+    lo, hi = mg.windows()
+    for g in range(G):       # the window is exactly the span of the shard's columns
+        cols = ci[int(rp[b[g]]):int(rp[b[g + 1]])]
+        assert (int(lo[g]), int(hi[g])) == (int(cols.min()), int(cols.max()) + 1)
+    # host convenience call
+    assert np.array_equal(mg.spmv(x).view(bits), y_ref.view(bits))
+    # resident: windows scattered, K local products, gathered on GPU 0
+    mg.set_x(x)
+    mg.scatter_x()
+    for _ in range(3):
+        mg.spmv_local()
+    mg.gather_y()
+    assert np.array_equal(mg.y_gathered().view(bits), y_ref.view(bits))
+    # resident: plain broadcast + all-gather (the path north_star words)
+    mg.set_x(x)
+    mg.broadcast_x()
+    mg.spmv_resident()
+    assert np.array_equal(mg.y_allgathered().view(bits), y_ref.view(bits))
+    t = mg.timing()
+    assert t["x_distribution"] is not None and t["compute"] > 0 and t["y_collection"] is not None
+    eb = mg.exchange_bytes()
+    assert eb["y_gather"] == (a.nrows() - int(b[1])) * a.dtype.itemsize
+    assert eb["x_scatter"] == sum(int(hi[g] - lo[g]) for g in range(1, G)) * a.dtype.itemsize
+    # iterative use: x <- A x three times with the halo exchange, against three oracle products
+    mg.set_x(x)
+    mg.scatter_x()
+    v = x
+    for _ in range(3):
+        mg.spmv_halo()
+        v = oracle.csr_spmv(rp, ci, va, v)
+    mg.gather_y()
+    assert np.array_equal(mg.y_gathered().view(bits), v.view(bits))
+    assert mg.timing()["halo"] is not None
+    # ... and a plain product afterwards still works (the vectors swapped roles an odd number of times)
+    mg.set_x(x)
+    mg.scatter_x()
+    mg.spmv_local()
+    mg.gather_y()
+    assert np.array_equal(mg.y_gathered().view(bits), y_ref.view(bits))
+
+
+@pytest.mark.parametrize("shards", [2, 3, 4, 8])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_virtual_shards_on_one_gpu(oracle, shards, dtype):
+    a, x = banded(120_000 + 77 * shards, dtype)
+    mg = sp.MultiGpuCsr(a, shards, devices=[0] * shards)
+    assert mg.transport == "copy"
+    check_all_paths(mg, a, x, oracle)
+    mg.close()
+
+
+def test_virtual_shards_wide_windows_and_ragged_rows(oracle):
+    """windows that cover most of x (the convenience call then broadcasts), rows of 1 ... 27 entries,
+    nnz-balanced (unequal) slices"""
+    n = 90_000
+    rp, ci, va = synth.ragged_csr(n, n, n, 23)       # uniform columns: every shard reads nearly all of x
+    a = sp.CsrMatrix(n, n, rp, ci, va)
+    x = synth.vector(n)
+    mg = sp.MultiGpuCsr(a, 3, devices=[0, 0, 0])
+    y = mg.spmv(x)
+    ref = oracle.csr_spmv(rp, ci, va, x)
+    bound = oracle.csr_abs_bound(rp, ci, va, x)
+    assert np.all(np.abs(y - ref) <= 1e-10 * bound + 1e-300)
+    sizes = np.diff(mg.partition().astype(np.int64))
+    assert sizes.min() != sizes.max() or n % 3 == 0
+    mg.close()
+
+
+def test_non_square_has_no_halo_and_repeats_need_copy_transport(oracle):
+    rp, ci, va = synth.banded_csr(50_000, 70_000, 14, 4096, 5)
+    a = sp.CsrMatrix(50_000, 70_000, rp, ci, va)
+    mg = sp.MultiGpuCsr(a, 2, devices=[0, 0])
+    x = synth.vector(70_000)
+    assert np.array_equal(mg.spmv(x), oracle.csr_spmv(rp, ci, va, x))
+    mg.set_x(x)
+    mg.scatter_x()
+    with pytest.raises(sp.Panic):
+        mg.spmv_halo()
+    mg.close()
+    with pytest.raises(sp.Panic):
+        sp.MultiGpuCsr(a, 2, devices=[0, 0], transport="rccl")   # RCCL refuses duplicate devices
+
+
+@pytest.mark.parametrize("transport", ["rccl", "copy"])
+@pytest.mark.parametrize("ngpus", [pytest.param(2, marks=need_gpus(2)), pytest.param(4, marks=need_gpus(4)),
+                                   pytest.param(8, marks=need_gpus(8))])
+def test_real_gpus(oracle, ngpus, transport):
+    """ngpus distinct GPUs: RCCL and peer copies.  Skipped on a 1-GPU box."""
+    for dtype in (np.float64, np.float32):
+        a, x = banded(400_000 + 1000 * ngpus, dtype)
+        mg = sp.MultiGpuCsr(a, ngpus, transport=transport)
+        assert mg.transport == transport
+        check_all_paths(mg, a, x, oracle)
+        mg.close()
+
+
+@pytest.mark.parametrize("ngpus", [pytest.param(2, marks=need_gpus(2)), pytest.param(4, marks=need_gpus(4)),
+                                   pytest.param(8, marks=need_gpus(8))])
+def test_row_partitioned_spmv_over_nccl(ngpus):
+    """spalinalg_amd/dist.py (one process per GPU, torch.distributed over RCCL): broadcast / scatter of x
+    windows / all-gather / gather on rank 0 / halo exchange, every rank checking its results against the
+    oracle.  Skipped on a 1-GPU box."""
+    port = 29700 + ngpus
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "tests", "dist_nccl_worker.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
+    assert "dist worker ok" in out.stdout

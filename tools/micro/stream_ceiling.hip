@@ -1,0 +1,265 @@
+// Micro-benchmark (development tool): what the HBM delivers for the FOOTPRINT of the CSR stream kernel
+// at config 3 (1.12 GB of f64 values + 0.28 GB of 16-bit columns + 40 MB of row pointers + 80 MB of x read,
+// 80 MB of y written), with no gather and no arithmetic -- the ceiling next to which the product kernel's
+// time is read -- as a function of (a) the workgroups a CU holds (forced through the LDS allocation) and
+// (b) how many tiles of loads a wave keeps in flight.  Also a plain 16-byte copy for the chip's copy rate.
+//   hipcc -O3 --offload-arch=gfx950 tools/micro/stream_ceiling.hip -o tools/micro/stream_ceiling
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#define CK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { printf("%s: %s\n", #e, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) double f64x2;
+
+__global__ __launch_bounds__(256) void copy16(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
+              c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void read16(const u32x4 *__restrict__ src, uint32_t *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    u32x4 acc = {0, 0, 0, 0};
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        u32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
+              c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        acc ^= a ^ b ^ c ^ d;
+    }
+    for (; i < n; i += stride) acc ^= src[i];
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) out[0] = 1;   // (never: keeps the loads alive)
+}
+
+// The stream kernel's loads for one tile of 64 rows x 14 entries: 7 x (16 B of values + 4 B of columns) per lane,
+// 2 row pointers per lane.
+struct Tile {
+    f64x2 v[7];
+    uint32_t c[7], r0, r1;
+};
+__device__ __forceinline__ void tile_load(Tile &t, const double *__restrict__ vals, const uint16_t *__restrict__ col16,
+                                          const uint32_t *__restrict__ rowptr, uint32_t row, uint32_t lane) {
+    const size_t e0 = (size_t)row * 14 + lane * 2;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        t.v[j] = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(vals + e0 + j * 128));
+        t.c[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(col16 + e0 + j * 128));
+    }
+    t.r0 = rowptr[row + lane];
+    t.r1 = rowptr[row + lane + 1];
+}
+__device__ __forceinline__ double tile_use(const Tile &t) {
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) s += t.v[j].x + t.v[j].y + (double)t.c[j];
+    return s + (double)(t.r1 - t.r0);
+}
+
+// One workgroup (4 waves) per super-tile of 1024 rows; a wave owns 4 tiles of 64 rows; PF tiles of loads ahead.
+// XWIN: stage 40 KB of x into LDS per super-tile (through L2, like the product kernel), else x is not read.
+template <int PF, bool XWIN>
+__global__ __launch_bounds__(256, 2) void footprint(const double *__restrict__ vals, const uint16_t *__restrict__ col16,
+                                                    const uint32_t *__restrict__ rowptr, const double *__restrict__ x,
+                                                    double *__restrict__ y, uint32_t nrows, uint32_t nblocks, uint32_t per_xcd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // per_xcd == 0: blocks in launch order (one front through memory); else every XCD a contiguous run of per_xcd blocks
+    const uint32_t b = per_xcd ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    if (b >= nblocks || (per_xcd && (blockIdx.x >> 3) >= per_xcd)) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t wrow = b * 1024 + wave * 256;
+    Tile t[4];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+        if (wrow + p * 64 < nrows) tile_load(t[p], vals, col16, rowptr, wrow + p * 64, lane);
+    if (XWIN) {
+        u32x4 *d4 = reinterpret_cast<u32x4 *>(smem);
+        const uint32_t c0 = b * 1024 > 2048 ? b * 1024 - 2048 : 0;
+        const u32x4 *s4 = reinterpret_cast<const u32x4 *>(x + min(c0, nrows - 5120));
+        u32x4 r[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) r[k] = s4[threadIdx.x + k * 256];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) d4[threadIdx.x + k * 256] = r[k];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t r0 = wrow + k * 64;
+        if (r0 >= nrows) break;
+        if (k + PF < 4 && r0 + PF * 64 < nrows) tile_load(t[(k + PF) & 3], vals, col16, rowptr, r0 + PF * 64, lane);
+        double s = tile_use(t[k & 3]);
+        if (XWIN) s += reinterpret_cast<const double *>(smem)[(lane * 37 + k) & 4095];
+        if (r0 + lane < nrows) y[r0 + lane] = s;
+    }
+}
+
+template <typename F>
+static double time_us(F launch, int iters) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipGetLastError());
+    return ms * 1e3 / iters;
+}
+
+template <int PF, bool XWIN>
+static void run_footprint(const char *name, size_t lds, const double *vals, const uint16_t *col16, const uint32_t *rowptr,
+                          const double *x, double *y, uint32_t nrows) {
+    const uint32_t nblocks = (nrows + 1023) / 1024, per_xcd = (nblocks + 7) / 8;
+    auto kern = footprint<PF, XWIN>;
+    CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const double us = time_us([&] {
+        hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(256), lds, 0, vals, col16, rowptr, x, y, nrows, nblocks, per_xcd);
+    }, 50);
+    const double bytes = (double)nrows * 14 * 10 + 4.0 * nrows + 8.0 * nrows + (XWIN ? 8.0 * nrows : 0.0);
+    printf("footprint %-34s lds %6zu B  %7.1f us  %7.1f GB/s moved (HBM-level bytes %.3f GB)\n", name, lds, us, bytes / us / 1e3,
+           bytes / 1e9);
+    fflush(stdout);
+}
+
+// --place: does the time depend on WHICH allocations the two big streams live in?  6 value arrays x 6 column arrays
+// (odd-sized dummies between them), every pair timed.
+static int place_main() {
+    const uint32_t nrows = 10'000'000;
+    const size_t nnz = (size_t)nrows * 14 + 4096;
+    const int K = 6;
+    double *vals[K], *x, *y;
+    uint16_t *col16[K];
+    uint32_t *rowptr;
+    void *dummy[2 * K];
+    for (int i = 0; i < K; ++i) {
+        CK(hipMalloc(&vals[i], nnz * 8)); CK(hipMemset(vals[i], 1, nnz * 8));
+        CK(hipMalloc(&dummy[2 * i], (size_t)(i + 1) * 7'654'321));
+        CK(hipMalloc(&col16[i], nnz * 2)); CK(hipMemset(col16[i], 1, nnz * 2));
+        CK(hipMalloc(&dummy[2 * i + 1], (size_t)(i + 3) * 3'456'789));
+    }
+    CK(hipMalloc(&rowptr, ((size_t)nrows + 65) * 4)); CK(hipMemset(rowptr, 0, ((size_t)nrows + 65) * 4));
+    CK(hipMalloc(&x, (size_t)nrows * 8)); CK(hipMalloc(&y, (size_t)nrows * 8));
+    CK(hipMemset(x, 0, (size_t)nrows * 8));
+    const uint32_t nblocks = (nrows + 1023) / 1024, per_xcd = (nblocks + 7) / 8;
+    auto kern = footprint<2, true>;
+    CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (int rep = 0; rep < 2; ++rep) {
+        printf("rep %d: rows = value array %%p..., columns = col16 array; us per launch\n", rep);
+        for (int i = 0; i < K; ++i) {
+            printf("vals %p:", (void *)vals[i]);
+            for (int j = 0; j < K; ++j) {
+                const double us = time_us([&] {
+                    hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(256), 72 * 1024, 0, vals[i], col16[j], rowptr, x, y, nrows, nblocks, per_xcd);
+                }, 20);
+                printf(" %6.1f", us);
+            }
+            printf("\n");
+            fflush(stdout);
+        }
+    }
+    for (int j = 0; j < K; ++j) printf("col16[%d] %p\n", j, (void *)col16[j]);
+    return 0;
+}
+
+// --stride: for each of 5 value arrays, the time as a function of the blocks per XCD run (i.e. of the distance
+// between the 8 streams that walk the array), and with no XCD runs at all.
+static int stride_main() {
+    const uint32_t nrows = 10'000'000;
+    const size_t nnz = (size_t)nrows * 14 + 4096;
+    const int K = 5;
+    double *vals[K], *x, *y;
+    uint16_t *col16;
+    uint32_t *rowptr;
+    void *dummy[K];
+    for (int i = 0; i < K; ++i) {
+        CK(hipMalloc(&vals[i], nnz * 8 + (32u << 20))); CK(hipMemset(vals[i], 1, nnz * 8));
+        CK(hipMalloc(&dummy[i], (size_t)(i + 1) * 7'654'321));
+    }
+    CK(hipMalloc(&col16, nnz * 2)); CK(hipMemset(col16, 1, nnz * 2));
+    CK(hipMalloc(&rowptr, ((size_t)nrows + 65) * 4)); CK(hipMemset(rowptr, 0, ((size_t)nrows + 65) * 4));
+    CK(hipMalloc(&x, (size_t)nrows * 8)); CK(hipMalloc(&y, (size_t)nrows * 8));
+    CK(hipMemset(x, 0, (size_t)nrows * 8));
+    const uint32_t nblocks = (nrows + 1023) / 1024, base = (nblocks + 7) / 8;
+    auto kern = footprint<2, true>;
+    CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int deltas[] = {0, 1, 2, 3, 4, 6, 8, 16, 32, 64, -1};
+    printf("columns: per-XCD run = ceil(nblocks / 8) + {0, 1, 2, 3, 4, 6, 8, 16, 32, 64} blocks, then launch order (no runs);"
+           " then the array shifted by 4 KB, 64 KB, 1 MB, 16 MB at run + 0\n");
+    for (int i = 0; i < K; ++i) {
+        printf("vals %p:", (void *)vals[i]);
+        for (int dl : deltas) {
+            const uint32_t per_xcd = dl < 0 ? 0u : base + (uint32_t)dl;
+            const uint32_t grid = dl < 0 ? nblocks : per_xcd * 8;
+            const double us = time_us([&] {
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 72 * 1024, 0, vals[i], col16, rowptr, x, y, nrows, nblocks, per_xcd);
+            }, 20);
+            printf(" %6.1f", us);
+        }
+        printf("  |");
+        for (size_t shift : {(size_t)4096, (size_t)65536, (size_t)1 << 20, (size_t)16 << 20}) {
+            const double *v = (const double *)((const char *)vals[i] + shift);
+            const double us = time_us([&] {
+                hipLaunchKernelGGL(kern, dim3(base * 8), dim3(256), 72 * 1024, 0, v, col16, rowptr, x, y, nrows, nblocks, base);
+            }, 20);
+            printf(" %6.1f", us);
+        }
+        printf("\n");
+        fflush(stdout);
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1 && std::string(argv[1]) == "--place") return place_main();
+    if (argc > 1 && std::string(argv[1]) == "--stride") return stride_main();
+    const uint32_t nrows = 10'000'000;
+    const size_t nnz = (size_t)nrows * 14 + 4096;
+    double *vals, *x, *y;
+    uint16_t *col16;
+    uint32_t *rowptr;
+    CK(hipMalloc(&vals, nnz * 8)); CK(hipMalloc(&col16, nnz * 2)); CK(hipMalloc(&rowptr, ((size_t)nrows + 65) * 4));
+    CK(hipMalloc(&x, (size_t)nrows * 8)); CK(hipMalloc(&y, (size_t)nrows * 8));
+    CK(hipMemset(vals, 1, nnz * 8)); CK(hipMemset(col16, 1, nnz * 2)); CK(hipMemset(rowptr, 0, ((size_t)nrows + 65) * 4));
+    CK(hipMemset(x, 0, (size_t)nrows * 8));
+    // plain copy / read of 1.6 GB
+    {
+        const size_t n16 = (size_t)100'000'000;   // 1.6 GB
+        u32x4 *a, *b;
+        uint32_t *flag;
+        CK(hipMalloc(&a, n16 * 16)); CK(hipMalloc(&b, n16 * 16)); CK(hipMalloc(&flag, 4));
+        CK(hipMemset(a, 3, n16 * 16));
+        for (int grid : {2048, 4096, 8192}) {
+            double us = time_us([&] { hipLaunchKernelGGL(copy16, dim3(grid), dim3(256), 0, 0, a, b, n16); }, 20);
+            printf("copy16  grid %5d  %7.1f us  %7.1f GB/s (read + write)\n", grid, us, 2.0 * n16 * 16 / us / 1e3);
+            us = time_us([&] { hipLaunchKernelGGL(read16, dim3(grid), dim3(256), 0, 0, a, flag, n16); }, 20);
+            printf("read16  grid %5d  %7.1f us  %7.1f GB/s (read only)\n", grid, us, 1.0 * n16 * 16 / us / 1e3);
+        }
+        CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(flag));
+    }
+    // the stream kernel's footprint
+    for (int rep = 0; rep < 2; ++rep) {
+        for (size_t lds : {(size_t)72 * 1024, (size_t)50 * 1024, (size_t)38 * 1024, (size_t)18 * 1024}) {
+            run_footprint<1, false>("1 tile ahead, no x", lds, vals, col16, rowptr, x, y, nrows);
+            run_footprint<2, false>("2 tiles ahead, no x", lds, vals, col16, rowptr, x, y, nrows);
+            run_footprint<3, false>("3 tiles ahead, no x", lds, vals, col16, rowptr, x, y, nrows);
+        }
+        run_footprint<1, true>("1 tile ahead, x window staged", 72 * 1024, vals, col16, rowptr, x, y, nrows);
+        run_footprint<2, true>("2 tiles ahead, x window staged", 72 * 1024, vals, col16, rowptr, x, y, nrows);
+        run_footprint<3, true>("3 tiles ahead, x window staged", 72 * 1024, vals, col16, rowptr, x, y, nrows);
+    }
+    return 0;
+}
