@@ -45,8 +45,9 @@ def parse():
                     help="BASELINE config: 3 = CSR 10Mx10M/140M nnz (headline, the default line), "
                          "2 = CSR 1Mx1M/14M nnz, 4 = CSC scatter 1Mx1M, 5 = COO->CSR assembly 50M entries, "
                          "1 = the reference's CPU-sized case (10k x 10k, 100k triplets) end to end")
-    ap.add_argument("--dist", default="banded", choices=["banded", "uniform"],
-                    help="column distribution: banded W=4096 (headline) or uniform (stress row)")
+    ap.add_argument("--dist", default="banded", choices=["banded", "uniform", "ragged"],
+                    help="column distribution: banded W=4096 (headline), uniform (stress row: columns anywhere), "
+                         "ragged (robustness row of SURVEY 8d: banded columns, row length 1 + next() % 27)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
@@ -71,6 +72,14 @@ def parse():
     ap.add_argument("--plain-collectives", action="store_true",
                     help="N > 1, --exchange end: use broadcast / all-gather even when every rank reads only a "
                          "window of x (default: rank 0 scatters the windows and gathers the y slices)")
+    ap.add_argument("--host", default="torch", choices=["torch", "mg"],
+                    help="who drives N > 1 GPUs: torch = one process per GPU over torch.distributed (the driver's "
+                         "launch contract, spalinalg_amd/dist.py); mg = THIS one process through the C ABI's spal_mg_* "
+                         "(what a single-process caller such as the Rust crate binds): python bench.py --host mg --gpus N")
+    ap.add_argument("--devices", default="",
+                    help="--host mg: comma-separated device list; repeats (e.g. 0,0,0,0) put several shards on one "
+                         "GPU over the copy transport -- a rehearsal of the multi-GPU path on a 1-GPU box")
+    ap.add_argument("--transport", default=None, choices=["rccl", "copy"], help="--host mg: exchange transport")
     ap.add_argument("--extras", action="store_true",
                     help="N > 1, --exchange end: also time K steps with an all-gather after every step and "
                          "report it beside the headline (extra collectives; off by default)")
@@ -99,6 +108,22 @@ def rotating(fns):
         fns[state["i"] % len(fns)]()
         state["i"] += 1
     return call
+
+
+def copy_ceiling(nrows, per_row):
+    """What the HBM of THIS box delivers for the stream kernel's footprint (tools/micro/stream_ceiling.hip, built by
+    __graft_entry__.build(): the same loads -- 16-byte value pairs, 4-byte column pairs, the x window through LDS,
+    y stores -- with no gather and no arithmetic), measured by a child process in the same run; plus the plain
+    16-byte copy / read rates.  None when the binary is missing."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "micro", "stream_ceiling")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "--quick", str(nrows), str(per_row)], capture_output=True, text=True, timeout=180)
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception:  # noqa: BLE001  (informational)
+        return None
 
 
 def traffic_entry(key):
@@ -317,6 +342,128 @@ def bench_coo(args):
     print(json.dumps(out))
 
 
+def steady(fn, sync, reps=12):
+    """median and min wall time (ms) of fn() + sync() over `reps` calls after two warm-up calls"""
+    for _ in range(2):
+        fn()
+        sync()
+    out = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        sync()
+        out.append((time.perf_counter() - t0) * 1e3)
+    out.sort()
+    return out[len(out) // 2], out[0]
+
+
+def bench_mg(args):
+    """--host mg: the row-partitioned product driven from ONE process through spal_mg_* (C ABI): x windows
+    scattered from GPU 0 (grouped ncclSend/ncclRecv) -> K local SpMVs -> y slices gathered on GPU 0."""
+    import spalinalg_amd as sp
+    import spal_synth as synth
+    if sp.device_count() < 1:
+        sys.exit("bench.py needs a GPU: libspal_hip has no CPU fallback")
+    cfg = synth.CONFIGS[args.config]
+    nrows, ncols, per_row = cfg["nrows"], cfg["ncols"], cfg["per_row"]
+    window = ncols if args.dist == "uniform" else cfg["window"]
+    np_dt = np.float64 if args.dtype == "f64" else np.float32
+    esz = np.dtype(np_dt).itemsize
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else None
+    G = len(devices) if devices else args.gpus
+    virtual = devices is not None and len(set(devices)) < len(devices)
+    t0 = time.time()
+    if args.dist == "ragged":
+        rp, ci, va = synth.ragged_csr(nrows, ncols, cfg["window"], synth.matrix_seed(args.config), dtype=np_dt)
+    else:
+        rp, ci, va = synth.banded_csr(nrows, ncols, per_row, window, synth.matrix_seed(args.config), dtype=np_dt)
+    nnz = int(rp[-1])
+    xh = synth.vector(ncols, dtype=np_dt)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    mg = sp.MultiGpuCsr(sp.CsrMatrix._trusted(nrows, ncols, rp, ci, va), G, devices=devices, transport=args.transport)
+    t_upload = time.time() - t0
+    eb = mg.exchange_bytes()
+    mg.set_x(xh)
+    windows_pay = eb["x_scatter"] * 4 <= (G - 1) * ncols * esz * 3
+    dist_x = mg.scatter_x if (windows_pay and not args.plain_collectives) else mg.broadcast_x
+    # warm-up, then the timed region: x once -> K local products -> y once
+    dist_x()
+    for _ in range(args.warmup):
+        mg.spmv_local()
+    mg.gather_y()
+    mg.synchronize()
+    t0 = time.perf_counter()
+    dist_x()
+    for _ in range(args.steps):
+        mg.spmv_local()
+    mg.gather_y()
+    mg.synchronize()
+    total_ms = (time.perf_counter() - t0) * 1e3
+    ms_per_step = total_ms / args.steps
+    y = mg.y_gathered()
+    # steady-state pieces: wall clock around call + synchronize, and the library's HIP events (longest over the GPUs)
+    comm = {}
+    for name, fn, phase in (("x_distribution", dist_x, "x_distribution"), ("y_collection", mg.gather_y, "y_collection")):
+        med, mn = steady(fn, mg.synchronize)
+        comm[name] = {"wall_ms_median": round(med, 4), "wall_ms_min": round(mn, 4), "event_ms": round(mg.timing()[phase], 4)}
+    med, mn = steady(mg.spmv_local, mg.synchronize, reps=30)
+    compute = {"wall_ms_median": round(med, 4), "wall_ms_min": round(mn, 4), "event_ms": round(mg.timing()["compute"], 4)}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mg.spmv_local()
+    mg.synchronize()
+    compute["ms_per_step_back_to_back"] = round((time.perf_counter() - t0) * 1e3 / args.steps, 6)
+    halo = None
+    if nrows == ncols:
+        mg.set_x(xh)
+        dist_x()
+        med, mn = steady(mg.spmv_halo, mg.synchronize, reps=20)
+        tm = mg.timing()
+        halo = {"step_wall_ms_median": round(med, 4), "step_wall_ms_min": round(mn, 4), "exchange_event_ms": round(tm["halo"], 4),
+                "bytes_per_step": eb["halo"]}
+    # parity: GPU 0's gathered y against the CPU oracle (bit for bit on the stream path)
+    import oracle  # checker only
+    yh = oracle.csr_spmv(rp, ci, va, xh)
+    bits = np.uint64 if esz == 8 else np.uint32
+    exact = bool(np.array_equal(y.view(bits), yh.view(bits)))
+    if not exact:
+        bound = oracle.csr_abs_bound(rp, ci, va, xh)
+        tol = 1e-10 if esz == 8 else 1e-4
+        if not np.all(np.abs(y.astype(np.float64) - yh.astype(np.float64)) <= tol * bound + 1e-300):
+            sys.exit("--host mg: the gathered y differs from the CPU oracle")
+    whole_bytes = synth.spmv_bytes(nnz, nrows, nrows, ncols, esz)
+    kern_ms = compute["ms_per_step_back_to_back"]
+    out = {
+        "metric": "CSR SpMV GFLOP/s (f64, 10Mx10M, 140M nnz)" if args.config == 3 and esz == 8 and args.dist == "banded"
+                  else f"CSR SpMV GFLOP/s ({args.dtype}, config {args.config}, {args.dist})",
+        "value": round(synth.spmv_flops(nnz) / (ms_per_step * 1e-3) / 1e9, 3), "unit": "GFLOP/s",
+        "n_gpus": len(set(devices)) if devices else G, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 6), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"CsrMatrix {args.dtype} SpMV y=A*x, {nrows}x{ncols}, {nnz} nnz, {args.dist} columns, rows "
+                               f"partitioned into {G} shards" + (f" on devices {devices} (virtual shards: a rehearsal)" if virtual else f" over {G} GPUs")
+                               + f", ONE process through the C ABI (spal_mg_*, transport {mg.transport}): x "
+                               + ("windows scattered from GPU 0" if dist_x == mg.scatter_x else "broadcast from GPU 0")
+                               + ", K local SpMVs, y slices gathered on GPU 0 -- all inside the timed region",
+                   "host": "mg", "shards": G, "transport": mg.transport, "partition": [int(b) for b in mg.partition()],
+                   "exchange_bytes": eb},
+        "algorithmic_bytes_per_step": whole_bytes,
+        "roofline": {"bound": "hbm", "achieved": round(whole_bytes / (kern_ms * 1e-3) / 1e9 / max(1, (len(set(devices)) if devices else G)), 2),
+                     "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(whole_bytes / (kern_ms * 1e-3) / 8e12 / max(1, (len(set(devices)) if devices else G)), 4), "traffic": None,
+                     "kernel": "csr_spmv_stream / csr_spmv_slide per shard", "kernel_ms": kern_ms,
+                     "note": "per GPU: the whole matrix's algorithmic bytes / the shards' concurrent kernels / the GPUs"},
+        "compute_only": compute, "comm_ms": comm, "halo": halo,
+        "efficiency_inputs": {"total_ms": round(total_ms, 4), "K": args.steps,
+                              "note": "total = x_distribution + K * compute + y_collection: recompute for any K"},
+        "gpu_equals_cpu_bit_for_bit": exact,
+        "setup_s": {"generate": round(t_gen, 2), "validate_narrow_upload_plan": round(t_upload, 2)},
+    }
+    print(json.dumps(out))
+    mg.close()
+
+
 def base_record(args, metric, value, unit, ms, workload, plan):
     return {"metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 6), "higher_is_better": True, "scaling": "strong",
@@ -335,6 +482,10 @@ def main():
         if not torch.cuda.is_available() or sp.device_count() < 1:
             sys.exit("bench.py needs a GPU: libspal_hip has no CPU fallback")
         return bench_small(args) if args.config == 1 else bench_csc(args) if args.config == 4 else bench_coo(args)
+    if args.host == "mg":
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            sys.exit("--host mg is ONE process driving every GPU: run it without torch.distributed.run")
+        return bench_mg(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -365,18 +516,29 @@ def main():
 
     cfg = synth.CONFIGS[args.config]
     nrows, ncols, per_row = cfg["nrows"], cfg["ncols"], cfg["per_row"]
-    window = cfg["window"] if args.dist == "banded" else ncols
+    window = ncols if args.dist == "uniform" else cfg["window"]
     np_dt = np.float64 if args.dtype == "f64" else np.float32
     t_dt = torch.float64 if args.dtype == "f64" else torch.float32
     esz = 8 if args.dtype == "f64" else 4
-    nnz = nrows * per_row
+
+    def gen_rows(a, b):
+        if args.dist == "ragged":
+            return synth.ragged_csr(nrows, ncols, window, synth.matrix_seed(args.config), dtype=np_dt, rows=(a, b))
+        return synth.banded_csr(nrows, ncols, per_row, window, synth.matrix_seed(args.config), dtype=np_dt, rows=(a, b))
 
     # ---- the rank's shard: rows [r0, r1), generated on the host, uploaded through the C ABI
-    bounds = even_rows(nrows, world)  # same entries in every row: even rows == even entries
-    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
     t0 = time.time()
-    rp, ci, va = synth.banded_csr(nrows, ncols, per_row, window, synth.matrix_seed(args.config),
-                                     dtype=np_dt, rows=(r0, r1))
+    if args.dist == "ragged":   # rows of 1 ... 27 entries: ranges with balanced stored entries
+        from spalinalg_amd.dist import partition_rows
+        rp_all = synth.ragged_rowptr(nrows, synth.matrix_seed(args.config))
+        nnz = int(rp_all[-1])
+        bounds = partition_rows(rp_all, world)
+        del rp_all
+    else:
+        nnz = nrows * per_row
+        bounds = even_rows(nrows, world)  # same entries in every row: even rows == even entries
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    rp, ci, va = gen_rows(r0, r1)
     t_gen = time.time() - t0
     t0 = time.time()
     shard = sp.CsrMatrix._trusted(r1 - r0, ncols, rp, ci, va)   # generator output is valid by construction;
@@ -579,7 +741,7 @@ def main():
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
     kern_ms_max = float(kmax.item())
 
-    local_nnz = (r1 - r0) * per_row
+    local_nnz = int(rp[-1])
     local_bytes = synth.spmv_bytes(local_nnz, r1 - r0, r1 - r0, ncols, esz)
     whole_bytes = synth.spmv_bytes(nnz, nrows, nrows, ncols, esz)
     achieved = local_bytes / (kern_ms * 1e-3) / 1e9          # GB/s, this rank's launch, ALGORITHMIC bytes (32-bit indices)
@@ -612,8 +774,7 @@ def main():
     if rank == 0 and world > 1:
         for g in range(world):
             for r in (int(bounds[g]), int(bounds[g + 1]) - 1):
-                _, c1, v1 = synth.banded_csr(nrows, ncols, per_row, window, synth.matrix_seed(args.config),
-                                                dtype=np_dt, rows=(r, r + 1))
+                _, c1, v1 = gen_rows(r, r + 1)
                 ref = float(np.dot(v1.astype(np.float64), xh[c1.astype(np.int64)].astype(np.float64)))
                 got = float(y[r].item())
                 if abs(got - ref) > tol * max(1.0, abs(ref)):
@@ -643,8 +804,8 @@ def main():
             traffic = None
 
     out = {
-        "metric": "CSR SpMV GFLOP/s (f64, 10Mx10M, 140M nnz)" if args.config == 3 and esz == 8
-                  else f"CSR SpMV GFLOP/s ({args.dtype}, config {args.config})",
+        "metric": "CSR SpMV GFLOP/s (f64, 10Mx10M, 140M nnz)" if args.config == 3 and esz == 8 and args.dist == "banded"
+                  else f"CSR SpMV GFLOP/s ({args.dtype}, config {args.config}, {args.dist})",
         "value": round(gflops, 3),
         "unit": "GFLOP/s",
         "n_gpus": world,
@@ -657,9 +818,10 @@ def main():
         "dtype": args.dtype,
         "data": "synthetic",
         "config": {
-            "workload": f"CsrMatrix {args.dtype} SpMV y=A*x, {nrows}x{ncols}, {per_row} nnz/row "
-                        f"({nnz} nnz), {args.dist} columns"
-                        + (f" W={window}" if args.dist == "banded" else "")
+            "workload": f"CsrMatrix {args.dtype} SpMV y=A*x, {nrows}x{ncols}, "
+                        + (f"{per_row} nnz/row" if args.dist != "ragged" else "1 + next() % 27 nnz/row (SURVEY 8d robustness row)")
+                        + f" ({nnz} nnz), {args.dist} columns"
+                        + (f" W={window}" if args.dist != "uniform" else "")
                         + f" (BASELINE configs[{2 if args.config == 3 else 1}]), "
                         + ((f"single GPU" + (f"; launches rotate over {copies} independent copies of (A, x, y), "
                                              f"together larger than the 256 MB Infinity Cache" if copies > 1 else ""))
@@ -715,6 +877,15 @@ def main():
         "setup_s": {"generate": round(t_gen, 2), "validate_narrow_upload_plan": round(t_upload, 2)},
     }
 
+    if world == 1:
+        # the ceiling next to which `frac` is read: what this box's HBM delivers for the same footprint
+        ceil = copy_ceiling(nrows, max(1, nnz // nrows))
+        if ceil:
+            out["roofline"]["copy_ceiling_gbs"] = ceil["footprint_gbs"]
+            out["roofline"]["moved_frac_of_ceiling"] = round(moved / ceil["footprint_gbs"], 4)
+            out["roofline"]["ceiling"] = dict(ceil, note="child process tools/micro/stream_ceiling --quick, same run, same GPU: the stream "
+                                                         "kernel's loads and stores without gather or arithmetic; copy16 / read16 = plain "
+                                                         "16-byte copy (read + write bytes) / read of the values array")
     if world == 1 and not args.no_cpu_baseline:
         import oracle  # CPU baseline leg only: the oracle is the thing timed here, never the product
         rp32, ci32 = rp.astype(np.uint32), ci.astype(np.uint32)

@@ -124,14 +124,21 @@ int spal_csr_download_f32(spal_csr_t a, uint64_t *rowptr, uint64_t *colind,
  * holds at once), "nt_store", "stream_global", "window_pages" (0 auto; LDS x
  * window budget in 256-column pages), "stream_row_max" (64-row tiles with a
  * longer row go to the overflow kernel; default 128), "skew" (-1 auto, 0, 1:
- * skewed LDS product strips) (stream kernel).  Unknown key or a value
+ * skewed LDS product strips), "slide" (-1 auto / 0: the sliding-window kernel
+ * and its ring-addressed x window for band-like plans), "slide_on" (0 / 1:
+ * launch it), "uniform_rows" (0 / 1: super-tiles whose rows all have one length
+ * do not read rowptr), "prefetch" (1 / 2 tiles of loads ahead), "place_tries"
+ * (autotune) (stream kernel).  Unknown key or a value
  * the kernels are not instantiated for: SPAL_ERR_INVALID_ARGUMENT. */
 int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value);
-/* Setup-time autotune: runs the planned kernel's variants (today: the stream
- * kernel with one workgroup per super-tile vs. its persistent form, each with
- * plain or non-temporal y stores) `iters` times each on the caller's device
- * vectors, keeps the fastest.  All variants
- * produce identical y.  Synchronises `stream`. */
+/* Setup-time autotune: runs the planned kernel's variants (the stream kernel
+ * with one workgroup per super-tile vs. its walking form -- the sliding-window
+ * kernel on band-like plans, else the persistent form -- each with plain or
+ * non-temporal y stores) `iters` times each on the caller's device vectors and
+ * keeps the fastest; then tries up to "place_tries" fresh allocations for the
+ * values array (identical kernels ran 5-14 % apart depending on the allocation
+ * that array lives in) and keeps the fastest.  All variants produce identical
+ * y.  Synchronises `stream`. */
 int spal_csr_autotune_f64(spal_csr_t a, const double *x_dev, double *y_dev,
                           void *stream, int iters);
 int spal_csr_autotune_f32(spal_csr_t a, const float *x_dev, float *y_dev,
@@ -141,7 +148,9 @@ int spal_csr_autotune_f32(spal_csr_t a, const float *x_dev, float *y_dev,
  * geometry ("rows_per_tile", "rows_per_block", "lanes_per_row", ...),
  * "lds_window_bytes", "stream_row_fraction" (rows in tiles that stream),
  * "overflow_tiles" (tiles left to the overflow kernel), "skew", "persistent",
- * "nt_store", "autotune_us". */
+ * "slide", "ring_pages", "uniform_row_fraction", "nt_store", "autotune_us"
+ * (one workgroup per super-tile, walking form, each then with non-temporal y
+ * stores), "placement_us" (before / after re-placing the values array). */
 int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len);
 
 /* ---- CSC: y = A * x (atomic scatter) --------------------------------------
@@ -311,6 +320,12 @@ int spal_dev_free(int device, void *ptr);
 int spal_memcpy_h2d(int device, void *dst_dev, const void *src_host, size_t bytes);
 int spal_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);
 int spal_device_synchronize(int device);
+/* Device blocks released by *_destroy / spal_dev_free are kept in a per-process
+ * cache for reuse (bounded by the environment variable SPAL_CACHE_BYTES; default:
+ * a quarter of the device's memory, at most half of what was free at first use).
+ * spal_cache_trim hands every cached block back to the driver, e.g. before
+ * another allocator in the process (torch) needs the memory. */
+int spal_cache_trim(void);
 
 #ifdef __cplusplus
 }

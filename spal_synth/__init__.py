@@ -90,6 +90,14 @@ def ragged_csr(nrows, ncols, window, seed, dtype=np.float64, rows=None):
     return rp, ci, va
 
 
+def ragged_rowptr(nrows, seed, rows=None):
+    """rowptr of ragged_csr alone (for partitioning before any entry is generated)"""
+    r0, r1 = (0, nrows) if rows is None else rows
+    rp = np.empty(r1 - r0 + 1, dtype=np.uint64)
+    _check(lib().spal_synth_ragged_rowptr(u64(nrows), u64(seed), u64(r0), u64(r1), _p(rp)))
+    return rp
+
+
 def vector(n, seed=SEED_X, dtype=np.float64):
     dtype = np.dtype(dtype)
     x = np.empty(n, dtype=dtype)

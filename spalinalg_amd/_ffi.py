@@ -107,3 +107,8 @@ def device_count() -> int:
     n = C.c_int(0)
     check(lib().spal_device_count(C.byref(n)))
     return n.value
+
+
+def cache_trim() -> None:
+    """Hands the library's cached device blocks back to the driver (see spal_cache_trim in include/spal.h)."""
+    check(lib().spal_cache_trim())

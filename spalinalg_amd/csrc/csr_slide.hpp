@@ -121,12 +121,25 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_slide(
     T *xw = prod_all + kStreamWaves * stream_strip<false>();
     vec_t *xw4 = reinterpret_cast<vec_t *>(xw);
 
-    // this workgroup's steps: [i0, i1) inside its XCD's contiguous run
-    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-    const uint32_t run_end = min((xcd + 1u) * per_xcd, nsteps);
-    const uint32_t i0 = xcd * per_xcd + slot * chunk;
-    if (i0 >= run_end) return;
-    const uint32_t i1 = min(i0 + chunk, run_end);
+    // this workgroup's steps: its XCD owns a contiguous range of steps, cut into RUNS of `chunk` steps that are dealt
+    // round-robin to the XCD's workgroups (blockIdx >> 3 = slot).  Inside a run the window slides; a new run stages
+    // its first window whole.  (One run per workgroup = chunk >= steps per XCD / slots is the fully persistent form;
+    // shorter runs keep the workgroups of an XCD on neighbouring memory -- one front instead of 64.)
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const uint32_t xbase = xcd * per_xcd;
+    if (xbase >= nsteps) return;
+    const uint32_t nx = min(per_xcd, nsteps - xbase);                 // steps of this XCD
+    const uint32_t nruns = (nx + chunk - 1u) / chunk;
+    if (slot >= nruns) return;
+    const uint32_t myruns = (nruns - slot + slots - 1u) / slots;
+    // steps of this workgroup: full runs, except that the XCD's last run may be short and is then this one's last
+    const uint32_t lastrun = slot + (myruns - 1u) * slots;
+    const uint32_t nk = (myruns - 1u) * chunk + min(chunk, nx - lastrun * chunk);
+    // k-th step of this workgroup -> its global step index (k past the end: the last one again)
+    auto gi = [&](uint32_t k) {
+        const uint32_t kc = min(k, nk - 1u);
+        return xbase + (slot + (kc / chunk) * slots) * chunk + kc % chunk;
+    };
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);   // scalar: tile bounds come by s_load
@@ -134,24 +147,24 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_slide(
     const uint32_t wmax = NP * kPageCols - 1u;
     const uint32_t last_vec = ncols / V - 1u;     // (ncols >= kPageCols by the plan)
 
-    // rows / entry range of this wave's tile at step i; steps past the run re-read its last step's tile (same count
-    // of loads on every path -- that is the point -- and nobody uses them)
-    auto tile_row = [&](uint32_t i) { return (min(i, i1 - 1u) * kStreamWaves + wave) * (uint32_t)RPT; };
-    auto tile_b = [&](uint32_t i) { return rowptr[min(tile_row(i), nrows)]; };
-    auto tile_e = [&](uint32_t i) { return rowptr[min(tile_row(i) + (uint32_t)RPT, nrows)]; };
+    // rows / entry range of this wave's tile at the workgroup's k-th step; steps past its last re-read that one's tile
+    // (same count of loads on every path -- that is the point -- and nobody uses them)
+    auto tile_row = [&](uint32_t k) { return (gi(k) * kStreamWaves + wave) * (uint32_t)RPT; };
+    auto tile_b = [&](uint32_t k) { return rowptr[min(tile_row(k), nrows)]; };
+    auto tile_e = [&](uint32_t k) { return rowptr[min(tile_row(k) + (uint32_t)RPT, nrows)]; };
 
     StreamTile<T> t[NB];
     uint32_t tb[NB], te[NB];     // entry ranges of the tiles whose loads go out next (asked for a step early, by s_load)
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
-        tb[q] = tile_b(i0 + (uint32_t)q);
-        te[q] = tile_e(i0 + (uint32_t)q);
+        tb[q] = tile_b((uint32_t)q);
+        te[q] = tile_e((uint32_t)q);
     }
-    uint2 d = sdesc[i0];
-    uint2 dn = sdesc[min(i0 + 1u, i1 - 1u)];
+    uint2 d = sdesc[gi(0u)];
+    uint2 dn = sdesc[gi(1u)];
 #pragma unroll
     for (int q = 0; q < PF; ++q)
-        slide_tile_load<T, RPT, S, UNI>(t[q], rowptr, col16, vals, tile_row(i0 + (uint32_t)q), nrows, tb[q], te[q], lane, ulen);
+        slide_tile_load<T, RPT, S, UNI>(t[q], rowptr, col16, vals, tile_row((uint32_t)q), nrows, tb[q], te[q], lane, ulen);
     // the first window, whole
     {
         const uint32_t f = d.x, nv = (d.y & 0xffu) * VP;
@@ -171,19 +184,19 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_slide(
     }
     __syncthreads();
 
-    // ---- one step; K = (i - i0) % NB is the slot of its tile
+    // ---- the workgroup's k-th step; K = k % NB is the slot of its tile
     auto step = [&](uint32_t i, auto kc) {
         constexpr int K = decltype(kc)::value;
         constexpr int KN = (K + PF) % NB;            // slot of the tile PF steps ahead: its loads go out now
         const uint32_t skip = (d.y >> 8) & 0xfu;
-        const bool more = i + 1u < i1;               // block-uniform
+        const bool more = i + 1u < nk;               // block-uniform
         // pages that enter the window with step i + 1: requested first (loads return in order: what is written to LDS
         // at the end of this step must not queue behind the tile requested below), stored after this step's products.
         // Unconditional (a thread without a vector to fetch reads x[0 ...]): a counted wait again.
         SlideNew nw = slide_new_pages(d.x, d.y & 0xffu, dn.x, dn.y & 0xffu);
         const uint32_t nlo = (nw.lo1 - nw.lo0) * VP;
         const uint32_t ntot = more ? nlo + (nw.hi1 - nw.hi0) * VP : 0u;
-        const bool async = more && (dn.y & kSlideAsync);
+        const bool async = more && (dn.y & kSlideAsync) && (i + 1u) % chunk != 0u;   // (a new run's window is staged whole)
         auto new_page = [&](uint32_t j) { return j < nlo ? nw.lo0 + j / VP : nw.hi0 + (j - nlo) / VP; };
         vec_t nv[kSlideAsyncVecs];
 #pragma unroll
@@ -198,15 +211,23 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_slide(
         tb[K] = tile_b(i + PF + 1u);
         te[K] = tile_e(i + PF + 1u);
         // this step's tile
-        const uint32_t r0 = (i * kStreamWaves + wave) * (uint32_t)RPT;
+        const uint32_t r0 = (gi(i) * kStreamWaves + wave) * (uint32_t)RPT;
+#ifdef SPAL_DIAG
+        if (SPAL_DIAG_ON(flags, 11)) {   // ablation: no products, no sums -- the loads, the window and the barriers only
+            T sacc = T(0);
+#pragma unroll
+            for (int j = 0; j < S; ++j) sacc += t[K].v[j].x + t[K].v[j].y + T(t[K].c[j]);
+            if (r0 + lane < nrows) y[r0 + lane] = sacc + T(t[K].rp1 - t[K].rp0);
+        } else
+#endif
         if (r0 < nrows && !((skip >> wave) & 1u))
-            stream_compute<T, RPT, false>(t[K], xw, wmax, prod, y, r0, nrows, lane, nt_store);
+            stream_compute<T, RPT, false>(t[K], xw, wmax, prod, y, r0, nrows, lane, nt_store, flags);
 #pragma unroll
         for (uint32_t k = 0; k < kSlideAsyncVecs; ++k) {
             const uint32_t j = threadIdx.x + k * kStreamBlock;
             if (async && j < ntot) xw4[(new_page(j) % NP) * VP + j % VP] = nv[k];
         }
-        __syncthreads();
+        if (!SPAL_DIAG_ON(flags, 12)) __syncthreads();   // (ablation bit 12: no barrier between steps -- wrong results)
         if (more && !async && ntot) {
             // the entering pages would overwrite slots this step still read (or are too many to hold in registers):
             // load them now that every wave is done with the step
@@ -226,14 +247,14 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_slide(
             __syncthreads();
         }
         d = dn;
-        dn = sdesc[min(i + 2u, i1 - 1u)];
+        dn = sdesc[gi(i + 2u)];
     };
 
-    for (uint32_t i = i0; i < i1; i += NB) {
+    for (uint32_t i = 0; i < nk; i += NB) {
         step(i, std::integral_constant<int, 0>{});
-        if (i + 1u < i1) step(i + 1u, std::integral_constant<int, 1>{});
+        if (i + 1u < nk) step(i + 1u, std::integral_constant<int, 1>{});
         if constexpr (NB > 2)
-            if (i + 2u < i1) step(i + 2u, std::integral_constant<int, 2>{});
+            if (i + 2u < nk) step(i + 2u, std::integral_constant<int, 2>{});
     }
 }
 

@@ -43,11 +43,13 @@ struct DevCache {
     size_t cached_bytes = 0;
     // default: a quarter of the device's memory (72 GB of 288), at least 8 GiB -- the 27 GB of output an
     // assembly of 2.3e9 triplets allocates must be reusable or every call pays hipMalloc / hipFree again
+    // (SPAL_CACHE_BYTES overrides; when the device cannot be asked, or is small, the cache stays small: at most
+    //  half of what was free at first use)
     size_t limit = [] {
         if (const char *e = getenv("SPAL_CACHE_BYTES")) return (size_t)strtoull(e, nullptr, 10);
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = 0; }
-        return std::max((size_t)8 << 30, total_b / 4);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return (size_t)256 << 20; }
+        return std::min(free_b / 2, std::max((size_t)8 << 30, total_b / 4));
     }();
     ~DevCache() {}  // the process is going away; the driver reclaims device memory
 };
@@ -148,14 +150,23 @@ hipError_t dev_free(void *ptr) {
             if (c.live[i].p == ptr) { b = c.live[i]; c.live.erase(c.live.begin() + i); break; }
     }
     if (!b.p) return hipFree(ptr);  // not ours: straight back
-    hipError_t e = hipDeviceSynchronize();  // what hipFree would have done: no user of the block is still running
+    // what hipFree would have done: no user of the block is still running -- on the block's OWN device, whatever
+    // device the caller has selected
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != b.device) (void)hipSetDevice(b.device);
+    hipError_t e = hipDeviceSynchronize();
+    if (cur >= 0 && cur != b.device) (void)hipSetDevice(cur);
     std::lock_guard<std::mutex> lock(c.mu);
     if (e == hipSuccess && c.cached_bytes + b.bytes <= c.limit) {
         c.free_blocks.push_back(b);
         c.cached_bytes += b.bytes;
         return hipSuccess;
     }
-    return hipFree(ptr);
+    if (cur != b.device) (void)hipSetDevice(b.device);
+    e = hipFree(ptr);
+    if (cur >= 0 && cur != b.device) (void)hipSetDevice(cur);
+    return e;
 }
 
 void dev_cache_trim() {
@@ -1381,6 +1392,12 @@ static int csr_download(spal_csr_t a, uint64_t *rowptr, uint64_t *colind, T *val
 // Times the applicable variants of the planned kernel on the caller's vectors
 // and keeps the fastest (all variants compute identical results).  Setup-time
 // work: it synchronises `stream`.
+//  1. form: one super-tile per workgroup, or the walking form -- the sliding-window kernel when the plan has
+//     it (bands), else the persistent form -- each with plain or non-temporal y stores;
+//  2. placement: the same kernel reading the same bytes ran in two classes 5 ... 14 % apart depending on
+//     WHICH allocation the values array (three quarters of the traffic) lives in -- not on its address
+//     bits, its offset, the other arrays or the XCD run length (profiles/r02/placement_*.txt).  Up to
+//     `place_tries` fresh allocations are tried for it and the fastest is kept.
 template <typename T>
 static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, int iters) {
     if (!a) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_autotune: handle is NULL");
@@ -1394,39 +1411,76 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
     std::lock_guard<std::mutex> lock(a->mu);
     CsrPlan &p = a->plan;
     for (float &t : a->tuned_us) t = 0.f;
+    a->place_us[0] = a->place_us[1] = 0.f;
+    a->place_tried = 0;
     if (a->nnz == 0 || p.kernel != 2 || p.tiles_per_wave != 4) return SPAL_OK;  // nothing to choose from
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
     SPAL_HIP_TRY(hipEventCreate(&e0));
     SPAL_HIP_TRY(hipEventCreate(&e1));
-    int best = (p.persistent ? 1 : 0) | (p.nt_store ? 2 : 0);
-    float best_ms = 1e30f;
     int rc = SPAL_OK;
-    // candidate c: bit 0 = persistent form, bit 1 = non-temporal y stores
+    auto timed = [&](int n, float *ms_per_launch) {   // n launches of the current configuration
+        for (int i = 0; i < 3 && rc == SPAL_OK; ++i) rc = csr_launch(a, x_dev, y_dev, st);
+        if (rc != SPAL_OK) return;
+        hipError_t e = hipEventRecord(e0, st);
+        for (int i = 0; i < n && rc == SPAL_OK; ++i) rc = csr_launch(a, x_dev, y_dev, st);
+        if (e == hipSuccess) e = hipEventRecord(e1, st);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) rc = fail(SPAL_ERR_HIP, "spal_csr_autotune: %s", hipGetErrorString(e));
+        *ms_per_launch = ms / (float)n;
+    };
+    // ---- 1. the form.  candidate c: bit 0 = walking form (sliding kernel / persistent), bit 1 = non-temporal y stores
+    const bool walking_is_slide = p.slide != 0;
+    int best = ((walking_is_slide ? p.slide_on : p.persistent) ? 1 : 0) | (p.nt_store ? 2 : 0);
+    float best_ms = 1e30f;
     for (int round = 0; round < 2 && rc == SPAL_OK; ++round) {      // round 0 also settles the clocks
         for (int cand = 0; cand < 4 && rc == SPAL_OK; ++cand) {
-            p.persistent = cand & 1;
+            if (walking_is_slide) { p.slide_on = cand & 1; p.persistent = 0; }
+            else p.persistent = cand & 1;
             p.nt_store = (cand >> 1) & 1;
-            for (int i = 0; i < 3 && rc == SPAL_OK; ++i) rc = csr_launch(a, x_dev, y_dev, st);
-            if (rc != SPAL_OK) break;
-            hipError_t e = hipEventRecord(e0, st);
-            for (int i = 0; i < iters && rc == SPAL_OK; ++i) rc = csr_launch(a, x_dev, y_dev, st);
-            if (e == hipSuccess) e = hipEventRecord(e1, st);
-            if (e == hipSuccess) e = hipEventSynchronize(e1);
             float ms = 0.f;
-            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-            if (e != hipSuccess) { rc = fail(SPAL_ERR_HIP, "spal_csr_autotune: %s", hipGetErrorString(e)); break; }
-            if (round == 1) {
-                a->tuned_us[cand] = ms * 1e3f / (float)iters;
+            timed(iters, &ms);
+            if (rc == SPAL_OK && round == 1) {
+                a->tuned_us[cand] = ms * 1e3f;
                 if (ms < best_ms) { best_ms = ms; best = cand; }
             }
         }
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    p.persistent = best & 1;
+    if (walking_is_slide) { p.slide_on = best & 1; p.persistent = 0; }
+    else p.persistent = best & 1;
     p.user_persistent = true;   // measured: a later re-plan keeps it
     p.nt_store = (best >> 1) & 1;
+    // ---- 2. the placement of the values array
+    const size_t vbytes = (size_t)a->cap_entries * (size_t)a->elem_size;
+    int tries = p.place_tries;
+    if (const char *e = getenv("SPAL_PLACE_TRIES")) tries = atoi(e);
+    if (rc == SPAL_OK && tries > 0 && vbytes >= ((size_t)64 << 20)) {
+        std::vector<void *> rejects;
+        float cur_ms = 0.f;
+        timed(iters, &cur_ms);
+        a->place_us[0] = cur_ms * 1e3f;
+        for (int k = 0; k < tries && rc == SPAL_OK; ++k) {
+            void *cand = nullptr;
+            if (dev_alloc(&cand, vbytes) != hipSuccess) { (void)hipGetLastError(); break; }   // out of memory: keep what we have
+            hipError_t e = hipMemcpyAsync(cand, a->d_values, vbytes, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) { rejects.push_back(cand); rc = fail(SPAL_ERR_HIP, "spal_csr_autotune: %s", hipGetErrorString(e)); break; }
+            void *old = a->d_values;
+            a->d_values = cand;
+            float ms = 0.f;
+            timed(iters, &ms);
+            ++a->place_tried;
+            if (rc == SPAL_OK && ms < 0.99f * cur_ms) { cur_ms = ms; rejects.push_back(old); }
+            else { a->d_values = old; rejects.push_back(cand); }
+        }
+        a->place_us[1] = cur_ms * 1e3f;
+        // the rejected blocks are released only now, so that no try was handed one of them again
+        (void)hipStreamSynchronize(st);
+        for (void *r : rejects) (void)dev_free(r);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return rc;
 }
 
@@ -1579,9 +1633,17 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         // "slide_on" 0 keeps the ring plan but launches the one-super-tile-per-workgroup kernels on it (A/B)
         if (value < -1 || value > 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "slide must be -1 (auto), 0 or 1");
         p.slide_user = (int)value;
+    } else if (!strcmp(key, "slide_run")) {
+        // sliding kernel: steps (of 4 tiles) per run; runs are dealt round-robin to an XCD's workgroups (0 = one run each)
+        if (value < 0 || value > 65535) return fail(SPAL_ERR_INVALID_ARGUMENT, "slide_run must be in [0, 65535]");
+        p.slide_run = (int)value;
     } else if (!strcmp(key, "slide_on")) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "slide_on must be 0 or 1");
         p.slide_on = (int)value;
+    } else if (!strcmp(key, "place_tries")) {
+        // autotune: fresh allocations tried for the values array (0 = leave it where it is)
+        if (value < 0 || value > 16) return fail(SPAL_ERR_INVALID_ARGUMENT, "place_tries must be in [0, 16]");
+        p.place_tries = (int)value;
     } else if (!strcmp(key, "uniform_rows")) {
         // stream kernel: super-tiles whose rows all have one length do not read rowptr (default 1)
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "uniform_rows must be 0 or 1");
@@ -1626,7 +1688,7 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "\"rows_per_block\": %d, \"rows_per_tile\": %d, \"blocks\": %u, \"threads_per_block\": %d, \"lds_x\": %d, "
              "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f, "
              "\"overflow_tiles\": %u, \"skew\": %d, \"persistent\": %d, \"nt_store\": %d, \"uniform_row_fraction\": %.4f, "
-             "\"prefetch\": %d, \"slide\": %d, \"ring_pages\": %d, \"tile_steps\": %d, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f], \"addr\": [\"%llx\", \"%llx\", \"%llx\"]}",
+             "\"prefetch\": %d, \"slide\": %d, \"ring_pages\": %d, \"tile_steps\": %d, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f], \"placement_us\": [%.1f, %.1f], \"placement_tries\": %d, \"addr\": [\"%llx\", \"%llx\", \"%llx\"]}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, (p.kernel == 2 || p.vec_col16) ? 16 : 32,
              p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
@@ -1638,7 +1700,8 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              p.kernel == 2 ? p.prefetch : 0, (p.kernel == 2 && p.slide && p.slide_on) ? 1 : 0,
              p.kernel == 2 ? p.ring_pages : 0, (p.kernel == 2 && p.slide) ? p.slide_S : 0,
              (double)a->tuned_us[0], (double)a->tuned_us[1],
-             (double)a->tuned_us[2], (double)a->tuned_us[3], (unsigned long long)(uintptr_t)a->d_values,
+             (double)a->tuned_us[2], (double)a->tuned_us[3], (double)a->place_us[0], (double)a->place_us[1],
+             a->place_tried, (unsigned long long)(uintptr_t)a->d_values,
              (unsigned long long)(uintptr_t)a->d_col16, (unsigned long long)(uintptr_t)a->d_rowptr);
     return SPAL_OK;
 }
@@ -1671,6 +1734,10 @@ int spal_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t byte
     DeviceGuard guard(device);
     if (guard.status != SPAL_OK) return guard.status;
     if (bytes) SPAL_HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return SPAL_OK;
+}
+int spal_cache_trim(void) {
+    dev_cache_trim();
     return SPAL_OK;
 }
 int spal_device_synchronize(int device) {

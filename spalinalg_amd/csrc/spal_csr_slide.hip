@@ -16,8 +16,10 @@ static hipError_t launch_slide_inst(const spal_csr *a, const void *x, void *y, h
     const uint32_t grid = p.persistent_blocks > 0 ? (uint32_t)p.persistent_blocks : 256u * (uint32_t)per_cu;
     const uint32_t per_xcd = (p.slide_steps + 7u) / 8u;
     const uint32_t slots = std::max(1u, grid / 8u);
-    const uint32_t chunk = (per_xcd + slots - 1u) / slots;
-    const uint32_t used = (per_xcd + chunk - 1u) / chunk;
+    // steps per run: one run per workgroup, or what the plan says ("slide_run": shorter runs dealt round-robin)
+    const uint32_t one_run = (per_xcd + slots - 1u) / slots;
+    const uint32_t chunk = p.slide_run > 0 ? std::min<uint32_t>((uint32_t)p.slide_run, one_run) : one_run;
+    const uint32_t used = std::min(slots, (per_xcd + chunk - 1u) / chunk);
     auto kern = csr_spmv_slide<T, RPT, S, UNI, PF>;
     static std::atomic<uint64_t> configured{0};
     const uint64_t bit = 1ull << (a->device & 63);
@@ -29,7 +31,7 @@ static hipError_t launch_slide_inst(const spal_csr *a, const void *x, void *y, h
     hipLaunchKernelGGL(kern, dim3(used * 8u), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_col16,
                        (const T *)a->d_values, (const T *)x, (T *)y, a->d_sdesc, (uint32_t)a->nrows, (uint32_t)a->ncols,
                        p.slide_steps, per_xcd, chunk, (uint32_t)p.ring_pages, (uint32_t)p.slide_uniform,
-                       (uint32_t)(p.nt_store ? 1 : 0));
+                       (uint32_t)(p.nt_store ? 1 : 0) | (uint32_t)p.diag);
     return hipGetLastError();
 }
 

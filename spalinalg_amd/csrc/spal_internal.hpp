@@ -111,8 +111,10 @@ struct CsrPlan {
     int slide = 0;           // the plan is eligible and built for it
     int ring_pages = 0;      // the LDS x window is a ring of this many pages (col16 = (page % ring) * 256 + column in page)
     uint32_t slide_steps = 0;  // steps of 4 * rows_per_tile rows
+    int slide_run = 0;       // steps per run (0 = one run per workgroup: fully persistent)
     int slide_S = 0;         // 128-entry steps of the largest streamed tile: every tile issues that many loads
     int slide_uniform = 0;   // 1 + the length of every row when all streamed rows have one length (rowptr is not read), else 0
+    int place_tries = 3;     // autotune: fresh allocations tried for the values array (see csr_autotune)
     int diag = 0;            // ablation builds (-DSPAL_DIAG) only: parts of the stream kernel switched off
     int persistent_blocks = 0;    // its grid; 0 = what the device holds at once (LDS per workgroup decides: f64 band 512)
     int rows_per_block = 0;  // R
@@ -156,6 +158,8 @@ struct spal_csr {
     uint64_t cap_entries = 0;      // allocated entries of d_colind / d_values (>= nnz + pad)
     // autotune: microseconds per launch of {plain, persistent} x {plain, non-temporal y stores}
     float tuned_us[4] = {0.f, 0.f, 0.f, 0.f};
+    float place_us[2] = {0.f, 0.f};   // autotune: per launch before / after re-placing the values array
+    int place_tried = 0;
     spal::CsrPlan plan;
     std::vector<uint2> win_base;   // host copy of the per-256-row column windows (planner cache)
     // host-convenience staging (spal_csr_spmv_*): guarded by mu

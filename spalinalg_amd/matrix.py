@@ -131,11 +131,21 @@ class _DeviceMatrix:
         if x.dtype != tdt or not x.is_cuda or not x.is_contiguous() or x.numel() != ncols:
             raise Panic(_ffi.SPAL_ERR_INVALID_ARGUMENT,
                         f"x must be a contiguous {tdt} device vector of length ncols = {ncols}")
+        if x.device.index != self.device:
+            raise Panic(_ffi.SPAL_ERR_INVALID_ARGUMENT,
+                        f"x lives on cuda:{x.device.index} but the matrix on cuda:{self.device}")
         if out is None:
             out = torch.empty(nrows, dtype=tdt, device=x.device)
         elif out.dtype != tdt or not out.is_cuda or not out.is_contiguous() or out.numel() != nrows:
             raise Panic(_ffi.SPAL_ERR_INVALID_ARGUMENT,
                         f"out must be a contiguous {tdt} device vector of length nrows = {nrows}")
+        elif out.device != x.device:
+            raise Panic(_ffi.SPAL_ERR_INVALID_ARGUMENT, "out and x live on different devices")
+        else:
+            # the kernels read x and write y through __restrict__ pointers: the two must not overlap
+            es = x.element_size()
+            if out.data_ptr() < x.data_ptr() + ncols * es and x.data_ptr() < out.data_ptr() + nrows * es:
+                raise Panic(_ffi.SPAL_ERR_INVALID_ARGUMENT, "out overlaps x (y = A*x is not computed in place)")
         self.spmv_dev(x.data_ptr(), out.data_ptr(), torch.cuda.current_stream(x.device))
         return out
 

@@ -755,3 +755,128 @@ def test_device_entry_point_is_graph_capturable(oracle):
     g.replay()
     torch.cuda.synchronize()
     assert np.array_equal(y1.cpu().numpy(), oracle.csr_spmv(rp, ci, va, 2.0 * xh))
+
+
+def test_tiles_per_wave_8_and_rows_per_tile(oracle):
+    """tiles_per_wave = 8 exists for 64-row tiles only: alone it gives correct (bit-identical) y, combined with
+    another tile height it is refused -- in either order -- instead of launching a plan built for other rows."""
+    n = 150_000
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, 31)
+    x = synth.vector(n)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    dev.set_option("kernel", 2)
+    dev.set_option("tiles_per_wave", 8)
+    assert dev.describe()["rows_per_block"] == 2048
+    assert np.array_equal(dev.spmv(x), y_ref)
+    dev.set_option("rows_per_tile", 64)
+    assert np.array_equal(dev.spmv(x), y_ref)
+    with pytest.raises(sp.Panic):
+        dev.set_option("rows_per_tile", 32)
+    assert np.array_equal(dev.spmv(x), y_ref)           # the refused option left the plan alone
+    dev.set_option("tiles_per_wave", 4)
+    dev.set_option("rows_per_tile", 32)
+    with pytest.raises(sp.Panic):
+        dev.set_option("tiles_per_wave", 8)
+    assert dev.describe()["rows_per_tile"] == 32 and np.array_equal(dev.spmv(x), y_ref)
+    for bad in (("prefetch", 3), ("slide", 2), ("place_tries", 99), ("uniform_rows", 2), ("diag", 256)):
+        with pytest.raises(sp.Panic):
+            dev.set_option(*bad)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("gen,rpt", [("banded14", 0), ("ragged", 0), ("banded30", 32), ("banded60", 16), ("banded100", 8),
+                                     ("banded5", 64), ("ragged", 24), ("ragged", 12)])
+def test_sliding_window_kernel_bit_identical(oracle, dtype, gen, rpt):
+    """csr_spmv_slide (bands: ring x window that slides from step to step, counted load waits) against the oracle,
+    bit for bit: uniform rows (rowptr not read) and ragged ones, every tile height, with the knobs that change how
+    it walks (runs dealt round-robin, grid size, non-temporal stores), and the same plan launched on the
+    one-super-tile-per-workgroup kernels (slide_on = 0: they read the ring-encoded columns too)."""
+    n = 180_000 + 333
+    if gen == "ragged":
+        rp, ci, va = synth.ragged_csr(n, n, 4096, 77, dtype=dtype)
+    else:
+        rp, ci, va = synth.banded_csr(n, n, int(gen[6:]), 4096, 77, dtype=dtype)
+    x = synth.vector(n, dtype=dtype)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    if rpt:
+        dev.set_option("rows_per_tile", rpt)
+    d = dev.describe()
+    assert d["kernel"] == "stream" and d["slide"] == 1 and d["ring_pages"] > 0 and d["stream_row_fraction"] > 0.95
+    assert (d["uniform_row_fraction"] == 1.0) == (gen != "ragged")
+    # (ragged rows at 64 per tile: the few tiles above 1024 entries go to the overflow kernel, whose rows are
+    #  tree-summed -- those rows to rounding, all others bit for bit)
+    exact = d["stream_row_fraction"] == 1.0
+    assert exact or (gen == "ragged" and rpt == 0 and d["overflow_tiles"] > 0)
+    bound = None if exact else oracle.csr_abs_bound(rp, ci, va, x)
+
+    def same(y):
+        if exact:
+            return np.array_equal(y, y_ref)
+        diff = y != y_ref
+        tol = 1e-10 if dtype == np.float64 else 1e-4
+        return diff.mean() < 0.05 and np.all(np.abs(y.astype(np.float64) - y_ref) <= tol * bound + 1e-300)
+
+    assert same(dev.spmv(x))
+    for opts in ({"slide_run": 3}, {"slide_run": 0, "persistent_blocks": 64}, {"persistent_blocks": 4096, "nt_store": 1},
+                 {"persistent_blocks": 0, "uniform_rows": 0}, {"uniform_rows": 1, "slide_on": 0}, {"slide_on": 1, "slide": 0},
+                 {"slide": -1, "prefetch": 2, "slide_on": 0}):
+        for k, v in opts.items():
+            dev.set_option(k, v)
+        assert same(dev.spmv(x)), opts
+
+
+def test_sliding_window_jumps_and_synchronous_page_loads(oracle):
+    """windows that do not slide smoothly: block-diagonal sections whose column ranges jump forwards and BACKWARDS
+    between steps (entering pages on both sides, disjoint windows, more pages than a thread can prefetch), a
+    matrix whose last page is cut by ncols (odd, so x ends inside a 16-byte vector), empty steps in between."""
+    rng = np.random.default_rng(5)
+    n, nc = 40_000, 50_001
+    rowptr, cols, = [0], []
+    starts = [0, 30_000, 2_000, 45_000, 44_000, 10_000, 49_000 - 2048, 0]
+    for r in range(n):
+        sec = (r // 2048) % len(starts)      # (sections of two super-tiles: a super-tile's pages stay one run)
+        if (r // 700) % 9 == 4:          # a stretch of empty rows
+            rowptr.append(rowptr[-1])
+            continue
+        base = min(starts[sec] + (r % 2048), nc - 2049)
+        k = int(rng.integers(1, 20))
+        c = np.sort(rng.choice(2049, size=k, replace=False)) + base
+        c = np.minimum(c, nc - 1)
+        c = np.unique(c)
+        cols.append(c)
+        rowptr.append(rowptr[-1] + c.size)
+    ci = np.concatenate(cols).astype(np.uint64)
+    rp = np.asarray(rowptr, dtype=np.uint64)
+    for dtype in (np.float64, np.float32):
+        va = rng.uniform(-1, 1, ci.size).astype(dtype)
+        x = rng.uniform(-1, 1, nc).astype(dtype)
+        y_ref = oracle.csr_spmv(rp, ci, va, x)
+        dev = sp.CsrMatrix(n, nc, rp, ci, va).device()
+        d = dev.describe()
+        assert d["slide"] == 1, d
+        assert np.array_equal(dev.spmv(x), y_ref)
+        dev.set_option("slide_run", 5)
+        assert np.array_equal(dev.spmv(x), y_ref)
+        dev.set_option("slide_on", 0)
+        assert np.array_equal(dev.spmv(x), y_ref)
+
+
+def test_sliding_window_unaligned_x_falls_back(oracle):
+    """the sliding kernel loads pages of x as 16-byte vectors: an x that is not 16-byte aligned is served by the
+    one-super-tile-per-workgroup kernel on the same (ring-encoded) plan -- same bits."""
+    torch = pytest.importorskip("torch")
+    n = 120_000
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, 3)
+    x = synth.vector(n)
+    dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    assert dev.describe()["slide"] == 1
+    big = torch.zeros(n + 8, dtype=torch.float64, device="cuda")
+    xs = big[1:n + 1]                       # 8 bytes off a 16-byte boundary
+    xs.copy_(torch.from_numpy(x))
+    assert xs.data_ptr() % 16 == 8
+    y = dev.spmv_torch(xs)
+    assert np.array_equal(y.cpu().numpy(), oracle.csr_spmv(rp, ci, va, x))
+    with pytest.raises(sp.Panic):           # y = A * x is not computed in place
+        dev.spmv_torch(xs, out=xs)

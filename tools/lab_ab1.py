@@ -38,11 +38,15 @@ def main():
     B = synth.spmv_bytes(nnz, n, n, n, np.dtype(dtype).itemsize)
     times = [[] for _ in variants]
     equal, plans = [None] * len(variants), [None] * len(variants)
+    defaults = {"slide": -1, "slide_on": 1, "uniform_rows": 1, "prefetch": 1, "persistent": 0, "nt_store": 0, "diag": 0,
+                "tiles_per_wave": 4, "rows_per_tile": 0, "persistent_blocks": 0, "slide_run": 0, "kernel": 0, "skew": -1, "window_pages": 0, "stream_global": 1}
+    named = {kv.split("=")[0] for v in variants for kv in v.split(",")}
     for r in range(rounds):
         for i, v in enumerate(variants):
-            for kv in v.split(","):
-                k, val = kv.split("=")
-                d.set_option(k, int(val))
+            opts = {k: defaults[k] for k in named if k in defaults}   # every option any variant names, back to its default
+            opts.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in v.split(",")})
+            for k, val in opts.items():
+                d.set_option(k, val)
             for _ in range(3):
                 d.spmv_torch(x, out=y)
             torch.cuda.synchronize()

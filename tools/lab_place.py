@@ -28,6 +28,12 @@ for i in range(nh):
 x = torch.from_numpy(synth.vector(n)).cuda()
 ys = [torch.empty_like(x) for _ in range(nh)]
 times = [[] for _ in range(nh)]
+if "tune" in sys.argv[1:]:
+    # what the setup-time autotune makes of each handle's placement
+    for i, d in enumerate(devs):
+        pl = d.autotune(x, ys[i], iters=20)
+        print(f"handle {i}: autotune_us {pl['autotune_us']} placement_us {pl['placement_us']} tries {pl['placement_tries']} "
+              f"slide {pl['slide']} nt {pl['nt_store']}", flush=True)
 if "pmc" in sys.argv[1:]:
     # counter passes (rocprofv3 --pmc): 6 launches per handle, handle after handle, so that the stream kernel's
     # dispatches group by handle in the CSV (tools/pmc_by_handle.py); first a timing of each for the record

@@ -8,6 +8,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -223,7 +224,47 @@ static int stride_main() {
     return 0;
 }
 
+// --quick <nrows> <per_row>: one JSON line for bench.py -- the rate at which the HBM delivers the stream kernel's
+// footprint for that shape (f64 values, 16-bit columns, x staged through LDS, y written; rows of per_row <= 14 * k
+// are approximated by the byte count: the kernel below is the 14-per-row one scaled to the same bytes), and the
+// plain 16-byte copy / read rates.
+static int quick_main(uint32_t nrows_req, uint32_t per_row) {
+    // same bytes as the request: the footprint kernel streams 14 entries per row
+    const uint64_t want_entries = (uint64_t)nrows_req * per_row;
+    const uint32_t nrows = (uint32_t)std::min<uint64_t>(want_entries / 14, 40'000'000ull);
+    const size_t nnz = (size_t)nrows * 14 + 4096;
+    double *vals, *x, *y;
+    uint16_t *col16;
+    uint32_t *rowptr;
+    CK(hipMalloc(&vals, nnz * 8)); CK(hipMalloc(&col16, nnz * 2)); CK(hipMalloc(&rowptr, ((size_t)nrows + 65) * 4));
+    CK(hipMalloc(&x, (size_t)nrows * 8 + 65536)); CK(hipMalloc(&y, (size_t)nrows * 8));
+    CK(hipMemset(vals, 1, nnz * 8)); CK(hipMemset(col16, 1, nnz * 2)); CK(hipMemset(rowptr, 0, ((size_t)nrows + 65) * 4));
+    CK(hipMemset(x, 0, (size_t)nrows * 8 + 65536));
+    const uint32_t nblocks = (nrows + 1023) / 1024, per_xcd = (nblocks + 7) / 8;
+    auto kern = footprint<2, true>;
+    CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    double best = 1e30;
+    for (int rep = 0; rep < 3; ++rep)
+        best = std::min(best, time_us([&] {
+            hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(256), 72 * 1024, 0, vals, col16, rowptr, x, y, nrows, nblocks, per_xcd);
+        }, 30));
+    const double bytes = (double)nrows * 14 * 10 + 4.0 * nrows + 8.0 * nrows + 8.0 * nrows;
+    const size_t n16 = nnz * 8 / 16;
+    double copy_us = 1e30, read_us = 1e30;
+    u32x4 *b;
+    uint32_t *flag;
+    CK(hipMalloc(&b, n16 * 16)); CK(hipMalloc(&flag, 4));
+    for (int rep = 0; rep < 2; ++rep) {
+        copy_us = std::min(copy_us, time_us([&] { hipLaunchKernelGGL(copy16, dim3(8192), dim3(256), 0, 0, (const u32x4 *)vals, b, n16); }, 10));
+        read_us = std::min(read_us, time_us([&] { hipLaunchKernelGGL(read16, dim3(8192), dim3(256), 0, 0, (const u32x4 *)vals, flag, n16); }, 10));
+    }
+    printf("{\"footprint_us\": %.2f, \"footprint_bytes\": %.0f, \"footprint_gbs\": %.1f, \"copy16_gbs\": %.1f, \"read16_gbs\": %.1f, "
+           "\"rows\": %u}\n", best, bytes, bytes / best / 1e3, 2.0 * n16 * 16 / copy_us / 1e3, 1.0 * n16 * 16 / read_us / 1e3, nrows);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 3 && std::string(argv[1]) == "--quick") return quick_main((uint32_t)atoll(argv[2]), (uint32_t)atoll(argv[3]));
     if (argc > 1 && std::string(argv[1]) == "--place") return place_main();
     if (argc > 1 && std::string(argv[1]) == "--stride") return stride_main();
     const uint32_t nrows = 10'000'000;
