@@ -422,16 +422,23 @@ def bench_mg(args):
         tm = mg.timing()
         halo = {"step_wall_ms_median": round(med, 4), "step_wall_ms_min": round(mn, 4), "exchange_event_ms": round(tm["halo"], 4),
                 "bytes_per_step": eb["halo"]}
-    # parity: GPU 0's gathered y against the CPU oracle (bit for bit on the stream path)
-    import oracle  # checker only
-    yh = oracle.csr_spmv(rp, ci, va, xh)
-    bits = np.uint64 if esz == 8 else np.uint32
-    exact = bool(np.array_equal(y.view(bits), yh.view(bits)))
-    if not exact:
-        bound = oracle.csr_abs_bound(rp, ci, va, xh)
-        tol = 1e-10 if esz == 8 else 1e-4
-        if not np.all(np.abs(y.astype(np.float64) - yh.astype(np.float64)) <= tol * bound + 1e-300):
-            sys.exit("--host mg: the gathered y differs from the CPU oracle")
+    # cpu_baseline leg: the oracle timed on one core, and GPU 0's gathered y compared with it (bit for bit on the stream path)
+    exact, cpu = None, None
+    if not args.no_cpu_baseline:
+        import oracle  # CPU baseline leg only
+        t0 = time.perf_counter()
+        yh = oracle.csr_spmv(rp, ci, va, xh)
+        el = time.perf_counter() - t0
+        bits = np.uint64 if esz == 8 else np.uint32
+        exact = bool(np.array_equal(y.view(bits), yh.view(bits)))
+        if not exact:
+            bound = oracle.csr_abs_bound(rp, ci, va, xh)
+            tol = 1e-10 if esz == 8 else 1e-4
+            if not np.all(np.abs(y.astype(np.float64) - yh.astype(np.float64)) <= tol * bound + 1e-300):
+                sys.exit("--host mg: the gathered y differs from the CPU oracle")
+        cpu = {"value": round(synth.spmv_flops(nnz) / el / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+               "sample": f"one full pass over the same matrix in {el:.2f} s, 1 thread, 64-bit indices",
+               "gpu_equals_cpu_bit_for_bit": exact}
     whole_bytes = synth.spmv_bytes(nnz, nrows, nrows, ncols, esz)
     kern_ms = compute["ms_per_step_back_to_back"]
     out = {
@@ -457,7 +464,7 @@ def bench_mg(args):
         "compute_only": compute, "comm_ms": comm, "halo": halo,
         "efficiency_inputs": {"total_ms": round(total_ms, 4), "K": args.steps,
                               "note": "total = x_distribution + K * compute + y_collection: recompute for any K"},
-        "gpu_equals_cpu_bit_for_bit": exact,
+        "cpu_baseline": cpu,
         "setup_s": {"generate": round(t_gen, 2), "validate_narrow_upload_plan": round(t_upload, 2)},
     }
     print(json.dumps(out))
