@@ -727,6 +727,51 @@ def main():
         dist.all_reduce(ag, op=dist.ReduceOp.MAX)
         allgather_ms = float(ag.item())
 
+    # ---- steady-state cost of every exchange step by itself (HIP events on the current stream, which each
+    # collective blocks until it is done; median over repetitions after warm-up; MAX over ranks), so that
+    # the end-to-end time can be recomputed for any K: total = x_distribution + K * compute + y_collection
+    comm_ms = None
+    if world > 1:
+        def ev_median(fn, reps=10):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                dist.barrier()
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record()
+                fn()
+                a1.record()
+                torch.cuda.synchronize()
+                ts.append(a0.elapsed_time(a1))
+            ts.sort()
+            t = torch.tensor([ts[len(ts) // 2]], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return round(float(t.item()), 4)
+
+        comm_ms = {}
+        if x_mode == "scatter_windows":
+            comm_ms["x_distribution"] = ev_median(lambda: op.distribute_x(x, ncols, x_needs))
+            comm_ms["x_broadcast_whole_vector"] = ev_median(lambda: op.broadcast_x(x))
+        else:
+            comm_ms["x_distribution"] = ev_median(lambda: op.broadcast_x(x))
+        op.local_only(x)
+        if y_mode == "gather_root":
+            comm_ms["y_collection"] = ev_median(lambda: op.gather_y_root(y))
+            comm_ms["y_allgather"] = ev_median(lambda: op.gather_y(y))
+        else:
+            comm_ms["y_collection"] = ev_median(lambda: op.gather_y(y))
+        if nrows == ncols:
+            if getattr(op, "halo_recv", None) is None:
+                op.plan_halo(int(ci.min()), int(ci.max()) + 1)     # collective: every rank is here
+            ybuf = torch.empty_like(x)
+            comm_ms["halo_step_incl_kernel"] = ev_median(lambda: op.spmv_halo(x, ybuf))
+            comm_ms["halo_bytes_received"] = int(op.halo_bytes)
+            del ybuf
+        comm_ms["note"] = ("steady state, per call, max over ranks; x_distribution and y_collection are what the "
+                           "timed region contains once each")
+
     # ---- the dominant kernel alone (HIP events on the launch stream = torch's current stream)
     k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     y_loc = op.y_local[: r1 - r0]
@@ -877,7 +922,8 @@ def main():
             "value": round(synth.spmv_flops(nnz) / (kern_ms_max * 1e-3) / 1e9, 3),
             "unit": "GFLOP/s",
         },
-        "x_bcast_ms": round(x_bcast_ms, 4),
+        "comm_ms": comm_ms,
+        "x_first_call_ms": round(x_bcast_ms, 4),   # (the first collective of the process: includes communicator warm-up)
         "allgather_every_step": None if allgather_ms is None else {
             "ms_per_step": round(allgather_ms, 6),
             "value": round(synth.spmv_flops(nnz) / (allgather_ms * 1e-3) / 1e9, 3), "unit": "GFLOP/s"},

@@ -190,3 +190,22 @@ def test_option_validation():
     assert lib.spal_csr_set_option(None, b"kernel", C.c_int64(1)) == _ffi.SPAL_ERR_INVALID_ARGUMENT
     assert lib.spal_csc_set_option(None, b"kernel", C.c_int64(1)) == _ffi.SPAL_ERR_INVALID_ARGUMENT
     assert lib.spal_csr_destroy(None) == 0 and lib.spal_csc_destroy(None) == 0 and lib.spal_coo_destroy(None) == 0
+
+
+def test_rust_ffi_declares_every_export():
+    """rust_shim/src/ffi.rs is generated from include/spal.h (tools/gen_rust_ffi.py): the committed file must be
+    what the generator makes of the current header, and must declare every exported function."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_rust_ffi.py"), "--check"]).returncode == 0, \
+        "rust_shim/src/ffi.rs is stale: run python tools/gen_rust_ffi.py"
+    text = open(os.path.join(root, "rust_shim", "src", "ffi.rs")).read()
+    from spalinalg_amd import _ffi
+    for name in _ffi.exported_names():
+        assert f"pub fn {name}(" in text, name
+    # every FFI function the hand-written Rust modules call is one the header declares
+    import re
+    for f in ("scalar.rs", "device.rs", "ops.rs", "multi.rs"):
+        for used in set(re.findall(r"ffi::(spal_[a-z0-9_]+)\(", open(os.path.join(root, "rust_shim", "src", f)).read())):
+            assert used in _ffi.exported_names(), (f, used)
