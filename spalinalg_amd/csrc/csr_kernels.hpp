@@ -772,6 +772,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     uint4 d = desc[b];  // block-uniform
     const uint32_t skip_bits = desc_skip_bits(d);
     d.z = desc_mode(d);
+    if ((d.w & 2u) && (flags & 2u)) return;   // a wide band's super-tile: csr_spmv_panel (csr_panel.hpp) takes it
     d.w &= 1u;
 
     if (d.z == kModeStream) {
@@ -888,6 +889,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
         uint4 d = desc[s];  // block-uniform
         const uint32_t skip_bits = desc_skip_bits(d);
         d.z = desc_mode(d);
+        const uint32_t dw_raw = d.w;
         d.w &= 1u;
         // the next super-tile's boundaries: asked for now, needed at this one's last tile
         const uint4 d_next = desc[min(s + 1, s_end - 1)];
@@ -942,6 +944,8 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream_persistent(
                 else tiles(std::true_type{});
             }
             cur_valid = fetched_next;
+        } else if (d.z == kModeStreamGlobal && (dw_raw & 2u) && (flags & 2u)) {
+            cur_valid = false;   // a wide band's super-tile: csr_spmv_panel takes it
         } else if (d.z == kModeStreamGlobal) {
             cur_valid = false;   // (no window involved: no barrier needed)
             stream_global_super_tile<T, TPW, RPT, SKEW>(rowptr, colind, vals, x, y, prod, row0, row1, ncols,

@@ -658,6 +658,12 @@ static hipError_t launch_vec_unroll(const spal_csr *a, const void *x, void *y, h
     }
 }
 
+// the panel kernel takes the flagged super-tiles (its page loads are 16-byte vectors of x); otherwise the
+// stream kernels gather x for them from global memory, as for any other super-tile wider than LDS
+static bool panel_runs(const spal_csr *a, const void *x) {
+    return a->plan.panel_on && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+}
+
 // stream kernel; its vector fallback for non-streamable super-tiles uses U = 2
 template <typename T, int TPW, int RPT, bool SKEW = false, int PF = 1>
 static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, hipStream_t st) {
@@ -674,7 +680,8 @@ static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, h
     hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
                        a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc, a->d_pages,
                        (uint32_t)a->nrows, (uint32_t)a->ncols, (uint32_t)a->nnz, p.nblocks, per_xcd,
-                       (uint32_t)(p.nt_store ? 1 : 0) | (uint32_t)p.diag, (uint32_t)p.ring_pages);
+                       (uint32_t)(p.nt_store ? 1 : 0) | ((a->n_ptiles && panel_runs(a, x)) ? 2u : 0u) | (uint32_t)p.diag,
+                       (uint32_t)p.ring_pages);
     return hipGetLastError();
 }
 
@@ -702,7 +709,7 @@ static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, voi
     hipLaunchKernelGGL(kern, dim3(used * 8), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
                        a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc, a->d_pages,
                        (uint32_t)a->nrows, (uint32_t)a->ncols, (uint32_t)a->nnz, p.nblocks, per_xcd, chunk,
-                       (uint32_t)(p.nt_store ? 1 : 0), (uint32_t)p.ring_pages);
+                       (uint32_t)(p.nt_store ? 1 : 0) | ((a->n_ptiles && panel_runs(a, x)) ? 2u : 0u), (uint32_t)p.ring_pages);
     return hipGetLastError();
 }
 
@@ -718,9 +725,11 @@ static hipError_t launch_overflow(const spal_csr *a, const void *x, void *y, hip
 template <typename T>
 static hipError_t launch_stream_main(const spal_csr *a, const void *x, void *y, hipStream_t st);
 
+
 template <typename T>
 static hipError_t launch_stream(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     hipError_t e = launch_stream_main<T>(a, x, y, st);
+    if (e == hipSuccess && a->n_ptiles && panel_runs(a, x)) e = launch_panel(a, x, y, st);
     if (e == hipSuccess && a->n_ovtiles) e = launch_overflow<T>(a, x, y, st);
     return e;
 }
@@ -830,7 +839,7 @@ static int block_windows(spal_csr *a, uint32_t R, std::vector<uint2> &win) {
 // that can be streamed and fills `desc`.
 static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4> &desc, uint32_t &cap,
                        double &frac, uint32_t **out_pages, uint32_t &n_over, std::vector<uint32_t> &skip,
-                       double &cost, bool decide_skew) {
+                       double &cost, bool decide_skew, std::vector<uint2> &panel_win) {
     *out_pages = nullptr;
     n_over = 0;
     const uint32_t nb = (uint32_t)((a->nrows + R - 1) / R);
@@ -905,6 +914,7 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
         if (cost_big < 0.97 * cost_small) use_cap = page_cap;
     }
     desc.assign(nb, make_uint4(0, 0, kModeVectorGlobal, 0));
+    panel_win.assign(nb, make_uint2(0u, 0u));
     uint64_t rows_stream = 0;
     cap = 0;
     for (uint32_t b = 0; b < nb; ++b) {
@@ -922,8 +932,16 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
             rows_stream += rows;
             continue;
         }
-        if (a->plan.stream_global) {   // columns too scattered for LDS: x through L2
+        if (a->plan.stream_global) {   // columns too scattered for LDS: x through L2 ...
             desc[b] = make_uint4(0, 0, kModeStreamGlobal, 0);
+            // ... unless the column SPAN is a few LDS windows wide (a wide band): then the super-tile is taken in
+            // column panels by csr_spmv_panel (csr_panel.hpp), desc.w bit 1
+            const uint32_t p_first = w.x >> kPageShift, p_span = ((w.y - 1u) >> kPageShift) - p_first + 1u;
+            if (a->plan.panel_pages > 0 && rpt <= 64u && a->plan.tiles_per_wave == 4 && !a->plan.skew &&
+                p_span <= (uint32_t)a->plan.panel_pages) {
+                desc[b].w |= 2u;
+                panel_win[b] = make_uint2(p_first, p_span);
+            }
             rows_stream += rows;
             continue;
         }
@@ -1014,6 +1032,7 @@ int csr_plan_build(spal_csr *a) {
         uint32_t *best_pages = nullptr;
         uint32_t n_over = 0, best_over = 0;
         std::vector<uint32_t> skip, best_skip;
+        std::vector<uint2> pwin, best_pwin;
         if (a->d_pages) { SPAL_HIP_TRY(dev_free(a->d_pages)); a->d_pages = nullptr; }
         if (a->d_ovtiles) { SPAL_HIP_TRY(dev_free(a->d_ovtiles)); a->d_ovtiles = nullptr; }
         a->n_ovtiles = 0;
@@ -1021,11 +1040,12 @@ int csr_plan_build(spal_csr *a) {
             const uint32_t R = (uint32_t)stream_rows(rpt > 128 ? 1 : rpt > 64 ? 2 : p.tiles_per_wave, rpt);   // (128 / 256-row tiles: two / one per wave, the same 1024 rows)
             uint32_t *pg = nullptr;
             double cost = 0.0;
-            int st = stream_plan(a, R, (uint32_t)rpt, desc, cap, frac, &pg, n_over, skip, cost, !p.user_skew && rpt == rpts[0]);
+            int st = stream_plan(a, R, (uint32_t)rpt, desc, cap, frac, &pg, n_over, skip, cost, !p.user_skew && rpt == rpts[0], pwin);
             if (st != SPAL_OK) { (void)dev_free(best_pages); return st; }
             if (best_cost < 0.0 || cost < 0.95 * best_cost) {  // a narrower tile must be estimated cheaper (see csr_stream_check)
                 best_cost = cost;
                 best_frac = frac; best_rpt = rpt; best_cap = cap; best_over = n_over; best_desc.swap(desc); best_skip.swap(skip);
+                best_pwin.swap(pwin);
                 (void)dev_free(best_pages);
                 best_pages = pg;
             } else {
@@ -1068,6 +1088,26 @@ int csr_plan_build(spal_csr *a) {
             SPAL_HIP_TRY(hipMemcpyAsync(a->d_desc, packed.data(), (size_t)p.nblocks * sizeof(uint4),
                                         hipMemcpyHostToDevice, a->stream));
             SPAL_HIP_TRY(hipStreamSynchronize(a->stream));   // `packed` goes out of scope
+            // wide bands: the super-tiles csr_spmv_panel takes in column panels
+            {
+                if (a->d_ptiles) { SPAL_HIP_TRY(dev_free(a->d_ptiles)); a->d_ptiles = nullptr; }
+                if (a->d_pwin) { SPAL_HIP_TRY(dev_free(a->d_pwin)); a->d_pwin = nullptr; }
+                std::vector<uint32_t> ids;
+                std::vector<uint2> wins;
+                for (uint32_t b = 0; b < p.nblocks; ++b)
+                    if (best_desc[b].z == kModeStreamGlobal && (best_desc[b].w & 2u)) { ids.push_back(b); wins.push_back(best_pwin[b]); }
+                a->n_ptiles = (uint32_t)ids.size();
+                if (a->n_ptiles) {
+                    SPAL_HIP_TRY(dev_alloc((void **)&a->d_ptiles, ids.size() * sizeof(uint32_t)));
+                    SPAL_HIP_TRY(dev_alloc((void **)&a->d_pwin, wins.size() * sizeof(uint2)));
+                    SPAL_HIP_TRY(hipMemcpyAsync(a->d_ptiles, ids.data(), ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, a->stream));
+                    SPAL_HIP_TRY(hipMemcpyAsync(a->d_pwin, wins.data(), wins.size() * sizeof(uint2), hipMemcpyHostToDevice, a->stream));
+                    SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
+                    // LDS: the panel window beside the strips (the one-super-tile kernels of this plan need none for these)
+                    const uint32_t pp = std::min<uint32_t>((uint32_t)(kStreamWindowBytes / (kPageCols * (uint32_t)a->elem_size)), 64u);
+                    p.panel_window_pages = (int)pp;
+                }
+            }
             // bands and the like: the sliding-window kernel (csr_slide.hpp) and its ring-addressed window
             SPAL_TRY(slide_plan(a, R, (uint32_t)best_rpt, best_desc, best_skip, best_cap / kPageCols));
             if (p.ring_pages) p.lds_entries = (uint32_t)p.ring_pages * kPageCols;
@@ -1216,6 +1256,8 @@ static void csr_free(spal_csr *a) {
     (void)dev_free(a->d_pages);
     (void)dev_free(a->d_ovtiles);
     (void)dev_free(a->d_sdesc);
+    (void)dev_free(a->d_ptiles);
+    (void)dev_free(a->d_pwin);
     (void)dev_free(a->d_x);
     (void)dev_free(a->d_y);
     stream_release(a->stream);
@@ -1633,6 +1675,14 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         // "slide_on" 0 keeps the ring plan but launches the one-super-tile-per-workgroup kernels on it (A/B)
         if (value < -1 || value > 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "slide must be -1 (auto), 0 or 1");
         p.slide_user = (int)value;
+    } else if (!strcmp(key, "panel_pages")) {
+        // super-tiles whose column span is at most this many 256-column pages (and wider than the LDS window) are
+        // taken in column panels by csr_spmv_panel; 0 = never (x through L2)
+        if (value < 0 || value > 4096) return fail(SPAL_ERR_INVALID_ARGUMENT, "panel_pages must be in [0, 4096]");
+        p.panel_pages = (int)value;
+    } else if (!strcmp(key, "panel_on")) {
+        if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "panel_on must be 0 or 1");
+        p.panel_on = (int)value;
     } else if (!strcmp(key, "slide_run")) {
         // sliding kernel: steps (of 4 tiles) per run; runs are dealt round-robin to an XCD's workgroups (0 = one run each)
         if (value < 0 || value > 65535) return fail(SPAL_ERR_INVALID_ARGUMENT, "slide_run must be in [0, 65535]");
@@ -1688,7 +1738,7 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "\"rows_per_block\": %d, \"rows_per_tile\": %d, \"blocks\": %u, \"threads_per_block\": %d, \"lds_x\": %d, "
              "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f, "
              "\"overflow_tiles\": %u, \"skew\": %d, \"persistent\": %d, \"nt_store\": %d, \"uniform_row_fraction\": %.4f, "
-             "\"prefetch\": %d, \"slide\": %d, \"ring_pages\": %d, \"tile_steps\": %d, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f], \"placement_us\": [%.1f, %.1f], \"placement_tries\": %d, \"addr\": [\"%llx\", \"%llx\", \"%llx\"]}",
+             "\"prefetch\": %d, \"slide\": %d, \"ring_pages\": %d, \"tile_steps\": %d, \"panel_tiles\": %u, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f], \"placement_us\": [%.1f, %.1f], \"placement_tries\": %d, \"addr\": [\"%llx\", \"%llx\", \"%llx\"]}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, (p.kernel == 2 || p.vec_col16) ? 16 : 32,
              p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
@@ -1699,6 +1749,7 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              (p.kernel == 2 && p.nt_store) ? 1 : 0, p.kernel == 2 ? p.uniform_row_fraction : 0.0,
              p.kernel == 2 ? p.prefetch : 0, (p.kernel == 2 && p.slide && p.slide_on) ? 1 : 0,
              p.kernel == 2 ? p.ring_pages : 0, (p.kernel == 2 && p.slide) ? p.slide_S : 0,
+             (p.kernel == 2 && p.panel_on) ? a->n_ptiles : 0u,
              (double)a->tuned_us[0], (double)a->tuned_us[1],
              (double)a->tuned_us[2], (double)a->tuned_us[3], (double)a->place_us[0], (double)a->place_us[1],
              a->place_tried, (unsigned long long)(uintptr_t)a->d_values,

@@ -1,5 +1,6 @@
 // spal_csr_slide.hip -- instantiations and launch of the sliding-window CSR kernel (csr_slide.hpp); a
 // translation unit of its own so that the build compiles it beside spal_csr.hip.
+#include "csr_panel.hpp"
 #include "csr_slide.hpp"
 #include "spal_internal.hpp"
 
@@ -69,6 +70,42 @@ static hipError_t launch_slide_rpt(const spal_csr *a, const void *x, void *y, hi
 
 hipError_t launch_slide(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     return a->elem_size == 8 ? launch_slide_rpt<double>(a, x, y, st) : launch_slide_rpt<float>(a, x, y, st);
+}
+
+template <typename T, int RPT>
+static hipError_t launch_panel_inst(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    const CsrPlan &p = a->plan;
+    const size_t lds = ((size_t)kStreamWaves * stream_strip<false>() + (size_t)p.panel_window_pages * kPageCols) * sizeof(T);
+    auto kern = csr_spmv_panel<T, RPT>;
+    static std::atomic<uint64_t> configured{0};
+    const uint64_t bit = 1ull << (a->device & 63);
+    if (lds > 48 * 1024 && !(configured.load(std::memory_order_relaxed) & bit)) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        configured.fetch_or(bit, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(kern, dim3(a->n_ptiles), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
+                       (const T *)a->d_values, (const T *)x, (T *)y, a->d_ptiles, a->d_pwin, a->d_desc, a->n_ptiles,
+                       (uint32_t)a->nrows, (uint32_t)a->ncols, (uint32_t)p.panel_window_pages,
+                       (uint32_t)(p.nt_store ? 1 : 0));
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_panel_rpt(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    switch (a->plan.rows_per_tile) {
+        case 64: return launch_panel_inst<T, 64>(a, x, y, st);
+        case 32: return launch_panel_inst<T, 32>(a, x, y, st);
+        case 24: return launch_panel_inst<T, 24>(a, x, y, st);
+        case 16: return launch_panel_inst<T, 16>(a, x, y, st);
+        case 12: return launch_panel_inst<T, 12>(a, x, y, st);
+        case 8: return launch_panel_inst<T, 8>(a, x, y, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_panel(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    return a->elem_size == 8 ? launch_panel_rpt<double>(a, x, y, st) : launch_panel_rpt<float>(a, x, y, st);
 }
 
 }  // namespace spal

@@ -111,6 +111,9 @@ struct CsrPlan {
     int slide = 0;           // the plan is eligible and built for it
     int ring_pages = 0;      // the LDS x window is a ring of this many pages (col16 = (page % ring) * 256 + column in page)
     uint32_t slide_steps = 0;  // steps of 4 * rows_per_tile rows
+    int panel_pages = 192;   // wide bands: super-tiles with a column span of at most this many pages go to csr_spmv_panel (0: never)
+    int panel_on = 1;        // launch it (0: those super-tiles gather x from global memory in the stream kernels)
+    int panel_window_pages = 0;  // pages of one panel (LDS)
     int slide_run = 0;       // steps per run (0 = one run per workgroup: fully persistent)
     int slide_S = 0;         // 128-entry steps of the largest streamed tile: every tile issues that many loads
     int slide_uniform = 0;   // 1 + the length of every row when all streamed rows have one length (rowptr is not read), else 0
@@ -152,6 +155,9 @@ struct spal_csr {
     uint32_t *d_ovtiles = nullptr; // [count][first rows of the n_ovtiles tiles the stream kernels skip (csr_spmv_overflow)]
     uint32_t n_ovtiles = 0;
     uint32_t *d_pages = nullptr;   // blocks * page budget: ascending page ids of super-tiles whose pages are not one run
+    uint32_t *d_ptiles = nullptr;  // panel kernel: the super-tiles it takes
+    uint2 *d_pwin = nullptr;       // ... and {first page, pages} of their column spans
+    uint32_t n_ptiles = 0;
     uint2 *d_sdesc = nullptr;      // sliding kernel: per step {first page, pages | skip << 8 | flags << 16}
     uint4 *d_desc = nullptr;       // per row block: Stream {first page / offset into d_pages, pages, mode, contiguous};
                                    // VectorLds {window base column, window length, mode, 0}
@@ -215,6 +221,8 @@ int csr_plan_build(spal_csr *a);
 int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream);
 // implemented in spal_csr_slide.hip: the sliding-window kernel for a plan with plan.slide set
 hipError_t launch_slide(const spal_csr *a, const void *x, void *y, hipStream_t st);
+// ... and the column-panel kernel over a->d_ptiles
+hipError_t launch_panel(const spal_csr *a, const void *x, void *y, hipStream_t st);
 // builds a handle around device arrays it takes ownership of (used by the COO
 // assembly, which produces CSR directly on the device)
 // (cap_entries = allocated entries of d_colind / d_values; re-allocated with

@@ -880,3 +880,41 @@ def test_sliding_window_unaligned_x_falls_back(oracle):
     assert np.array_equal(y.cpu().numpy(), oracle.csr_spmv(rp, ci, va, x))
     with pytest.raises(sp.Panic):           # y = A * x is not computed in place
         dev.spmv_torch(xs, out=xs)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("window,gen,rpt", [(16384, "banded14", 0), (40000, "banded14", 0), (16384, "ragged", 0),
+                                            (20000, "banded30", 32), (16384, "banded60", 16), (47000, "banded14", 0)])
+def test_wide_bands_in_column_panels_bit_identical(oracle, dtype, window, gen, rpt):
+    """a band wider than the LDS window: csr_spmv_panel keeps the entries in registers and walks the x window in
+    panels; every product is formed once and rows are summed left to right, so the result equals the oracle's
+    bit for bit -- as does the same plan with the panel kernel off (x gathered through L2)."""
+    n = 150_000 + 17
+    if gen == "ragged":
+        rp, ci, va = synth.ragged_csr(n, n, window, 5, dtype=dtype)
+    else:
+        rp, ci, va = synth.banded_csr(n, n, int(gen[6:]), window, 5, dtype=dtype)
+    x = synth.vector(n, dtype=dtype)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    if rpt:
+        dev.set_option("rows_per_tile", rpt)
+    d = dev.describe()
+    assert d["kernel"] == "stream" and d["slide"] == 0, d
+    if dtype == np.float64 or window >= 20000:
+        assert d["panel_tiles"] > 0, d           # (f32 at 16384 columns: 64 pages of f32 still fit LDS)
+    exact = d["overflow_tiles"] == 0
+
+    def same(y):
+        if exact:
+            return np.array_equal(y, y_ref)
+        bound = oracle.csr_abs_bound(rp, ci, va, x)
+        tol = 1e-10 if dtype == np.float64 else 1e-4
+        return (y != y_ref).mean() < 0.05 and np.all(np.abs(y.astype(np.float64) - y_ref) <= tol * bound + 1e-300)
+
+    assert same(dev.spmv(x))
+    for opts in ({"panel_on": 0}, {"panel_on": 1, "persistent": 1}, {"persistent": 0, "nt_store": 1}, {"panel_pages": 0}):
+        for k, v in opts.items():
+            dev.set_option(k, v)
+        assert same(dev.spmv(x)), opts
+    assert dev.describe()["panel_tiles"] == 0      # panel_pages = 0: no super-tile is flagged
