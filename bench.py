@@ -50,6 +50,8 @@ def parse():
                          "ragged (robustness row of SURVEY 8d: banded columns, row length 1 + next() % 27)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ceiling", action="store_true",
+                    help="skip the copy-ceiling child process (profiling runs: one process under the profiler)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--opt", action="append", default=[], help="kernel option key=value (tuning)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -932,7 +934,7 @@ def main():
 
     if world == 1:
         # the ceiling next to which `frac` is read: what this box's HBM delivers for the same footprint
-        ceil = copy_ceiling(nrows, max(1, nnz // nrows))
+        ceil = None if args.no_ceiling else copy_ceiling(nrows, max(1, nnz // nrows))
         if ceil:
             out["roofline"]["copy_ceiling_gbs"] = ceil["footprint_gbs"]
             out["roofline"]["moved_frac_of_ceiling"] = round(moved / ceil["footprint_gbs"], 4)

@@ -185,7 +185,9 @@ int spal_csc_download_f32(spal_csc_t a, uint64_t *colptr, uint64_t *rowind,
  * 1024-column block fits LDS, global atomics otherwise), 2 = transposed: the
  * matrix is converted to CSR on the device once and the CSR kernels run
  * (deterministic; bit-identical to the reference's k-ascending order), 0 = auto
- * (= 2).  "lds" 0/1, "lanes_per_col" tune kernel 1. */
+ * (= 2).  "lds" 0/1, "cols_per_block" (0 auto / 1024 / 2048 / 4096 columns per
+ * super-tile), "flush" (0 global atomics / 1 window stores + ordered reduce)
+ * tune kernel 1. */
 int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value);
 /* as spal_csr_autotune_* for the transposed route (kernel 2); no-op for kernel 1 */
 int spal_csc_autotune_f64(spal_csc_t a, const double *x_dev, double *y_dev,

@@ -335,10 +335,13 @@ static size_t sort_lds_bytes() {
 // Sorts by bits [lo_bit, lo_bit + nbits) of key, stably.  The first pass reads
 // (k_in, a_in, v_in) when given (the caller's arrays, left untouched), else
 // buffer set `cur`; `cur` is updated to the set that holds the result.
+// first_offs: the scanned per-tile digit counts of the FIRST pass over (k_in ...), when the caller has them
+// (the COO handle computes them for its uploaded triplets at upload time: coo_first_pass_offsets).
 template <typename T>
 static hipError_t radix_sort_bits(SortBuffers<T> &b, uint64_t len, uint32_t lo_bit, uint32_t nbits,
                                   int &cur, hipStream_t st, const uint32_t *k_in = nullptr,
-                                  const uint32_t *a_in = nullptr, const T *v_in = nullptr) {
+                                  const uint32_t *a_in = nullptr, const T *v_in = nullptr,
+                                  const uint32_t *first_offs = nullptr) {
     if (len == 0) return hipSuccess;
     const uint32_t nblk = (uint32_t)((len + kSortTile - 1) / kSortTile);
     const uint64_t ncounts = 256ull * nblk;
@@ -353,13 +356,18 @@ static hipError_t radix_sort_bits(SortBuffers<T> &b, uint64_t len, uint32_t lo_b
         const uint32_t *ai = k_in ? a_in : b.aux[cur];
         const T *vi = k_in ? v_in : b.val[cur];
         const int dst = k_in ? cur : (cur ^ 1);
-        hipLaunchKernelGGL(radix_hist, dim3(nblk), dim3(kHistThreads), 0, st, ki, len, shift, b.counts,
-                           nblk);
-        hipError_t e = exclusive_scan_u32(b.counts, b.counts, ncounts, b.sums, nullptr, st);
-        if (e != hipSuccess) return e;
+        const uint32_t *offs = b.counts;
+        if (k_in && first_offs && shift == lo_bit) {
+            offs = first_offs;   // counted and scanned when the triplets were uploaded
+        } else {
+            hipLaunchKernelGGL(radix_hist, dim3(nblk), dim3(kHistThreads), 0, st, ki, len, shift, b.counts,
+                               nblk);
+            hipError_t e = exclusive_scan_u32(b.counts, b.counts, ncounts, b.sums, nullptr, st);
+            if (e != hipSuccess) return e;
+        }
         const uint32_t per_xcd = (nblk + 7) / 8;
         hipLaunchKernelGGL(radix_scatter<T>, dim3(SPAL_SORT_XCD ? per_xcd * 8 : nblk), dim3(kSortThreads),
-                           lds, st, ki, ai, vi, b.key[dst], b.aux[dst], b.val[dst], len, shift, b.counts,
+                           lds, st, ki, ai, vi, b.key[dst], b.aux[dst], b.val[dst], len, shift, offs,
                            nblk, per_xcd);
         cur = dst;
         k_in = nullptr;
@@ -811,6 +819,41 @@ struct Assembled {
     std::vector<uint2> win256;
 };
 
+// rows of a group the local sort finishes in LDS: about a thousand entries on average
+static uint32_t coo_group_bits(uint64_t len, uint64_t n_major) {
+    const double mean = (double)len / (double)n_major;
+    const uint32_t rbits = bits_for(n_major);
+    uint32_t gbits = 8;
+    while (gbits > 0 && mean * (double)(1u << gbits) > 1400.0) --gbits;
+    if (gbits >= rbits) gbits = rbits - 1;  // at least one pass: it also brings the triplets into the workspace
+    return gbits;
+}
+
+// The first radix pass of an assembly reads the uploaded triplets as they are, so its per-tile digit counts are
+// a function of the handle alone: counted and scanned once, when the triplets arrive (for rows and for columns:
+// CSR and CSC assemblies), instead of in every assembly.
+static hipError_t coo_first_pass_offsets(spal_coo *c, bool by_cols, hipStream_t st) {
+    const uint64_t len = c->len, n_major = by_cols ? c->ncols : c->nrows;
+    if (len == 0) return hipSuccess;
+    const uint32_t shift = coo_group_bits(len, n_major);
+    const uint32_t nblk = (uint32_t)((len + kSortTile - 1) / kSortTile);
+    const uint64_t ncounts = 256ull * nblk;
+    uint32_t *d = nullptr, *sums = nullptr;
+    hipError_t e = dev_alloc((void **)&d, ncounts * 4);
+    if (e == hipSuccess) e = dev_alloc((void **)&sums, ((ncounts + kScanTile - 1) / kScanTile + 1) * 4);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(radix_hist, dim3(nblk), dim3(kHistThreads), 0, st, by_cols ? c->d_cols : c->d_rows, len,
+                           shift, d, nblk);
+        e = exclusive_scan_u32(d, d, ncounts, sums, nullptr, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)dev_free(sums);
+    if (e != hipSuccess) { (void)dev_free(d); return e; }
+    c->d_first_offs[by_cols ? 1 : 0] = d;
+    c->first_shift[by_cols ? 1 : 0] = (int)shift;
+    return hipSuccess;
+}
+
 template <typename T>
 static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &res) {
     const uint64_t len = c->len;
@@ -855,12 +898,12 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
     // first pass reads the uploaded triplets directly (they stay untouched).  Groups
     // of 2^gbits rows (about a thousand entries on average) are finished in LDS.
     const double mean = (double)len / (double)nrows;
-    uint32_t gbits = 8;
-    while (gbits > 0 && mean * (double)(1u << gbits) > 1400.0) --gbits;
-    if (gbits >= rbits) gbits = rbits - 1;  // at least one pass: it also brings the triplets into the workspace
+    const uint32_t gbits = coo_group_bits(len, n_major);
     int cur = 0;
+    const int o = by_cols ? 1 : 0;
     SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, gbits, rbits - gbits, cur, st, d_major, d_minor,
-                                    (const T *)c->d_vals));
+                                    (const T *)c->d_vals,
+                                    (c->d_first_offs[o] && c->first_shift[o] == (int)gbits) ? c->d_first_offs[o] : nullptr));
     // ---- 2. group offsets; the fullest group
     const uint32_t ngroups = (uint32_t)(((uint64_t)nrows + (1u << gbits) - 1) >> gbits);
     launch_row_starts(sb.key[cur], (uint32_t)len, ngroups, start.as<uint32_t>(), st, gbits);
@@ -1050,6 +1093,8 @@ int transpose_device(int device, int elem_size, uint64_t nmajor, uint64_t nminor
 static void coo_free(spal_coo *c) {
     if (!c) return;
     (void)dev_free(c->d_work);
+    (void)dev_free(c->d_first_offs[0]);
+    (void)dev_free(c->d_first_offs[1]);
     (void)dev_free(c->d_rows);
     (void)dev_free(c->d_cols);
     (void)dev_free(c->d_vals);
@@ -1096,6 +1141,9 @@ static int coo_upload(int device, uint64_t nrows, uint64_t ncols, uint64_t len, 
         c->work_bytes = coo_workspace_layout(len, nrows, sizeof(T)).bytes;
         e = dev_alloc((void **)&c->d_work, c->work_bytes);
     }
+    // ... and the first radix pass's tile offsets, for both orientations (see coo_first_pass_offsets)
+    if (e == hipSuccess && len) e = coo_first_pass_offsets(c, false, nullptr);
+    if (e == hipSuccess && len) e = coo_first_pass_offsets(c, true, nullptr);
     if (e != hipSuccess) {
         coo_free(c);
         return fail(e == hipErrorOutOfMemory ? SPAL_ERR_OUT_OF_MEMORY : SPAL_ERR_HIP,

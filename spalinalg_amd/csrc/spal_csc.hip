@@ -26,15 +26,21 @@ namespace spal {
 #ifndef SPAL_CSC_BLOCK
 #define SPAL_CSC_BLOCK 1024
 #endif
-#ifndef SPAL_CSC_COLS
-#define SPAL_CSC_COLS 1024
-#endif
+
 constexpr int kCscBlock = SPAL_CSC_BLOCK;      // threads of the scatter kernel
-constexpr int kCscCols = SPAL_CSC_COLS;        // columns per super-tile
+// Columns per super-tile: the widest of 4096 / 2048 / 1024 whose row windows fit LDS (csc_plan_build).  Wider
+// super-tiles flush fewer window rows per column -- the contiguous global atomics of the flush are what bounds
+// config 4: 1024 columns 39.7 MB of atomics 53.5 us, 2048 23.8 MB 44.6 us, 4096 15.9 MB 42.7 us
+// (profiles/r02/csc_scatter_column_tiles.txt) -- and 245 workgroups are one round of the device.
+constexpr int kCscColsMax = 4096;   // (the x tile of the widest form: 32 KiB of f64)
+static_assert(kCscColsMax % kCscBlock == 0, "whole x elements per thread");
 // LDS y window budget (+ 8 KiB x tile): two 1024-thread workgroups per CU either way; a band's
 // clamped edge needs more rows than its interior (config 4: 6717 against 5120), and ONE super-tile
 // left to the global-atomic path kept the whole launch busy (47 us -> 78 us)
-constexpr uint32_t kCscWindowBytes = 70 * 1024;
+// (x tile + window <= 80 KiB: 70 KiB of window beside 1024 columns of f64 x, 64 KiB beside 2048)
+// LDS of a workgroup: x tile + y window.  1024 / 2048 columns: 80 KiB in all, two workgroups per CU; 4096 columns:
+// 32 KiB of x + 94 KiB of window, one.
+constexpr uint32_t csc_window_bytes(int cols) { return (cols >= 4096 ? 94u : cols >= 2048 ? 64u : 70u) * 1024u; }
 constexpr uint32_t kCscModeGlobal = 0, kCscModeLds = 1;
 
 // ---- plan-time kernels ---------------------------------------------------------
@@ -42,11 +48,11 @@ constexpr uint32_t kCscModeGlobal = 0, kCscModeLds = 1;
 // and last entry of a column bound its rows)
 __global__ __launch_bounds__(256) void csc_block_windows(const uint32_t *__restrict__ colptr,
                                                          const uint32_t *__restrict__ rowind,
-                                                         uint32_t ncols, uint2 *__restrict__ out) {
+                                                         uint32_t ncols, uint32_t cols, uint2 *__restrict__ out) {
     __shared__ uint32_t s_min, s_max;
     if (threadIdx.x == 0) { s_min = 0xffffffffu; s_max = 0u; }
     __syncthreads();
-    const uint32_t k0 = blockIdx.x * kCscCols, k1 = min(k0 + (uint32_t)kCscCols, ncols);
+    const uint32_t k0 = blockIdx.x * cols, k1 = min(k0 + cols, ncols);
     uint32_t lo = 0xffffffffu, hi = 0u;
     for (uint32_t k = k0 + threadIdx.x; k < k1; k += 256) {
         const uint32_t a0 = colptr[k], a1 = colptr[k + 1];
@@ -65,10 +71,10 @@ __global__ __launch_bounds__(256) void csc_block_windows(const uint32_t *__restr
 __global__ __launch_bounds__(256) void csc_encode_meta(const uint32_t *__restrict__ colptr,
                                                        const uint32_t *__restrict__ rowind,
                                                        const uint4 *__restrict__ desc,
-                                                       uint32_t *__restrict__ meta, uint32_t ncols) {
+                                                       uint32_t *__restrict__ meta, uint32_t ncols, uint32_t cols) {
     const uint4 d = desc[blockIdx.x];
     if (d.z != kCscModeLds) return;
-    const uint32_t k0 = blockIdx.x * kCscCols, k1 = min(k0 + (uint32_t)kCscCols, ncols);
+    const uint32_t k0 = blockIdx.x * cols, k1 = min(k0 + cols, ncols);
     for (uint32_t k = k0 + threadIdx.x; k < k1; k += 256)
         for (uint32_t p = colptr[k]; p < colptr[k + 1]; ++p)
             meta[p] = (rowind[p] - d.x) | ((k - k0) << 16);
@@ -82,7 +88,7 @@ __device__ __forceinline__ void lds_add(T *p, T v) {
 }
 
 // desc[b] = {window base row, window length, mode, 0}
-template <typename T, int L>
+template <typename T, int kCscCols>
 __global__ __launch_bounds__(kCscBlock, kCscBlock >= 1024 ? 1 : 2) void csc_spmv_scatter(
     const uint32_t *__restrict__ colptr, const uint32_t *__restrict__ rowind,
     const uint32_t *__restrict__ meta, const T *__restrict__ vals, const T *__restrict__ x,
@@ -107,7 +113,8 @@ __global__ __launch_bounds__(kCscBlock, kCscBlock >= 1024 ? 1 : 2) void csc_spmv
         // barrier: zeroing and staging hide behind those loads.
         constexpr uint32_t U = SPAL_CSC_U;
         constexpr uint32_t kBatch = 2 * U * kCscBlock;
-        static_assert(kCscCols <= kCscBlock, "one x element per thread");
+        static_assert(kCscCols % kCscBlock == 0 || kCscCols < kCscBlock, "whole x elements per thread");
+        constexpr uint32_t XPT = kCscCols > kCscBlock ? kCscCols / kCscBlock : 1;   // x elements per thread
         uint32_t batch0 = p0 & ~1u;   // uniform: first entry of the current batch
         pair_t v[U];
         u2_t m[U];
@@ -119,9 +126,13 @@ __global__ __launch_bounds__(kCscBlock, kCscBlock >= 1024 ? 1 : 2) void csc_spmv
             v[u] = __builtin_nontemporal_load(reinterpret_cast<const pair_t *>(vals + e));
             m[u] = __builtin_nontemporal_load(reinterpret_cast<const u2_t *>(meta + e));
         }
-        const T xk = x[min(k0 + threadIdx.x, k1 - 1u)];
+        T xk[XPT];
+#pragma unroll
+        for (uint32_t q = 0; q < XPT; ++q) xk[q] = x[min(k0 + threadIdx.x + q * kCscBlock, k1 - 1u)];
         for (uint32_t i = threadIdx.x; i < d.y; i += kCscBlock) yw[i] = T(0);
-        if (threadIdx.x < k1 - k0) xt[threadIdx.x] = xk;
+#pragma unroll
+        for (uint32_t q = 0; q < XPT; ++q)
+            if (threadIdx.x + q * kCscBlock < k1 - k0) xt[threadIdx.x + q * kCscBlock] = xk[q];
         __syncthreads();
         while (true) {
 #pragma unroll
@@ -234,19 +245,19 @@ static int pick_lanes_csc(double mean) {
     return L;
 }
 
-template <typename T, int L>
-static hipError_t csc_launch_l(const spal_csc *a, const void *x, void *y, hipStream_t st) {
+template <typename T, int COLS>
+static hipError_t csc_launch_c(const spal_csc *a, const void *x, void *y, hipStream_t st) {
     const uint32_t per_xcd = (a->nblocks + 7) / 8;
     // x tile + the y window; global-mode super-tiles keep their column pointers where the window would be
-    const size_t lds = std::max(((size_t)kCscCols + a->lds_entries) * sizeof(T),
-                                (size_t)kCscCols * sizeof(T) + ((size_t)kCscCols + 2) * sizeof(uint32_t));
-    auto kern = csc_spmv_scatter<T, L>;
+    const size_t lds = std::max(((size_t)COLS + a->lds_entries) * sizeof(T),
+                                (size_t)COLS * sizeof(T) + ((size_t)COLS + 2) * sizeof(uint32_t));
+    auto kern = csc_spmv_scatter<T, COLS>;
     static std::atomic<uint64_t> configured{0};
     if (lds > 48 * 1024) {
         const uint64_t bit = 1ull << (a->device & 63);
         if (!(configured.load(std::memory_order_relaxed) & bit)) {
             hipError_t e = hipFuncSetAttribute((const void *)kern,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             configured.fetch_or(bit, std::memory_order_relaxed);
         }
@@ -266,13 +277,10 @@ static hipError_t csc_launch_t(const spal_csc *a, const void *x, void *y, hipStr
     hipError_t e = hipSuccess;
     if (!assign || a->nnz == 0) e = hipMemsetAsync(y, 0, a->nrows * sizeof(T), st);
     if (e != hipSuccess || a->nnz == 0) return e;
-    switch (a->lanes_per_col) {
-        case 2: e = csc_launch_l<T, 2>(a, x, y, st); break;
-        case 4: e = csc_launch_l<T, 4>(a, x, y, st); break;
-        case 8: e = csc_launch_l<T, 8>(a, x, y, st); break;
-        case 16: e = csc_launch_l<T, 16>(a, x, y, st); break;
-        case 32: e = csc_launch_l<T, 32>(a, x, y, st); break;
-        case 64: e = csc_launch_l<T, 64>(a, x, y, st); break;
+    switch (a->cols_per_block) {
+        case 1024: e = csc_launch_c<T, 1024>(a, x, y, st); break;
+        case 2048: e = csc_launch_c<T, 2048>(a, x, y, st); break;
+        case 4096: e = csc_launch_c<T, 4096>(a, x, y, st); break;
         default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess || !two_phase) return e;
@@ -302,7 +310,6 @@ static int csc_launch(spal_csc *a, const void *x, void *y, hipStream_t st) {
 
 // Per-super-tile windows and modes; packed metadata for the LDS mode.
 static int csc_plan_build(spal_csc *a) {
-    a->nblocks = (uint32_t)((a->ncols + kCscCols - 1) / kCscCols);
     if (a->d_desc) { SPAL_HIP_TRY(dev_free(a->d_desc)); a->d_desc = nullptr; }
     if (a->d_windows) { SPAL_HIP_TRY(dev_free(a->d_windows)); a->d_windows = nullptr; }
     if (a->d_chunk_ptr) { SPAL_HIP_TRY(dev_free(a->d_chunk_ptr)); a->d_chunk_ptr = nullptr; }
@@ -312,19 +319,51 @@ static int csc_plan_build(spal_csc *a) {
     a->nchunks = 0;
     a->lds_entries = 0;
     a->lds_col_fraction = 0.0;
+    a->cols_per_block = a->user_cols ? a->user_cols : 1024;
+    a->nblocks = (uint32_t)((a->ncols + a->cols_per_block - 1) / a->cols_per_block);
     std::vector<uint4> desc(a->nblocks, make_uint4(0, 0, kCscModeGlobal, 0));
     if (a->nnz && a->use_lds) {
+        // row windows per 1024 columns (one device pass); wider super-tiles are unions of those
+        const uint32_t nb1 = (uint32_t)((a->ncols + 1023) / 1024);
         uint2 *d_win = nullptr;
-        SPAL_HIP_TRY(dev_alloc((void **)&d_win, (size_t)a->nblocks * sizeof(uint2)));
-        hipLaunchKernelGGL(csc_block_windows, dim3(a->nblocks), dim3(256), 0, a->stream, a->d_colptr,
-                           a->d_rowind, (uint32_t)a->ncols, d_win);
-        std::vector<uint2> win(a->nblocks);
-        hipError_t e = hipMemcpyAsync(win.data(), d_win, (size_t)a->nblocks * sizeof(uint2),
+        SPAL_HIP_TRY(dev_alloc((void **)&d_win, (size_t)nb1 * sizeof(uint2)));
+        hipLaunchKernelGGL(csc_block_windows, dim3(nb1), dim3(256), 0, a->stream, a->d_colptr,
+                           a->d_rowind, (uint32_t)a->ncols, 1024u, d_win);
+        std::vector<uint2> win1(nb1);
+        hipError_t e = hipMemcpyAsync(win1.data(), d_win, (size_t)nb1 * sizeof(uint2),
                                       hipMemcpyDeviceToHost, a->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
         (void)dev_free(d_win);
         SPAL_HIP_TRY(e);
-        const uint32_t budget = std::min<uint32_t>(kCscWindowBytes / (uint32_t)a->elem_size, 65536u);
+        auto windows_for = [&](int cols, std::vector<uint2> &win, uint64_t &fit_cols) {
+            const uint32_t k = (uint32_t)cols / 1024u, nb = (uint32_t)((a->ncols + cols - 1) / cols);
+            const uint32_t budget = std::min<uint32_t>(csc_window_bytes(cols) / (uint32_t)a->elem_size, 65536u);
+            win.assign(nb, make_uint2(0xffffffffu, 0u));
+            fit_cols = 0;
+            for (uint32_t b = 0; b < nb; ++b) {
+                for (uint32_t j = b * k; j < std::min(nb1, (b + 1) * k); ++j)
+                    if (win1[j].y) { win[b].x = std::min(win[b].x, win1[j].x); win[b].y = std::max(win[b].y, win1[j].y); }
+                if (win[b].y == 0 || win[b].y - win[b].x <= budget)
+                    fit_cols += std::min<uint64_t>((uint64_t)cols, a->ncols - (uint64_t)b * cols);
+            }
+        };
+        // the widest super-tile whose windows fit as well as the 1024-column ones do
+        std::vector<uint2> win;
+        uint64_t fit = 0, fit1024 = 0;
+        windows_for(1024, win, fit1024);
+        if (!a->user_cols) {
+            for (int cols : {4096, 2048}) {
+                std::vector<uint2> w;
+                windows_for(cols, w, fit);
+                if (fit >= fit1024) { a->cols_per_block = cols; win.swap(w); break; }
+            }
+        } else {
+            windows_for(a->cols_per_block, win, fit);
+        }
+        a->nblocks = (uint32_t)((a->ncols + a->cols_per_block - 1) / a->cols_per_block);
+        desc.assign(a->nblocks, make_uint4(0, 0, kCscModeGlobal, 0));
+        const uint32_t kCscCols = (uint32_t)a->cols_per_block;
+        const uint32_t budget = std::min<uint32_t>(csc_window_bytes(a->cols_per_block) / (uint32_t)a->elem_size, 65536u);
         uint64_t cols_lds = 0, slot = 0;
         bool all_lds = true;
         a->nchunks = (uint32_t)((a->nrows + kCscChunk - 1) / kCscChunk);
@@ -375,7 +414,7 @@ static int csc_plan_build(spal_csc *a) {
             SPAL_HIP_TRY(hipMemsetAsync(a->d_meta, 0, (size_t)(a->nnz + kStreamPad) * sizeof(uint32_t), a->stream));
         }
         hipLaunchKernelGGL(csc_encode_meta, dim3(a->nblocks), dim3(256), 0, a->stream, a->d_colptr,
-                           a->d_rowind, a->d_desc, a->d_meta, (uint32_t)a->ncols);
+                           a->d_rowind, a->d_desc, a->d_meta, (uint32_t)a->ncols, (uint32_t)a->cols_per_block);
         SPAL_HIP_TRY(hipGetLastError());
     }
     SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
@@ -685,6 +724,13 @@ int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value) {
         a->flush = (int)value;
         return SPAL_OK;
     }
+    if (!strcmp(key, "cols_per_block")) {
+        // columns of a super-tile of the scatter kernel: 0 = the widest of 4096 / 2048 / 1024 whose row windows fit LDS
+        if (value != 0 && value != 1024 && value != 2048 && value != 4096)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "cols_per_block must be 0 (auto), 1024, 2048 or 4096");
+        a->user_cols = (int)value;
+        return csc_plan_build(a);
+    }
     if (!strcmp(key, "lds")) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "lds must be 0 or 1");
         a->use_lds = (int)value;
@@ -702,7 +748,7 @@ int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len) {
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz,
              a->kernel == 2 ? "transposed_csr" : a->lds_entries ? "lds_privatised_scatter" : "atomic_scatter",
-             kCscCols, a->nblocks,
+             a->cols_per_block, a->nblocks,
              a->lanes_per_col, (unsigned long long)a->lds_entries * (unsigned long long)a->elem_size,
              a->lds_col_fraction, (a->flush && a->d_windows) ? "windows_then_reduce" : "global_atomics",
              (unsigned long long)a->windows_entries * (unsigned long long)a->elem_size);

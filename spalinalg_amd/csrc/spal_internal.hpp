@@ -191,6 +191,8 @@ struct spal_csc {
     uint64_t windows_entries = 0;
     int flush = 0;                 // 0 = global atomics per window row (default: measured faster), 1 = windows + ordered reduce
     int all_lds = 0;               // every super-tile with entries is in LDS mode: y needs no memset
+    int cols_per_block = 1024;     // columns of a super-tile: 4096 / 2048 / 1024 (the widest whose row windows fit LDS)
+    int user_cols = 0;             // option "cols_per_block" (0 = automatic)
     uint32_t nblocks = 0;
     uint32_t lds_entries = 0;      // largest LDS y window (elements); 0 = global scatter only
     double lds_col_fraction = 0.0;
@@ -210,6 +212,9 @@ struct spal_coo {
     uint32_t *d_rows = nullptr, *d_cols = nullptr;
     void *d_vals = nullptr;
     void *d_work = nullptr;   // sort buffers + scratch of the assembly, allocated at upload
+    // scanned per-tile digit counts of the first radix pass over the uploaded triplets, by rows [0] / by columns [1]
+    uint32_t *d_first_offs[2] = {nullptr, nullptr};
+    int first_shift[2] = {-1, -1};
     size_t work_bytes = 0;
     std::mutex mu;            // serialises assemblies on one handle (shared workspace)
     int last_group_rows = 0, last_group_cap = 0;  // geometry of the last assembly's local sort (0 = general route)

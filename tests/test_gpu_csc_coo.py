@@ -136,6 +136,17 @@ def test_csc_lds_and_global_paths(oracle):
     for lanes in (2, 64):
         dev.set_option("lanes_per_col", lanes)
         assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10)
+    # every width of the scatter kernel's column super-tiles (wider ones leave more of them to the global path here)
+    for cols in (1024, 2048, 4096, 0):
+        dev.set_option("cols_per_block", cols)
+        d = dev.describe()
+        assert cols == 0 or d["cols_per_block"] == cols
+        assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10)
+        dev.set_option("flush", 1)
+        assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10)
+        dev.set_option("flush", 0)
+    with pytest.raises(sp.Panic):
+        dev.set_option("cols_per_block", 512)
 
 
 def test_csc_config4(oracle):
@@ -150,6 +161,7 @@ def test_csc_config4(oracle):
     y_ref = oracle.csc_spmv(n, cp, ri, cv, x)
     assert_spmv_close(y, y_ref, oracle.csr_abs_bound(rp, ci, va, x), 1e-10)
     assert m.device().describe()["lds_col_fraction"] > 0.99
+    assert m.device().describe()["cols_per_block"] == 4096      # the band's windows fit beside 4096 columns of x
     m.device().set_option("flush", 1)           # windows + ordered reduce (writes y without a memset here)
     assert_spmv_close(m * x, y_ref, oracle.csr_abs_bound(rp, ci, va, x), 1e-10)
     m.device().set_option("flush", 0)
