@@ -3,8 +3,8 @@
 // A band of 16 384 or 65 536 columns under 1024 rows spans 68 / 260 pages of x: more than the 24 (48 KB) a
 // workgroup stages beside its product strips.  csr_spmv_stream then gathers x from global memory / L2, 128-byte
 // lines for 8-byte reads: 31 % of the HBM roofline at W = 16 384.  Here the workgroup keeps the ENTRIES of its 16
-// tiles in registers (4 tiles per wave, loaded once, coalesced) and walks the window in panels of kPanelPages
-// pages: stage panel p in LDS, multiply every entry whose column lies in it (the product replaces the value in its
+// tiles in registers (4 tiles per wave, loaded once, coalesced) and walks the window in panels of 40 pages (80 KB:
+// the panel and the product strips, needed only after the last panel, share the workgroup's LDS): stage panel p in LDS, multiply every entry whose column lies in it (the product replaces the value in its
 // register), next panel.  Every entry belongs to exactly one panel, so after the last one all products exist; they
 // then go through the wave's LDS strip tile by tile and lane l sums row l left to right -- the reference's order
 // of additions (src/csr/ops/mul.rs:31-38) with each product rounded once, exactly as in csr_spmv_stream: rows
@@ -30,8 +30,9 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_panel(
     constexpr uint32_t V = 16 / sizeof(T), VP = kPageCols / V;
     constexpr uint32_t kRows = stream_rows(kPanelTiles, RPT);
     const bool nt_store = flags & 1u;
+    // the panel window and, after the last panel, the waves' product strips: the same LDS
     T *prod_all = reinterpret_cast<T *>(spal_smem);
-    T *xw = prod_all + kStreamWaves * stream_strip<false>();
+    T *xw = prod_all;
     vec_t *xw4 = reinterpret_cast<vec_t *>(xw);
     if (blockIdx.x >= npanel_tiles) return;
     const uint32_t b = ptiles[blockIdx.x];
@@ -54,7 +55,9 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_panel(
     for (int k = 0; k < kPanelTiles; ++k)
         stream_load_g<T, RPT>(t[k], rowptr, colind, vals, min(wrow + k * (uint32_t)RPT, row1), row1, tb[k], tb[k + 1], lane, ulen);
 
-    // the panels of the window, ascending
+    // the panels of the window, ascending.  (Staging panel p + 1 asynchronously -- LDS-DMA into a second buffer --
+    // was measured and lost: twice the panels at half the size, 553 vs 476 us at W = 16 384; the pass over the
+    // entries per panel, not the staging, is what a panel costs.  profiles/r02/wide_bands_column_panels.txt)
     for (uint32_t p0 = 0; p0 < win.y; p0 += panel_pages) {
         const uint32_t np = min(panel_pages, win.y - p0), f = win.x + p0;
         if (p0) __syncthreads();                          // every wave is done with the previous panel
@@ -87,6 +90,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_panel(
             }
         }
     }
+    __syncthreads();   // the last panel is done with: the product strips take its place in LDS
     // products -> strip -> left-to-right row sums, a tile at a time
 #pragma unroll
     for (int k = 0; k < kPanelTiles; ++k) {

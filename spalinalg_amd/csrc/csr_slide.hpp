@@ -135,10 +135,12 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_slide(
     // steps of this workgroup: full runs, except that the XCD's last run may be short and is then this one's last
     const uint32_t lastrun = slot + (myruns - 1u) * slots;
     const uint32_t nk = (myruns - 1u) * chunk + min(chunk, nx - lastrun * chunk);
-    // k-th step of this workgroup -> its global step index (k past the end: the last one again)
+    // k-th step of this workgroup -> its global step index.  k past the end: the matrix's first step -- its tile is
+    // what every workgroup's last PF load slots then read (the count of loads must not depend on the path), so it
+    // stays in L2; re-reading the workgroup's own last tile cost 37 MB of HBM reads per launch (streaming loads
+    // are not kept).
     auto gi = [&](uint32_t k) {
-        const uint32_t kc = min(k, nk - 1u);
-        return xbase + (slot + (kc / chunk) * slots) * chunk + kc % chunk;
+        return k < nk ? xbase + (slot + (k / chunk) * slots) * chunk + k % chunk : 0u;
     };
 
     const uint32_t lane = threadIdx.x & (kWave - 1);

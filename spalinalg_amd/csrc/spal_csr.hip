@@ -1104,7 +1104,11 @@ int csr_plan_build(spal_csr *a) {
                     SPAL_HIP_TRY(hipMemcpyAsync(a->d_pwin, wins.data(), wins.size() * sizeof(uint2), hipMemcpyHostToDevice, a->stream));
                     SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
                     // LDS: the panel window beside the strips (the one-super-tile kernels of this plan need none for these)
-                    const uint32_t pp = std::min<uint32_t>((uint32_t)(kStreamWindowBytes / (kPageCols * (uint32_t)a->elem_size)), 64u);
+                    // a panel: 80 KB of LDS (two workgroups per CU), shared with the product strips; option
+                    // "panel_window" sets it in pages (up to 156 KB: one workgroup per CU, fewer passes over the entries)
+                    const uint32_t page_b = kPageCols * (uint32_t)a->elem_size;
+                    uint32_t pp = (80u * 1024u) / page_b;
+                    if (p.panel_window_user > 0) pp = std::min<uint32_t>((uint32_t)p.panel_window_user, (156u * 1024u) / page_b);
                     p.panel_window_pages = (int)pp;
                 }
             }
@@ -1680,6 +1684,9 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         // taken in column panels by csr_spmv_panel; 0 = never (x through L2)
         if (value < 0 || value > 4096) return fail(SPAL_ERR_INVALID_ARGUMENT, "panel_pages must be in [0, 4096]");
         p.panel_pages = (int)value;
+    } else if (!strcmp(key, "panel_window")) {
+        if (value < 0 || value > 624) return fail(SPAL_ERR_INVALID_ARGUMENT, "panel_window must be in [0, 624] pages");
+        p.panel_window_user = (int)value;
     } else if (!strcmp(key, "panel_on")) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "panel_on must be 0 or 1");
         p.panel_on = (int)value;

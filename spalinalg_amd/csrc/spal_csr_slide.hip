@@ -75,7 +75,8 @@ hipError_t launch_slide(const spal_csr *a, const void *x, void *y, hipStream_t s
 template <typename T, int RPT>
 static hipError_t launch_panel_inst(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     const CsrPlan &p = a->plan;
-    const size_t lds = ((size_t)kStreamWaves * stream_strip<false>() + (size_t)p.panel_window_pages * kPageCols) * sizeof(T);
+    // the panel window; the strips reuse it after the last panel
+    const size_t lds = std::max((size_t)kStreamWaves * stream_strip<false>(), (size_t)p.panel_window_pages * kPageCols) * sizeof(T);
     auto kern = csr_spmv_panel<T, RPT>;
     static std::atomic<uint64_t> configured{0};
     const uint64_t bit = 1ull << (a->device & 63);

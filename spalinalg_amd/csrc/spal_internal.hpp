@@ -114,6 +114,7 @@ struct CsrPlan {
     int panel_pages = 192;   // wide bands: super-tiles with a column span of at most this many pages go to csr_spmv_panel (0: never)
     int panel_on = 1;        // launch it (0: those super-tiles gather x from global memory in the stream kernels)
     int panel_window_pages = 0;  // pages of one panel (LDS)
+    int panel_window_user = 0;   // option "panel_window" (0 = 80 KB)
     int slide_run = 0;       // steps per run (0 = one run per workgroup: fully persistent)
     int slide_S = 0;         // 128-entry steps of the largest streamed tile: every tile issues that many loads
     int slide_uniform = 0;   // 1 + the length of every row when all streamed rows have one length (rowptr is not read), else 0

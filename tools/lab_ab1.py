@@ -39,7 +39,7 @@ def main():
     times = [[] for _ in variants]
     equal, plans = [None] * len(variants), [None] * len(variants)
     defaults = {"slide": -1, "slide_on": 1, "uniform_rows": 1, "prefetch": 1, "persistent": 0, "nt_store": 0, "diag": 0,
-                "tiles_per_wave": 4, "rows_per_tile": 0, "persistent_blocks": 0, "slide_run": 0, "panel_on": 1, "panel_pages": 192, "kernel": 0, "skew": -1, "window_pages": 0, "stream_global": 1}
+                "tiles_per_wave": 4, "rows_per_tile": 0, "persistent_blocks": 0, "slide_run": 0, "panel_on": 1, "panel_pages": 192, "panel_window": 0, "kernel": 0, "skew": -1, "window_pages": 0, "stream_global": 1}
     named = {kv.split("=")[0] for v in variants for kv in v.split(",")}
     for r in range(rounds):
         for i, v in enumerate(variants):
