@@ -538,7 +538,9 @@ int spal_mg_create_transport(int ngpus, const int *devices, int transport, spal_
         return fail(SPAL_ERR_INVALID_ARGUMENT, "a device list with repeats needs the copy transport (RCCL refuses duplicate devices)");
     }
     c->transport = transport >= 0 ? transport : (c->repeats ? kTransportCopy : kTransportRccl);
-    if (ngpus == 1) c->transport = kTransportCopy;   // nothing to exchange: no RCCL needed
+    if (ngpus == 1 && transport != kTransportRccl) c->transport = kTransportCopy;   // nothing to exchange: no RCCL needed
+    // (ngpus == 1 with the RCCL transport asked for explicitly: a one-rank communicator -- loads RCCL and runs its
+    //  calls, which is all of that path a 1-GPU box can exercise)
     c->streams.assign(ngpus, nullptr);
     c->ready.assign(ngpus, nullptr);
     c->pulled.assign(ngpus, nullptr);

@@ -131,6 +131,39 @@ def test_non_square_has_no_halo_and_repeats_need_copy_transport(oracle):
         sp.MultiGpuCsr(a, 2, devices=[0, 0], transport="rccl")   # RCCL refuses duplicate devices
 
 
+def test_rccl_loads_and_runs_with_one_rank(oracle):
+    """what a 1-GPU box can exercise of the RCCL transport: librccl is found and loaded (dlopen), a one-rank
+    communicator is created (ncclCommInitAll), ncclBroadcast / ncclAllGather run in their groups; with one rank
+    there is nothing to send, so the grouped ncclSend / ncclRecv lists are empty."""
+    a, x = banded(200_000)
+    mg = sp.MultiGpuCsr(a, 1, transport="rccl")
+    assert mg.transport == "rccl"
+    y_ref = oracle.csr_spmv(a.rowptr(), a.colind(), a.values(), x)
+    assert np.array_equal(mg.spmv(x), y_ref)
+    mg.set_x(x)
+    mg.broadcast_x()
+    mg.spmv_resident()
+    assert np.array_equal(mg.y_allgathered(), y_ref)
+    mg.set_x(x)
+    mg.scatter_x()
+    mg.spmv_halo()
+    mg.gather_y()
+    assert np.array_equal(mg.y_gathered(), y_ref)
+    mg.close()
+
+
+def test_dist_worker_rehearsal_two_ranks_on_one_gpu():
+    """tests/dist_nccl_worker.py with two ranks sharing GPU 0 over gloo: every collective path of
+    spalinalg_amd/dist.py (scatter of x windows, gather on rank 0, halo steps, ragged unequal slices) with the
+    real kernels, on a 1-GPU box; the nccl run of the same worker is test_row_partitioned_spmv_over_nccl."""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29711",
+                          os.path.join(ROOT, "tests", "dist_nccl_worker.py"), "--backend", "gloo", "--same-device"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
+    assert "dist worker ok" in out.stdout
+
+
 @pytest.mark.parametrize("transport", ["rccl", "copy"])
 @pytest.mark.parametrize("ngpus", [pytest.param(2, marks=need_gpus(2)), pytest.param(4, marks=need_gpus(4)),
                                    pytest.param(8, marks=need_gpus(8))])
