@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #define CK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { printf("%s: %s\n", #e, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -102,6 +103,40 @@ __global__ __launch_bounds__(256, 2) void footprint(const double *__restrict__ v
         double s = tile_use(t[k & 3]);
         if (XWIN) s += reinterpret_cast<const double *>(smem)[(lane * 37 + k) & 4095];
         if (r0 + lane < nrows) y[r0 + lane] = s;
+    }
+}
+
+// The same loads, but a fixed grid of workgroups each walking a contiguous run of super-tiles (what the sliding
+// kernel does), two tiles ahead across super-tile boundaries, no x window: does the walk itself cost bandwidth?
+template <int PF>
+__global__ __launch_bounds__(256, 2) void footprint_walk(const double *__restrict__ vals, const uint16_t *__restrict__ col16,
+                                                         const uint32_t *__restrict__ rowptr, double *__restrict__ y,
+                                                         uint32_t nrows, uint32_t nsteps, uint32_t per_xcd, uint32_t chunk,
+                                                         uint32_t G) {
+    // G workgroups share a run of G * chunk steps: member m takes its steps m, m + G, m + 2G, ... (G = 1: a run each)
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, grp = slot / G, mem = slot % G;
+    const uint32_t run_end = min((xcd + 1u) * per_xcd, nsteps);
+    const uint32_t g0 = xcd * per_xcd + grp * chunk * G;
+    if (g0 + mem >= run_end) return;
+    const uint32_t g1 = min(g0 + chunk * G, run_end);
+    const uint32_t i0 = 0, i1 = (g1 - g0 - mem + G - 1u) / G;      // this member's steps, numbered 0 ...
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    Tile t[PF + 1];
+    auto gstep = [&](uint32_t i) { return g0 + mem + min(i, i1 - 1u) * G; };
+    auto row_of = [&](uint32_t i) { return min((gstep(i) * 4u + wave) * 64u, nrows - 64u); };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) tile_load(t[p], vals, col16, rowptr, row_of(i0 + p), lane);
+    auto step = [&](uint32_t i, auto kc) {
+        constexpr int K = decltype(kc)::value;
+        tile_load(t[(K + PF) % (PF + 1)], vals, col16, rowptr, row_of(i + PF), lane);
+        const double s = tile_use(t[K]);
+        const uint32_t r0 = (gstep(i) * 4u + wave) * 64u;
+        if (r0 + lane < nrows) y[r0 + lane] = s;
+    };
+    for (uint32_t i = i0; i < i1; i += PF + 1) {
+        step(i, std::integral_constant<int, 0>{});
+        if (i + 1 < i1) step(i + 1, std::integral_constant<int, 1>{});
+        if constexpr (PF >= 2) if (i + 2 < i1) step(i + 2, std::integral_constant<int, 2>{});
     }
 }
 
@@ -263,7 +298,40 @@ static int quick_main(uint32_t nrows_req, uint32_t per_row) {
     return 0;
 }
 
+// --walk: the fixed-grid walk against one workgroup per super-tile, same arrays
+static int walk_main() {
+    const uint32_t nrows = 10'000'000;
+    const size_t nnz = (size_t)nrows * 14 + 4096;
+    double *vals, *x, *y;
+    uint16_t *col16;
+    uint32_t *rowptr;
+    CK(hipMalloc(&vals, nnz * 8)); CK(hipMalloc(&col16, nnz * 2)); CK(hipMalloc(&rowptr, ((size_t)nrows + 65) * 4));
+    CK(hipMalloc(&x, (size_t)nrows * 8)); CK(hipMalloc(&y, (size_t)nrows * 8));
+    CK(hipMemset(vals, 1, nnz * 8)); CK(hipMemset(col16, 1, nnz * 2)); CK(hipMemset(rowptr, 0, ((size_t)nrows + 65) * 4));
+    CK(hipMemset(x, 0, (size_t)nrows * 8));
+    const uint32_t nblocks = (nrows + 1023) / 1024, per_xcd_b = (nblocks + 7) / 8;
+    const uint32_t nsteps = (nrows + 255) / 256, per_xcd = (nsteps + 7) / 8;
+    auto k1 = footprint<2, false>;
+    auto kw = footprint_walk<2>;
+    CK(hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void *)kw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (int rep = 0; rep < 3; ++rep) {
+        double us = time_us([&] { hipLaunchKernelGGL(k1, dim3(per_xcd_b * 8), dim3(256), 72 * 1024, 0, vals, col16, rowptr, x, y, nrows, nblocks, per_xcd_b); }, 30);
+        printf("one workgroup per super-tile (9766 workgroups)      %7.1f us\n", us);
+        for (uint32_t grid : {512u, 1024u}) {
+            for (uint32_t G : {1u, 2u, 4u, 8u, 16u, 64u}) {
+                const uint32_t slots = grid / 8, chunk = (per_xcd + slots - 1) / slots;
+                us = time_us([&] { hipLaunchKernelGGL(kw, dim3(slots * 8), dim3(256), 72 * 1024, 0, vals, col16, rowptr, y, nrows, nsteps, per_xcd, chunk, G); }, 30);
+                printf("walk: %5u workgroups x %4u steps of 256 rows, %2u workgroups interleaved per run   %7.1f us\n", slots * 8, chunk, G, us);
+            }
+        }
+        fflush(stdout);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && std::string(argv[1]) == "--walk") return walk_main();
     if (argc > 3 && std::string(argv[1]) == "--quick") return quick_main((uint32_t)atoll(argv[2]), (uint32_t)atoll(argv[3]));
     if (argc > 1 && std::string(argv[1]) == "--place") return place_main();
     if (argc > 1 && std::string(argv[1]) == "--stride") return stride_main();
