@@ -313,7 +313,7 @@ def bench_coo(args):
     out["roofline"] = {"bound": "hbm", "achieved": round(lb / (ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
                        "frac": round(lb / (ms * 1e-3) / 8e12, 4),
                        "traffic": traffic_entry("config5_assembly_f64") if args.dtype == "f64" else None,
-                       "kernel": "radix_hist/scatter x2 + coo_group_sort + coo_group_pack + CSR planning (whole assembly call)",
+                       "kernel": "radix_scatter x2 + radix_hist + coo_group_sort (look-back placement) + CSR planning (whole assembly call)",
                        "kernel_ms": round(ms, 6), "algorithmic_bytes_per_launch": lb,
                        "note": "algorithmic = lower bound 16*len + 12*nnz_out + 4*(nrows+1); a multi-pass sort "
                                "inherently moves several times this",

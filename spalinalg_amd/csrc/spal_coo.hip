@@ -10,21 +10,19 @@
 // reordering step is stable and each run is summed by ONE thread in insertion
 // order.
 //
-// Pipeline (device only; two small read-backs: the fullest group, the output size):
-//   1. stable LSD radix sort by the ROW BITS ABOVE gbits only (8 bits per pass:
-//      2 passes at config 5), carrying (col, value) as payload -- the entries of
-//      a group of 2^gbits consecutive rows (about a thousand entries) end up
-//      contiguous, still in insertion order.  Each pass: per-tile digit
-//      histogram -> scan -> scatter that first reorders the tile in LDS so every
-//      digit leaves as one contiguous, coalesced run.
-//   2. group offsets by one streaming pass over the sorted keys; the fullest
-//      group decides the LDS capacity of step 3 (512 ... 2048 entries).
-//   3. one workgroup per group, everything in LDS and entry-parallel: counting
-//      sort by the low row bits, stable rank by column inside each row, run
-//      heads sum their runs in insertion order, zeros dropped, survivors written
-//      in place at the front of the group's segment, per-row counts.
-//   4. scan of the per-row counts = rowptr; the groups are copied to their place
-//      in the final colind / values.
+// Pipeline (device only; one read-back at the end: the output size and the groups' column spans):
+//   0. at upload (functions of the uploaded indices alone, for rows and for columns): the first radix pass's
+//      per-tile digit offsets; the offsets of the groups of 2^gbits consecutive rows (about a thousand entries
+//      each) in the row-sorted order, and the fullest group, which decides the LDS capacity of step 2
+//      (512 ... 2048 entries).
+//   1. stable LSD radix sort by the ROW BITS ABOVE gbits only (8 bits per pass: 2 passes at config 5), carrying
+//      (col, value) as payload -- the entries of a group end up contiguous, still in insertion order.  Each pass:
+//      per-tile digit histogram -> scan -> scatter that first reorders the tile in LDS so every digit leaves as
+//      one contiguous, coalesced run.
+//   2. one workgroup per group, everything in LDS and entry-parallel: counting sort by the low row bits, stable
+//      rank by column inside each row, run heads sum their runs in insertion order, zeros dropped; the group's
+//      place in the result comes from a decoupled look-back over the groups before it, and the survivors and
+//      the rowptr of the group's rows are written once, at their final offsets.
 // If some group holds more than 2048 entries the assembly runs the general
 // route -- LSD passes over the column bits first, then all row bits -- and a
 // lane-sequential run summation, which is correct for any input, only slower.
@@ -453,6 +451,24 @@ static void launch_row_starts(const uint32_t *sorted_row, uint32_t n, uint32_t n
 
 constexpr int kGroupCap = 2048;  // entries a group of rows may hold for the LDS local sort
 
+// counts[key >> shift] += 1 for every uploaded index (upload time, once per handle and orientation).  Sorted or
+// clustered input puts a whole wave on one counter: such a wave adds its lane count once.
+__global__ __launch_bounds__(256) void coo_group_hist(const uint32_t *__restrict__ keys, uint64_t len, uint32_t shift,
+                                                      uint32_t *__restrict__ counts) {
+    for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < len; i0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t i = i0 + threadIdx.x;
+        const bool ok = i < len;
+        const uint32_t g = ok ? keys[i] >> shift : 0xffffffffu;
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+        if (__all(g == g0 || !ok)) {
+            const uint64_t m = __ballot(ok && g == g0);
+            if (m && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) atomicAdd(&counts[g0], (uint32_t)__popcll(m));
+        } else if (ok) {
+            atomicAdd(&counts[g], 1u);
+        }
+    }
+}
+
 // part[blk] = entries of the fullest group among those this workgroup visits
 // (no atomics: thousands of waves raising one shared maximum serialise on it;
 // groups_check_final folds the partial results)
@@ -507,16 +523,71 @@ __global__ __launch_bounds__(256) void groups_check_final(const uint32_t *__rest
 //      predecessor's; the head sums its run left to right = insertion order
 //      (coo.rs:42-46); sums that compare equal to zero are dropped (coo.rs:64).
 //   4. survivors are numbered in sorted order (ballots + a scan of the 4 x K
-//      wave counts) and written in place to the FRONT of the group's segment
-//      (the whole group sits in registers / LDS by then), already in final CSR
-//      order; kept[row] = survivors of the row (LDS counters).
+//      wave counts); the group learns how many survivors the groups before it
+//      hold (group_lookback) and writes its own at their FINAL offsets of
+//      colind / values, and rowptr of its rows (LDS counters + a scan).
+// state[g] of the look-back below: (status << 32) | count, status 0 = nothing yet, 1 = the group's own number of
+// survivors, 2 = survivors of groups 0 ... g inclusive.
+constexpr unsigned long long kGroupOwn = 1ull << 32, kGroupUpTo = 2ull << 32;
+constexpr uint32_t kLookbackSpins = 1u << 21;   // (seconds: a bound, so that every wave reaches its exit)
+
+// Survivors in all groups before `grp`, for the group that holds `total` of its own: decoupled look-back over the
+// groups' 8-byte state words (wave 0 of the workgroup, all 64 lanes: 64 predecessors per round).  The count travels
+// IN the word that flags it (relaxed agent-scope stores / loads: written through, read past L1), so no release /
+// acquire fence is paid -- with fences (an L2 write-back per group) this form lost to a separate pack kernel.
+// Progress: workgroups are dispatched in blockIdx order (XCD x takes the workgroups = x mod 8, in order), so the
+// lowest unfinished group is always resident and waits for nobody.  Should that ever not hold, the spin bound
+// raises *err and the host repeats the assembly on the general route.  (A resident grid whose workgroups walk the
+// groups b, b + grid, ... with the next group's loads in flight during the look-back needs no such assumption; it
+// was measured and is slower: 1.93 vs 1.68 ms per assembly, the static order keeps a fast workgroup from running ahead.)
+// Measured (config 5, profiles/r02/coo_lookback.txt): the wait costs 174 us of coo_group_sort's 750 (groups finish in
+// order, so a workgroup also waits out every slower predecessor still in flight) against 193 + 32 us for the pack
+// kernel and row scan it replaces, and 1.2 GB less traffic.  Polling 128 or 512 predecessors per round trip is slower
+// (1.86 / 1.98 vs 1.75 ms per assembly), the sleep between polls does not matter (1 ... 64: 1.75 - 1.79 ms).
+__device__ __forceinline__ uint32_t group_lookback(unsigned long long *state, uint32_t grp, uint32_t total,
+                                                   uint32_t lane, uint32_t *err) {
+    if (lane == 0)
+        __hip_atomic_store(&state[grp], (grp ? kGroupOwn : kGroupUpTo) | total, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    if (grp == 0) return 0;
+    uint32_t mine = 0, spins = 0;                         // lane-local part of the sum
+    int64_t base = (int64_t)grp - 1;                      // lane 0 looks at the nearest predecessor
+    for (;;) {
+        const int64_t idx = base - (int64_t)lane;
+        const unsigned long long sv = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                               : kGroupUpTo;   // before group 0: nothing
+        const uint32_t status = (uint32_t)(sv >> 32);
+        const uint64_t missing = __ballot(status == 0), upto = __ballot(status == 2);
+        // the nearest predecessor that knows its inclusive count ends the walk; everyone nearer must have reported
+        const uint64_t need = upto ? ((2ull << __builtin_ctzll(upto)) - 1ull) : ~0ull;
+        if (missing & need) {
+            if (++spins > kLookbackSpins) {
+                if (lane == 0) atomicOr(err, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+        if ((need >> lane) & 1ull) mine += (uint32_t)sv;
+        if (upto) break;
+        base -= 64;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += (uint32_t)__shfl_xor((int)mine, o, 64);
+    if (lane == 0)
+        __hip_atomic_store(&state[grp], kGroupUpTo | (unsigned long long)(uint32_t)(mine + total), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    return mine;
+}
+
 template <typename T, int CAP>
 __global__ __launch_bounds__(256) void coo_group_sort(const uint32_t *__restrict__ gstart,
                                                       const uint32_t *__restrict__ sorted_row,
-                                                      uint32_t *__restrict__ cols, T *__restrict__ vals,
-                                                      uint32_t nrows, uint32_t gbits,
-                                                      uint32_t *__restrict__ kept,
-                                                      uint2 *__restrict__ gwin) {
+                                                      const uint32_t *__restrict__ cols, const T *__restrict__ vals,
+                                                      uint32_t nrows, uint32_t gbits, uint32_t ngroups,
+                                                      unsigned long long *__restrict__ state, uint32_t *__restrict__ err,
+                                                      uint32_t *__restrict__ rowptr, uint32_t *__restrict__ out_col,
+                                                      T *__restrict__ out_val, uint2 *__restrict__ gwin) {
     constexpr int K = CAP / 256;  // rounds per wave = sorted positions per thread
     __shared__ T s_v2[CAP];
     __shared__ uint32_t s_c1[CAP];
@@ -526,22 +597,37 @@ __global__ __launch_bounds__(256) void coo_group_sort(const uint32_t *__restrict
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_wc[K * 4];
     __shared__ uint32_t s_cmin, s_cmax;   // columns of the survivors (the CSR planner's window input)
+    __shared__ uint32_t s_base, s_total;  // survivors of the groups before this one / of this one
     __shared__ uint8_t s_r2[CAP];
     // volatile: lanes of a wave hand counts to each other through this array
     // between two rounds; the compiler must re-read it every round
     __shared__ volatile uint32_t s_cnt[4][256];
 
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const uint32_t grp = blockIdx.x;
-    const uint32_t r0 = grp << gbits;                     // < nrows (the grid has ceil(nrows / 2^gbits) groups)
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t grp = blockIdx.x;                      // < ngroups
+    const uint32_t r0 = grp << gbits;                     // < nrows (there are ceil(nrows / 2^gbits) groups)
     const uint32_t nr = min(1u << gbits, nrows - r0);     // rows of this group, <= 256
     const uint32_t e0 = gstart[grp], n = gstart[grp + 1] - e0;  // n <= CAP (checked by the host)
-    if (n == 0) {  // block-uniform
-        if (t < nr) kept[r0 + t] = 0;
+    const bool last = grp + 1 == ngroups;
+    if (n == 0) {  // block-uniform: no entries, but the group's rows start where the groups before it end
+        if (w == 0) {
+            const uint32_t before = group_lookback(state, grp, 0u, lane, err);
+            if (lane == 0) s_base = before;
+        }
+        __syncthreads();
+        const uint32_t before = s_base;
+        if (t < nr) rowptr[r0 + t] = before;
+        if (last) {
+            if (t == 0) rowptr[nrows] = before;
+            out_col[before + t] = 0u;                     // the stream kernel's over-read margin (256 entries)
+            out_val[before + t] = T(0);
+        }
         if (t == 0) gwin[grp] = make_uint2(0xffffffffu, 0u);
         return;
     }
-    // 0. loads (clamped lanes re-read the last entry) and counter reset
+    // 0. one batch of loads (clamped lanes re-read the last entry: every load is issued unconditionally, back to
+    // back); wave w owns the entries [w * chunk, (w + 1) * chunk)
     const uint32_t chunk = ((n + 255) / 256) * 64;        // entries per wave, a multiple of 64, <= 64 K
     uint32_t rc[K], rid[K], pos[K];
     T rv[K];
@@ -552,182 +638,169 @@ __global__ __launch_bounds__(256) void coo_group_sort(const uint32_t *__restrict
         rv[k] = vals[e0 + ic];
         rid[k] = sorted_row[e0 + ic] - r0;
     }
-    for (uint32_t i = t; i < 4 * 256; i += 256) s_cnt[i >> 8][i & 255] = 0;
-    s_rk[t] = 0;
-    if (t == 0) { s_cmin = 0xffffffffu; s_cmax = 0u; }
-    __syncthreads();
-    // 1. stable counting sort by row inside the group
-    const uint64_t lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if (64u * k >= chunk) break;  // block-uniform
-        const bool ok = w * chunk + 64u * k + lane < n;
-        const uint32_t d = rid[k];
-        uint64_t peers = __ballot(ok);   // lanes of this round with the same row
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const uint64_t m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
-        }
-        const uint32_t before = ok ? s_cnt[w][d] : 0u;
-        pos[k] = before + (uint32_t)__popcll(peers & lt);
-        // the lowest peer lane publishes the new count (one writer per row)
-        if (ok && (peers & lt) == 0) s_cnt[w][d] = before + (uint32_t)__popcll(peers);
-    }
-    __syncthreads();
-    {   // thread d: exclusive prefix of row d's counts over the waves, then the row starts
-        uint32_t run = 0;
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-            const uint32_t c = s_cnt[ww][t];
-            s_cnt[ww][t] = run;
-            run += c;
-        }
-        const uint32_t inc = wave_inclusive_scan(run);
-        if (lane == 63) s_wsum[w] = inc;
+    {
+        for (uint32_t i = t; i < 4 * 256; i += 256) s_cnt[i >> 8][i & 255] = 0;
+        s_rk[t] = 0;
+        if (t == 0) { s_cmin = 0xffffffffu; s_cmax = 0u; }
         __syncthreads();
-        uint32_t base = 0;
+        // 1. stable counting sort by row inside the group
 #pragma unroll
-        for (uint32_t i = 0; i < 4; ++i)
-            if (i < w) base += s_wsum[i];
-        s_rs[t] = base + inc - run;
-        if (t == 255) s_rs[256] = base + inc;  // = n
-    }
-    __syncthreads();
+        for (int k = 0; k < K; ++k) {
+            if (64u * k >= chunk) break;  // block-uniform
+            const bool ok = w * chunk + 64u * k + lane < n;
+            const uint32_t d = rid[k];
+            uint64_t peers = __ballot(ok);   // lanes of this round with the same row
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if (64u * k >= chunk) break;
-        if (w * chunk + 64u * k + lane < n) {
-            pos[k] += s_rs[rid[k]] + s_cnt[w][rid[k]];   // place in row order, insertion order inside the row
-            s_c1[pos[k]] = rc[k];
-        }
-    }
-    __syncthreads();
-    // 2. rank by column inside the row -> (row, col) order
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if (64u * k >= chunk) break;
-        if (w * chunk + 64u * k + lane < n) {
-            const uint32_t d = rid[k], a = s_rs[d], b = s_rs[d + 1], ci = rc[k], i = pos[k];
-            uint32_t rank = 0, j = a;
-            for (; j + 4 <= b; j += 4) {
-                const uint32_t q0 = s_c1[j], q1 = s_c1[j + 1], q2 = s_c1[j + 2], q3 = s_c1[j + 3];
-                rank += (uint32_t)((q0 < ci) | ((q0 == ci) & (j < i)));
-                rank += (uint32_t)((q1 < ci) | ((q1 == ci) & (j + 1 < i)));
-                rank += (uint32_t)((q2 < ci) | ((q2 == ci) & (j + 2 < i)));
-                rank += (uint32_t)((q3 < ci) | ((q3 == ci) & (j + 3 < i)));
+            for (int b = 0; b < 8; ++b) {
+                const uint64_t m = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? m : ~m;
             }
-            for (; j < b; ++j) {
-                const uint32_t q = s_c1[j];
-                rank += (uint32_t)((q < ci) | ((q == ci) & (j < i)));
+            const uint32_t before = ok ? s_cnt[w][d] : 0u;
+            pos[k] = before + (uint32_t)__popcll(peers & lt);
+            // the lowest peer lane publishes the new count (one writer per row)
+            if (ok && (peers & lt) == 0) s_cnt[w][d] = before + (uint32_t)__popcll(peers);
+        }
+        __syncthreads();
+        {   // thread d: exclusive prefix of row d's counts over the waves, then the row starts
+            uint32_t run = 0;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                const uint32_t c = s_cnt[ww][t];
+                s_cnt[ww][t] = run;
+                run += c;
             }
-            pos[k] = a + rank;
-        }
-    }
-    __syncthreads();   // every rank is known: the row-ordered columns may be overwritten
+            const uint32_t inc = wave_inclusive_scan(run);
+            if (lane == 63) s_wsum[w] = inc;
+            __syncthreads();
+            uint32_t base = 0;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if (64u * k >= chunk) break;
-        if (w * chunk + 64u * k + lane < n) {
-            s_c2[pos[k]] = rc[k];
-            s_v2[pos[k]] = rv[k];
-            s_r2[pos[k]] = (uint8_t)rid[k];
+            for (uint32_t i = 0; i < 4; ++i)
+                if (i < w) base += s_wsum[i];
+            s_rs[t] = base + inc - run;
+            if (t == 255) s_rs[256] = base + inc;  // = n
         }
-    }
-    __syncthreads();
-    // 3. heads and run sums; thread t takes the sorted positions t, t + 256, ...
-    T acc[K];
-    uint64_t keepm[K];
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        keepm[k] = 0;
-        acc[k] = T(0);
-        if (256u * k >= n) continue;  // block-uniform
-        const uint32_t p = 256u * k + t;
-        const bool live = p < n;
-        const uint32_t pc = live ? p : n - 1, pp = pc ? pc - 1 : 0, pn = min(pc + 1, n - 1);
-        const uint32_t cp = s_c2[pc], cprev = s_c2[pp], cnext = s_c2[pn];
-        const uint32_t rp = s_r2[pc], rprev = s_r2[pp], rnext = s_r2[pn];
-        T a = s_v2[pc];
-        const bool head = live && (pc == 0 || cprev != cp || rprev != rp);
-        const bool dup = head && pn != pc && cnext == cp && rnext == rp;
-        if (__any(dup)) {  // duplicates are rare: most waves skip this
-            if (dup) {
-                for (uint32_t q = pc + 1; q < n && s_c2[q] == cp && s_r2[q] == rp; ++q) a = a + s_v2[q];
+        for (int k = 0; k < K; ++k) {
+            if (64u * k >= chunk) break;
+            if (w * chunk + 64u * k + lane < n) {
+                pos[k] += s_rs[rid[k]] + s_cnt[w][rid[k]];   // place in row order, insertion order inside the row
+                s_c1[pos[k]] = rc[k];
             }
         }
-        const bool keep = head && a != T(0);
-        acc[k] = a;
-        keepm[k] = __ballot(keep);
-        if (lane == 0) s_wc[k * 4 + w] = (uint32_t)__popcll(keepm[k]);
-    }
-    __syncthreads();
-    // 4. numbering in sorted order = (round, wave, lane); in-place write; row counts
-    if (t < 64) {  // K * 4 <= 64 wave counts: one wave scans them
-        const uint32_t kk = min(t, (uint32_t)(K * 4 - 1));
-        const uint32_t c = (t < (uint32_t)(K * 4) && 256u * (kk >> 2) < n) ? s_wc[kk] : 0u;
-        const uint32_t inc = wave_inclusive_scan(c);
-        if (t < (uint32_t)(K * 4)) s_wc[t] = inc - c;
-    }
-    __syncthreads();
-    uint32_t cmin = 0xffffffffu, cmax = 0u;
+        __syncthreads();
+        // 2. rank by column inside the row -> (row, col) order
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if (256u * k >= n) continue;
-        if ((keepm[k] >> lane) & 1ull) {
+        for (int k = 0; k < K; ++k) {
+            if (64u * k >= chunk) break;
+            if (w * chunk + 64u * k + lane < n) {
+                const uint32_t d = rid[k], a = s_rs[d], b = s_rs[d + 1], ci = rc[k], i = pos[k];
+                uint32_t rank = 0, j = a;
+                for (; j + 4 <= b; j += 4) {
+                    const uint32_t q0 = s_c1[j], q1 = s_c1[j + 1], q2 = s_c1[j + 2], q3 = s_c1[j + 3];
+                    rank += (uint32_t)((q0 < ci) | ((q0 == ci) & (j < i)));
+                    rank += (uint32_t)((q1 < ci) | ((q1 == ci) & (j + 1 < i)));
+                    rank += (uint32_t)((q2 < ci) | ((q2 == ci) & (j + 2 < i)));
+                    rank += (uint32_t)((q3 < ci) | ((q3 == ci) & (j + 3 < i)));
+                }
+                for (; j < b; ++j) {
+                    const uint32_t q = s_c1[j];
+                    rank += (uint32_t)((q < ci) | ((q == ci) & (j < i)));
+                }
+                pos[k] = a + rank;
+            }
+        }
+        __syncthreads();   // every rank is known: the row-ordered columns may be overwritten
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (64u * k >= chunk) break;
+            if (w * chunk + 64u * k + lane < n) {
+                s_c2[pos[k]] = rc[k];
+                s_v2[pos[k]] = rv[k];
+                s_r2[pos[k]] = (uint8_t)rid[k];
+            }
+        }
+        __syncthreads();
+        const uint32_t cur_n = n;
+        // 3. heads and run sums; thread t takes the sorted positions t, t + 256, ...
+        T acc[K];
+        uint64_t keepm[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            keepm[k] = 0;
+            acc[k] = T(0);
+            if (256u * k >= cur_n) continue;  // block-uniform
             const uint32_t p = 256u * k + t;
-            const uint32_t o = e0 + s_wc[k * 4 + w] + (uint32_t)__popcll(keepm[k] & lt);
-            const uint32_t cp = s_c2[p];
-            cols[o] = cp;
-            vals[o] = acc[k];
-            atomicAdd(&s_rk[s_r2[p]], 1u);
-            cmin = min(cmin, cp);
-            cmax = max(cmax, cp + 1u);
+            const bool live = p < cur_n;
+            const uint32_t pc = live ? p : cur_n - 1, pp = pc ? pc - 1 : 0, pn = min(pc + 1, cur_n - 1);
+            const uint32_t cp = s_c2[pc], cprev = s_c2[pp], cnext = s_c2[pn];
+            const uint32_t rp = s_r2[pc], rprev = s_r2[pp], rnext = s_r2[pn];
+            T a = s_v2[pc];
+            const bool head = live && (pc == 0 || cprev != cp || rprev != rp);
+            const bool dup = head && pn != pc && cnext == cp && rnext == rp;
+            if (__any(dup)) {  // duplicates are rare: most waves skip this
+                if (dup) {
+                    for (uint32_t q = pc + 1; q < cur_n && s_c2[q] == cp && s_r2[q] == rp; ++q) a = a + s_v2[q];
+                }
+            }
+            const bool keep = head && a != T(0);
+            acc[k] = a;
+            keepm[k] = __ballot(keep);
+            if (lane == 0) s_wc[k * 4 + w] = (uint32_t)__popcll(keepm[k]);
         }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        cmin = min(cmin, (uint32_t)__shfl_xor((int)cmin, o, 64));
-        cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, o, 64));
-    }
-    if (lane == 0) { atomicMin(&s_cmin, cmin); atomicMax(&s_cmax, cmax); }
-    __syncthreads();
-    if (t == 0) gwin[grp] = make_uint2(s_cmin, s_cmax);
-    if (t < nr) kept[r0 + t] = s_rk[t];
-}
-
-// Moves the survivors of every group (contiguous at the front of the group's
-// segment, see above) to their final place rowptr[first row of the group]: a
-// straight coalesced copy, one workgroup per group.
-template <typename T, int CAP>
-__global__ __launch_bounds__(256) void coo_group_pack(const uint32_t *__restrict__ gstart,
-                                                      const uint32_t *__restrict__ rowptr,
-                                                      const uint32_t *__restrict__ cols,
-                                                      const T *__restrict__ vals, uint32_t nrows,
-                                                      uint32_t gbits, uint32_t *__restrict__ out_col,
-                                                      T *__restrict__ out_val) {
-    constexpr int K = CAP / 256;
-    const uint32_t grp = blockIdx.x;
-    const uint32_t r0 = grp << gbits, r1 = r0 + min(1u << gbits, nrows - r0);
-    const uint32_t e0 = gstart[grp], o0 = rowptr[r0], cnt = rowptr[r1] - o0;
-    uint32_t rc[K];
-    T rv[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const uint32_t j = threadIdx.x + 256u * k;
-        rc[k] = 0;
-        rv[k] = T(0);
-        if (j < cnt) {
-            rc[k] = cols[e0 + j];
-            rv[k] = vals[e0 + j];
+        __syncthreads();
+        // 4. numbering in sorted order = (round, wave, lane); the group's place in the result (look-back over the
+        // groups before it); survivors written at their FINAL offsets; rowptr of the group's rows
+        if (t < 64) {  // K * 4 <= 64 wave counts: one wave scans them
+            const uint32_t kk = min(t, (uint32_t)(K * 4 - 1));
+            const uint32_t c = (t < (uint32_t)(K * 4) && 256u * (kk >> 2) < cur_n) ? s_wc[kk] : 0u;
+            const uint32_t inc = wave_inclusive_scan(c);
+            if (t < (uint32_t)(K * 4)) s_wc[t] = inc - c;
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            const uint32_t before = group_lookback(state, grp, total, lane, err);
+            if (t == 0) { s_base = before; s_total = total; }
         }
-    }
+        __syncthreads();
+        const uint32_t before = s_base;
+        uint32_t cmin = 0xffffffffu, cmax = 0u;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const uint32_t j = threadIdx.x + 256u * k;
-        if (j < cnt) {
-            out_col[o0 + j] = rc[k];
-            out_val[o0 + j] = rv[k];
+        for (int k = 0; k < K; ++k) {
+            if (256u * k >= cur_n) continue;
+            if ((keepm[k] >> lane) & 1ull) {
+                const uint32_t p = 256u * k + t;
+                const uint32_t o = before + s_wc[k * 4 + w] + (uint32_t)__popcll(keepm[k] & lt);
+                const uint32_t cp = s_c2[p];
+                out_col[o] = cp;
+                out_val[o] = acc[k];
+                atomicAdd(&s_rk[s_r2[p]], 1u);
+                cmin = min(cmin, cp);
+                cmax = max(cmax, cp + 1u);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            cmin = min(cmin, (uint32_t)__shfl_xor((int)cmin, o, 64));
+            cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, o, 64));
+        }
+        if (lane == 0) { atomicMin(&s_cmin, cmin); atomicMax(&s_cmax, cmax); }
+        __syncthreads();
+        if (t == 0) gwin[grp] = make_uint2(s_cmin, s_cmax);
+        {   // rowptr[r0 + i] = survivors before the group + those of its rows before row i
+            const uint32_t c = s_rk[t];                       // (0 beyond the group's rows)
+            const uint32_t inc = wave_inclusive_scan(c);
+            if (lane == 63) s_wsum[w] = inc;
+            __syncthreads();
+            uint32_t pre = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; ++i)
+                if (i < w) pre += s_wsum[i];
+            if (t < nr) rowptr[r0 + t] = before + pre + inc - c;
+        }
+        if (last) {
+            const uint32_t nnz = before + s_total;
+            if (t == 0) rowptr[nrows] = nnz;
+            out_col[nnz + t] = 0u;                            // the stream kernel's over-read margin (256 entries)
+            out_val[nnz + t] = T(0);
         }
     }
 }
@@ -780,16 +853,34 @@ struct DevView {
 // when the COO matrix is uploaded (setup, not the timed path).
 struct CooWorkspace {
     size_t bytes = 0;
-    size_t off_key[2], off_aux[2], off_val[2], off_counts, off_sums, off_start, off_kept, off_flag,
-        off_total, off_gwin;
+    size_t off_key[2], off_aux[2], off_val[2], off_counts, off_sums, off_state, off_total, off_gwin;
 };
+
+#ifndef SPAL_COO_GROUP_TARGET
+#define SPAL_COO_GROUP_TARGET 1400
+#endif
+// rows of a group the local sort finishes in LDS: about a thousand entries on average
+static uint32_t coo_group_bits(uint64_t len, uint64_t n_major) {
+    const double mean = (double)len / (double)n_major;
+    const uint32_t rbits = bits_for(n_major);
+    uint32_t gbits = 8;
+    while (gbits > 0 && mean * (double)(1u << gbits) > (double)SPAL_COO_GROUP_TARGET) --gbits;
+    if (gbits >= rbits) gbits = rbits - 1;  // at least one pass: it also brings the triplets into the workspace
+    return gbits;
+}
+static uint32_t coo_group_count(uint64_t len, uint64_t n_major) {
+    const uint32_t gbits = coo_group_bits(len, n_major);
+    return (uint32_t)((n_major + (1ull << gbits) - 1) >> gbits);
+}
+
 static CooWorkspace coo_workspace_layout(uint64_t len, uint64_t nrows, size_t elem) {
     CooWorkspace w;
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 255) & ~(size_t)255; return r; };
     const uint64_t nblk = (len + kSortTile - 1) / kSortTile;
     const uint64_t ncounts = 256ull * std::max<uint64_t>(nblk, 1);
-    const uint64_t scan_n = std::max<uint64_t>(std::max<uint64_t>(ncounts, len), nrows + 1);
+    const uint64_t scan_n = std::max<uint64_t>(ncounts, len);
+    const uint64_t ngroups = len ? coo_group_count(len, nrows) : 1;
     for (int i = 0; i < 2; ++i) {
         w.off_key[i] = take(len * 4);
         w.off_aux[i] = take(len * 4);
@@ -797,11 +888,9 @@ static CooWorkspace coo_workspace_layout(uint64_t len, uint64_t nrows, size_t el
     }
     w.off_counts = take(ncounts * 4);
     w.off_sums = take(((scan_n + kScanTile - 1) / kScanTile) * 4);
-    w.off_start = take((nrows + 1) * 4);
-    w.off_kept = take((nrows + 1) * 4);
-    w.off_flag = take(16 + (size_t)kCheckBlocks * 16);  // maxima + per-workgroup partial maxima
+    w.off_state = take(ngroups * 8 + 16);   // the look-back words of coo_group_sort, then its error flag
     w.off_total = take(4);
-    w.off_gwin = take((nrows + 1) * 8);   // one uint2 per group of rows (at most one per row)
+    w.off_gwin = take(ngroups * 8);         // one uint2 per group of rows
     w.bytes = o;
     return w;
 }
@@ -819,16 +908,6 @@ struct Assembled {
     std::vector<uint2> win256;
 };
 
-// rows of a group the local sort finishes in LDS: about a thousand entries on average
-static uint32_t coo_group_bits(uint64_t len, uint64_t n_major) {
-    const double mean = (double)len / (double)n_major;
-    const uint32_t rbits = bits_for(n_major);
-    uint32_t gbits = 8;
-    while (gbits > 0 && mean * (double)(1u << gbits) > 1400.0) --gbits;
-    if (gbits >= rbits) gbits = rbits - 1;  // at least one pass: it also brings the triplets into the workspace
-    return gbits;
-}
-
 // The first radix pass of an assembly reads the uploaded triplets as they are, so its per-tile digit counts are
 // a function of the handle alone: counted and scanned once, when the triplets arrive (for rows and for columns:
 // CSR and CSC assemblies), instead of in every assembly.
@@ -838,19 +917,41 @@ static hipError_t coo_first_pass_offsets(spal_coo *c, bool by_cols, hipStream_t 
     const uint32_t shift = coo_group_bits(len, n_major);
     const uint32_t nblk = (uint32_t)((len + kSortTile - 1) / kSortTile);
     const uint64_t ncounts = 256ull * nblk;
-    uint32_t *d = nullptr, *sums = nullptr;
+    const uint32_t ngroups = coo_group_count(len, n_major);
+    const uint32_t *keys = by_cols ? c->d_cols : c->d_rows;
+    uint32_t *d = nullptr, *sums = nullptr, *gs = nullptr, *part = nullptr;
+    const uint64_t scan_n = std::max<uint64_t>(ncounts, ngroups);
     hipError_t e = dev_alloc((void **)&d, ncounts * 4);
-    if (e == hipSuccess) e = dev_alloc((void **)&sums, ((ncounts + kScanTile - 1) / kScanTile + 1) * 4);
+    if (e == hipSuccess) e = dev_alloc((void **)&sums, ((scan_n + kScanTile - 1) / kScanTile + 1) * 4);
+    if (e == hipSuccess) e = dev_alloc((void **)&gs, ((size_t)ngroups + 1) * 4);
+    if (e == hipSuccess) e = dev_alloc((void **)&part, (size_t)(kCheckBlocks + 4) * 4);
+    uint32_t fullest = 0;
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(radix_hist, dim3(nblk), dim3(kHistThreads), 0, st, by_cols ? c->d_cols : c->d_rows, len,
-                           shift, d, nblk);
+        hipLaunchKernelGGL(radix_hist, dim3(nblk), dim3(kHistThreads), 0, st, keys, len, shift, d, nblk);
         e = exclusive_scan_u32(d, d, ncounts, sums, nullptr, st);
+    }
+    // the groups: entries per group of 2^shift majors (a histogram of the uploaded indices), their offsets, the fullest
+    if (e == hipSuccess) e = hipMemsetAsync(gs, 0, ((size_t)ngroups + 1) * 4, st);
+    if (e == hipSuccess) {
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((len + 1023) / 1024, 4096);
+        hipLaunchKernelGGL(coo_group_hist, dim3(blocks), dim3(256), 0, st, keys, len, shift, gs);
+        e = exclusive_scan_u32(gs, gs, ngroups, sums, nullptr, st, true);
+    }
+    if (e == hipSuccess) {
+        const uint32_t nparts = std::max<uint32_t>(std::min<uint32_t>((ngroups + 255) / 256, (uint32_t)kCheckBlocks), 1u);
+        hipLaunchKernelGGL(groups_check, dim3(nparts), dim3(256), 0, st, gs, ngroups, part + 4);
+        hipLaunchKernelGGL(groups_check_final, dim3(1), dim3(256), 0, st, part + 4, nparts, part);
+        e = hipMemcpyAsync(&fullest, part, 4, hipMemcpyDeviceToHost, st);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)dev_free(sums);
-    if (e != hipSuccess) { (void)dev_free(d); return e; }
-    c->d_first_offs[by_cols ? 1 : 0] = d;
-    c->first_shift[by_cols ? 1 : 0] = (int)shift;
+    (void)dev_free(part);
+    if (e != hipSuccess) { (void)dev_free(d); (void)dev_free(gs); return e; }
+    const int o = by_cols ? 1 : 0;
+    c->d_first_offs[o] = d;
+    c->first_shift[o] = (int)shift;
+    c->d_gstart[o] = gs;
+    c->fullest[o] = fullest;
     return hipSuccess;
 }
 
@@ -883,8 +984,7 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
         c->work_bytes = ws.bytes;
     }
     char *wb = (char *)c->d_work;
-    DevView start{wb + ws.off_start}, kept{wb + ws.off_kept}, flag{wb + ws.off_flag},
-        total{wb + ws.off_total}, sums{wb + ws.off_sums};
+    DevView total{wb + ws.off_total}, sums{wb + ws.off_sums};
     SortBuffers<T> sb;
     for (int i = 0; i < 2; ++i) {
         sb.key[i] = (uint32_t *)(wb + ws.off_key[i]);
@@ -894,32 +994,17 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
     sb.counts = (uint32_t *)(wb + ws.off_counts);
     sb.sums = sums.as<uint32_t>();
 
-    // ---- 1. stable sort by the row bits above gbits, (col, value) carried along; the
-    // first pass reads the uploaded triplets directly (they stay untouched).  Groups
-    // of 2^gbits rows (about a thousand entries on average) are finished in LDS.
+    // The groups of 2^gbits rows (about a thousand entries on average) that are finished in LDS, their offsets in
+    // the row-sorted triplets and the fullest one: known since the upload (coo_first_pass_offsets).
+    // LDS of the group kernel is 17 B per entry of capacity: the smallest capacity that holds the fullest group
+    // (more workgroups per CU); none -> general route
     const double mean = (double)len / (double)nrows;
     const uint32_t gbits = coo_group_bits(len, n_major);
-    int cur = 0;
+    const uint32_t ngroups = coo_group_count(len, n_major);
     const int o = by_cols ? 1 : 0;
-    SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, gbits, rbits - gbits, cur, st, d_major, d_minor,
-                                    (const T *)c->d_vals,
-                                    (c->d_first_offs[o] && c->first_shift[o] == (int)gbits) ? c->d_first_offs[o] : nullptr));
-    // ---- 2. group offsets; the fullest group
-    const uint32_t ngroups = (uint32_t)(((uint64_t)nrows + (1u << gbits) - 1) >> gbits);
-    launch_row_starts(sb.key[cur], (uint32_t)len, ngroups, start.as<uint32_t>(), st, gbits);
-    {
-        const uint32_t nparts = std::max<uint32_t>(std::min<uint32_t>((ngroups + 255) / 256, (uint32_t)kCheckBlocks), 1u);
-        uint32_t *part = reinterpret_cast<uint32_t *>(flag.p + 16);
-        hipLaunchKernelGGL(groups_check, dim3(nparts), dim3(256), 0, st, start.as<uint32_t>(), ngroups, part);
-        hipLaunchKernelGGL(groups_check_final, dim3(1), dim3(256), 0, st, part, nparts, flag.as<uint32_t>());
-    }
-    uint32_t fullest = 0;
-    SPAL_HIP_TRY(hipMemcpyAsync(&fullest, flag.p, 4, hipMemcpyDeviceToHost, st));
-    SPAL_HIP_TRY(hipStreamSynchronize(st));
-    // LDS of the group kernel is 17 B per entry of capacity: the smallest capacity
-    // that holds the fullest group (more workgroups per CU); none -> general route
-    const int group_cap = fullest <= 512 ? 512 : fullest <= 1024 ? 1024 : fullest <= 1536 ? 1536
-                          : fullest <= (uint32_t)kGroupCap ? kGroupCap : 0;
+    const uint32_t fullest = c->fullest[o];
+    int group_cap = !c->d_gstart[o] ? 0 : fullest <= 512 ? 512 : fullest <= 1024 ? 1024 : fullest <= 1536 ? 1536
+                    : fullest <= (uint32_t)kGroupCap ? kGroupCap : 0;
     c->last_group_rows = group_cap ? (int)(1u << gbits) : 0;
     c->last_group_cap = group_cap;
     if (getenv("SPAL_COO_DEBUG"))
@@ -928,44 +1013,66 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
 
     uint32_t nnz = 0;
     DevBuf ocol, oval;
+    int cur = 0;
     if (group_cap) {
-        // ---- 3. per group: rows, columns, run sums, zero drop -- in LDS
+        // ---- 1. stable sort by the row bits above gbits, (col, value) carried along; the first pass reads the
+        // uploaded triplets directly (they stay untouched)
+        SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, gbits, rbits - gbits, cur, st, d_major, d_minor, (const T *)c->d_vals,
+                                        (c->d_first_offs[o] && c->first_shift[o] == (int)gbits) ? c->d_first_offs[o] : nullptr));
+        // ---- 2. per group: rows, columns, run sums, zero drop in LDS; its place in the result by look-back over
+        // the groups before it; survivors and rowptr written at their final offsets.  The result arrays are sized
+        // for no entry dropped (the count is only known afterwards) and trimmed when a quarter or more is unused.
         auto k_sort = group_cap == 512 ? coo_group_sort<T, 512> : group_cap == 1024 ? coo_group_sort<T, 1024>
                       : group_cap == 1536 ? coo_group_sort<T, 1536> : coo_group_sort<T, kGroupCap>;
-        auto k_pack = group_cap == 512 ? coo_group_pack<T, 512> : group_cap == 1024 ? coo_group_pack<T, 1024>
-                      : group_cap == 1536 ? coo_group_pack<T, 1536> : coo_group_pack<T, kGroupCap>;
         uint2 *d_gwin = reinterpret_cast<uint2 *>(wb + ws.off_gwin);
-        hipLaunchKernelGGL(k_sort, dim3(ngroups), dim3(256), 0, st, start.as<uint32_t>(), sb.key[cur],
-                           sb.aux[cur], sb.val[cur], nrows, gbits, kept.as<uint32_t>(), d_gwin);
-        std::vector<uint2> gwin(ngroups);
-        // ---- 4. rowptr = scan of the kept counts; pack
-        SPAL_HIP_TRY(exclusive_scan_u32(kept.as<uint32_t>(), rowptr.as<uint32_t>(), nrows,
-                                        sums.as<uint32_t>(), total.as<uint32_t>(), st, true));
-        SPAL_HIP_TRY(hipMemcpyAsync(&nnz, total.p, 4, hipMemcpyDeviceToHost, st));
-        SPAL_HIP_TRY(hipMemcpyAsync(gwin.data(), d_gwin, (size_t)ngroups * sizeof(uint2), hipMemcpyDeviceToHost, st));
-        SPAL_HIP_TRY(hipStreamSynchronize(st));  // the one data-dependent size
-        {   // fold the groups (2^gbits <= 256 rows each) into windows of 256 rows
-            const uint32_t per = 256u >> gbits;
-            res.win256.assign(((size_t)nrows + 255) / 256, make_uint2(0xffffffffu, 0u));
-            for (uint32_t g = 0; g < ngroups; ++g) {
-                uint2 &w = res.win256[g / per];
-                w.x = std::min(w.x, gwin[g].x);
-                w.y = std::max(w.y, gwin[g].y);
-            }
-        }
-        const uint64_t cap = (uint64_t)nnz + 256;  // the stream kernel's over-read margin
+        unsigned long long *d_state = reinterpret_cast<unsigned long long *>(wb + ws.off_state);
+        uint32_t *d_err = reinterpret_cast<uint32_t *>(d_state + ngroups);
+        uint64_t cap = len + 256;  // + the stream kernel's over-read margin
         SPAL_HIP_TRY(ocol.alloc(cap * 4));
         SPAL_HIP_TRY(oval.alloc(cap * sizeof(T)));
-        SPAL_HIP_TRY(hipMemsetAsync((char *)ocol.p + (size_t)nnz * 4, 0, 256 * 4, st));
-        SPAL_HIP_TRY(hipMemsetAsync((char *)oval.p + (size_t)nnz * sizeof(T), 0, 256 * sizeof(T), st));
-        hipLaunchKernelGGL(k_pack, dim3(ngroups), dim3(256), 0, st, start.as<uint32_t>(),
-                           rowptr.as<uint32_t>(), sb.aux[cur], sb.val[cur], nrows, gbits, ocol.as<uint32_t>(),
-                           oval.as<T>());
+        SPAL_HIP_TRY(hipMemsetAsync(d_state, 0, (size_t)ngroups * 8 + 16, st));
+        hipLaunchKernelGGL(k_sort, dim3(ngroups), dim3(256), 0, st, c->d_gstart[o], sb.key[cur], sb.aux[cur],
+                           sb.val[cur], nrows, gbits, ngroups, d_state, d_err, rowptr.as<uint32_t>(),
+                           ocol.as<uint32_t>(), oval.as<T>(), d_gwin);
         SPAL_HIP_TRY(hipGetLastError());
+        std::vector<uint2> gwin(ngroups);
+        unsigned long long tail[2] = {0, 0};   // the last group's state word (survivors of all groups), the error flag
+        SPAL_HIP_TRY(hipMemcpyAsync(tail, d_state + (ngroups - 1), 16, hipMemcpyDeviceToHost, st));
+        SPAL_HIP_TRY(hipMemcpyAsync(gwin.data(), d_gwin, (size_t)ngroups * sizeof(uint2), hipMemcpyDeviceToHost, st));
         SPAL_HIP_TRY(hipStreamSynchronize(st));
-        res.ptr = (uint32_t *)rowptr.release(); res.ind = (uint32_t *)ocol.release();
-        res.val = oval.release(); res.nnz = nnz; res.cap = cap;
-        return SPAL_OK;
+        if ((uint32_t)tail[1] == 0 && (tail[0] >> 32) == 2) {
+            nnz = (uint32_t)tail[0];
+            {   // fold the groups (2^gbits <= 256 rows each) into windows of 256 rows
+                const uint32_t per = 256u >> gbits;
+                res.win256.assign(((size_t)nrows + 255) / 256, make_uint2(0xffffffffu, 0u));
+                for (uint32_t g = 0; g < ngroups; ++g) {
+                    uint2 &w = res.win256[g / per];
+                    w.x = std::min(w.x, gwin[g].x);
+                    w.y = std::max(w.y, gwin[g].y);
+                }
+            }
+            if (((uint64_t)nnz + 256) * 4 <= cap * 3) {   // many duplicates summed: do not keep len-sized arrays
+                DevBuf tcol, tval;
+                const uint64_t tcap = (uint64_t)nnz + 256;
+                SPAL_HIP_TRY(tcol.alloc(tcap * 4));
+                SPAL_HIP_TRY(tval.alloc(tcap * sizeof(T)));
+                SPAL_HIP_TRY(hipMemcpyAsync(tcol.p, ocol.p, tcap * 4, hipMemcpyDeviceToDevice, st));
+                SPAL_HIP_TRY(hipMemcpyAsync(tval.p, oval.p, tcap * sizeof(T), hipMemcpyDeviceToDevice, st));
+                SPAL_HIP_TRY(hipStreamSynchronize(st));
+                std::swap(tcol.p, ocol.p);
+                std::swap(tval.p, oval.p);
+                cap = tcap;
+            }
+            res.ptr = (uint32_t *)rowptr.release(); res.ind = (uint32_t *)ocol.release();
+            res.val = oval.release(); res.nnz = nnz; res.cap = cap;
+            return SPAL_OK;
+        }
+        // the look-back gave up waiting (never observed: see group_lookback) -> the general route below
+        if (getenv("SPAL_COO_DEBUG")) fprintf(stderr, "[spal coo] look-back timed out, general route\n");
+        c->last_group_rows = 0;
+        c->last_group_cap = 0;
+        (void)dev_free(ocol.release());
+        (void)dev_free(oval.release());
     }
 
     // ---- general route: sort by column bits, then by row bits (LSD), with the
@@ -1095,6 +1202,8 @@ static void coo_free(spal_coo *c) {
     (void)dev_free(c->d_work);
     (void)dev_free(c->d_first_offs[0]);
     (void)dev_free(c->d_first_offs[1]);
+    (void)dev_free(c->d_gstart[0]);
+    (void)dev_free(c->d_gstart[1]);
     (void)dev_free(c->d_rows);
     (void)dev_free(c->d_cols);
     (void)dev_free(c->d_vals);

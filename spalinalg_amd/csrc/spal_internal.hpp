@@ -216,6 +216,10 @@ struct spal_coo {
     // scanned per-tile digit counts of the first radix pass over the uploaded triplets, by rows [0] / by columns [1]
     uint32_t *d_first_offs[2] = {nullptr, nullptr};
     int first_shift[2] = {-1, -1};
+    // ... and the offsets of the groups of rows (columns) the local sort takes, with the fullest group's entries:
+    // functions of the uploaded indices alone as well
+    uint32_t *d_gstart[2] = {nullptr, nullptr};
+    uint32_t fullest[2] = {0, 0};
     size_t work_bytes = 0;
     std::mutex mu;            // serialises assemblies on one handle (shared workspace)
     int last_group_rows = 0, last_group_cap = 0;  // geometry of the last assembly's local sort (0 = general route)
