@@ -89,11 +89,13 @@ def main():
     t.append(traffic_of("4", {"csc_spmv_scatter": 1, "__amd_rocclr_fillBufferAligned": 1}, "config4_scatter_f64",
                         "bench.py --config 4 --copies 1: csc_spmv_scatter + the y memset"))
     f5 = pmc_means("fetch5")
-    per5 = {k: 1 for k in f5 if k.startswith(("radix_", "coo_", "rows_", "groups_", "scan_"))}
-    for k in ("radix_scatter", "scan_tile_sums", "scan_sums_inplace", "scan_apply"):
-        if k in per5:
-            per5[k] = 2 if k == "radix_scatter" else 1
-    t.append(traffic_of("5", per5, "config5_assembly_f64", "bench.py --config 5: kernels of one assembly (radix_scatter runs twice; scans / planning of the result counted once each)"))
+    # kernels of ONE assembly: both radix scatters, the second pass's histogram and its scan, the group kernel, the
+    # planning of the resulting CSR handle.  Not counted: what runs once per handle at upload (coo_group_hist,
+    # groups_check*, the first pass's histogram and scans).
+    per5 = {k: 1 for k in f5 if k.startswith(("radix_", "coo_group_sort", "scan_", "csr_block", "csr_stream_check", "csr_slide_scan"))}
+    if "radix_scatter" in per5:
+        per5["radix_scatter"] = 2
+    t.append(traffic_of("5", per5, "config5_assembly_f64", "bench.py --config 5: kernels of one assembly (radix_scatter runs twice; the second pass's histogram, its scan and the planning of the result once each; upload-time kernels not counted)"))
     open(f"{OUT}/pmc_traffic.txt", "w").write("# HBM bytes per launch from rocprofv3 --pmc passes (tools/prof_r2.sh)\n" + "\n".join(t) + "\n")
     lines += t
     json.dump(traffic, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
