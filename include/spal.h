@@ -80,7 +80,13 @@ int spal_partition_rows(const uint64_t *rowptr, uint64_t nrows,
  * (`impl Mul for &CsrMatrix<T>`, src/csr/ops/mul.rs:5-59); bound as
  * `impl Mul<&[T]> for &CsrMatrix<T>`.
  * create: borrows rowptr()/colind()/values() (src/csr.rs:228-258), checks
- * the constructor's invariants, narrows indices to 32 bits and uploads. */
+ * the constructor's invariants, narrows indices to 32 bits and uploads.
+ * Limits: nrows, ncols < 2^32.  The number of stored entries is not limited
+ * (the reference's offsets are usize, src/csr.rs:66-72): beyond 2^32 - 65537
+ * entries the handle keeps the matrix as row blocks with 32-bit offsets each
+ * (spal_csr_describe reports "kernel": "row_blocks" and the cuts); products,
+ * download, options and autotune work on the whole; spal_csr_to_csc is then
+ * refused (SPAL_ERR_UNSUPPORTED), and so are CSC / COO handles of that size. */
 int spal_csr_create_f64(int device, uint64_t nrows, uint64_t ncols,
                         const uint64_t *rowptr, uint64_t rowptr_len,
                         const uint64_t *colind, uint64_t colind_len,

@@ -379,14 +379,6 @@ static uint32_t bits_for(uint64_t n) {  // bits needed for values in [0, n)
     return b ? b : 1;
 }
 
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)dev_free(p); }
-    hipError_t alloc(size_t bytes) { return dev_alloc((void **)&p, bytes ? bytes : 1); }
-    template <typename U> U *as() { return reinterpret_cast<U *>(p); }
-    void *release() { void *q = p; p = nullptr; return q; }
-};
-
 // --------------------------------------------------------------------------
 // after the row sort
 // --------------------------------------------------------------------------

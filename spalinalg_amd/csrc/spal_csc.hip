@@ -656,6 +656,9 @@ int spal_csc_to_csr(spal_csc_t a, spal_csr_t *out) {
 int spal_csr_to_csc(spal_csr_t a, spal_csc_t *out) {
     if (!a || !out) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_to_csc: null argument");
     *out = nullptr;
+    if (!a->parts.empty())
+        return fail(SPAL_ERR_UNSUPPORTED, "spal_csr_to_csc: %llu entries do not fit one set of 32-bit device offsets "
+                    "(a CSC handle is not split into blocks)", (unsigned long long)a->nnz);
     DeviceGuard guard(a->device);
     if (guard.status != SPAL_OK) return guard.status;
     std::lock_guard<std::mutex> lock(a->mu);

@@ -778,6 +778,11 @@ static hipError_t launch_lanes(const spal_csr *a, const void *x, void *y, hipStr
 }
 
 int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream) {
+    if (!a->parts.empty()) {   // row blocks: each writes its own rows of y
+        for (size_t b = 0; b < a->parts.size(); ++b)
+            SPAL_TRY(csr_launch(a->parts[b], x_dev, (char *)y_dev + a->part_row0[b] * (uint64_t)a->elem_size, stream));
+        return SPAL_OK;
+    }
     if (a->nnz == 0) {
         const uint64_t n = a->nrows;
         if (a->elem_size == 8)
@@ -852,11 +857,13 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
                                                          : (a->elem_size == 4 ? 64u : kStreamWindowBytes / page_bytes));
     };
     uint32_t small_cap = small_pages();
-    uint32_t *d_pages = nullptr;
-    uint4 *d_info = nullptr, *d_ok = nullptr;
-    SPAL_HIP_TRY(dev_alloc((void **)&d_ok, (size_t)nb * sizeof(uint4)));
-    SPAL_HIP_TRY(dev_alloc((void **)&d_info, (size_t)nb * sizeof(uint4)));
-    SPAL_HIP_TRY(dev_alloc((void **)&d_pages, (size_t)nb * page_cap * 4));
+    // temporaries of the plan: returned to the allocator on every path out of this function
+    DevBuf b_pages, b_info, b_ok, b_win;
+    SPAL_HIP_TRY(b_ok.alloc((size_t)nb * sizeof(uint4)));
+    SPAL_HIP_TRY(b_info.alloc((size_t)nb * sizeof(uint4)));
+    SPAL_HIP_TRY(b_pages.alloc((size_t)nb * page_cap * 4));
+    uint32_t *d_pages = b_pages.as<uint32_t>();
+    uint4 *d_info = b_info.as<uint4>(), *d_ok = b_ok.as<uint4>();
     hipLaunchKernelGGL(csr_stream_check, dim3(nb), dim3(256), 0, a->stream, a->d_rowptr, (uint32_t)a->nrows, R,
                        rpt, (uint32_t)a->plan.stream_row_max, 128u / (uint32_t)a->elem_size, d_ok);
     // column windows already known per 256 rows (e.g. handed over by the assembly): fold and pass them
@@ -864,7 +871,8 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
     if (!a->win_base.empty() && R % kWinBase == 0) {
         std::vector<uint2> win;
         SPAL_TRY(block_windows(a, R, win));
-        SPAL_HIP_TRY(dev_alloc((void **)&d_win, (size_t)nb * sizeof(uint2)));
+        SPAL_HIP_TRY(b_win.alloc((size_t)nb * sizeof(uint2)));
+        d_win = b_win.as<uint2>();
         SPAL_HIP_TRY(hipMemcpyAsync(d_win, win.data(), (size_t)nb * sizeof(uint2), hipMemcpyHostToDevice, a->stream));
         SPAL_HIP_TRY(hipStreamSynchronize(a->stream));   // `win` goes out of scope
     }
@@ -874,15 +882,12 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
                        d_win, d_info, d_pages);
     std::vector<uint4> chk(nb);   // {a bit per tile that does not stream, cost of the tiles, entries, -}
     std::vector<uint4> info(nb);
-    hipError_t e = hipMemcpyAsync(chk.data(), d_ok, (size_t)nb * sizeof(uint4), hipMemcpyDeviceToHost, a->stream);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(info.data(), d_info, (size_t)nb * sizeof(uint4), hipMemcpyDeviceToHost, a->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
-    (void)dev_free(d_ok);
-    (void)dev_free(d_info);
-    (void)dev_free(d_win);
-    if (e != hipSuccess) { (void)dev_free(d_pages); }
-    SPAL_HIP_TRY(e);
+    SPAL_HIP_TRY(hipMemcpyAsync(chk.data(), d_ok, (size_t)nb * sizeof(uint4), hipMemcpyDeviceToHost, a->stream));
+    SPAL_HIP_TRY(hipMemcpyAsync(info.data(), d_info, (size_t)nb * sizeof(uint4), hipMemcpyDeviceToHost, a->stream));
+    SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
+    (void)dev_free(b_ok.release());
+    (void)dev_free(b_info.release());
+    (void)dev_free(b_win.release());
     if (decide_skew) {   // skewed product strips when most rows are a multiple of 128 bytes long (16 f64 / 32 f32 entries)
         uint64_t aligned = 0;
         for (uint32_t b = 0; b < nb; ++b) aligned += chk[b].w & 0xffffu;
@@ -978,7 +983,7 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
         frac = a->nrows ? (double)rows_tiles / (double)a->nrows : 0.0;
     }
     (void)rows_stream;
-    *out_pages = d_pages;
+    *out_pages = (uint32_t *)b_pages.release();
     return SPAL_OK;
 }
 
@@ -1143,7 +1148,8 @@ int csr_plan_build(spal_csr *a) {
                 uint32_t listed = 0;
                 SPAL_HIP_TRY(hipMemcpyAsync(&listed, d_list, 4, hipMemcpyDeviceToHost, a->stream));
                 SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
-                if (listed > pieces || listed < best_over) return SPAL_ERR_HIP;   // (cannot happen: both count the same tiles)
+                if (listed > pieces || listed < best_over)   // (cannot happen: both count the same tiles)
+                    return fail(SPAL_ERR_HIP, "csr plan: %u tiles listed for the overflow kernel, %u counted", listed, best_over);
                 a->n_ovtiles = listed;
             }
             SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
@@ -1252,6 +1258,7 @@ int csr_plan_build(spal_csr *a) {
 
 static void csr_free(spal_csr *a) {
     if (!a) return;
+    for (spal_csr *part : a->parts) csr_free(part);
     (void)dev_free(a->d_rowptr);
     (void)dev_free(a->d_colind);
     (void)dev_free(a->d_values);
@@ -1321,31 +1328,18 @@ int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, 
     return SPAL_OK;
 }
 
+// rows [r0, r1) of validated host arrays -> a handle whose offsets are relative to rowptr[r0]
 template <typename T>
-static int csr_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t *rowptr,
-                      uint64_t rowptr_len, const uint64_t *colind, uint64_t colind_len,
-                      const T *values, uint64_t values_len, spal_csr_t *out) {
-    if (!out) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_create: out is NULL");
-    *out = nullptr;
-    if (!rowptr || (!colind && colind_len) || (!values && values_len))
-        return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_create: null array");
-    int reason = 0;
-    SPAL_TRY(spal_csr_validate(nrows, ncols, rowptr, rowptr_len, colind, colind_len, values_len, &reason));
-    const uint64_t nnz = rowptr[nrows];
-    if (nrows >= 0xffffffffull || ncols > 0xffffffffull || nnz > kMaxEntries)
-        return fail(SPAL_ERR_UNSUPPORTED,
-                    "shape %llu x %llu with %llu entries does not fit 32-bit device indices",
-                    (unsigned long long)nrows, (unsigned long long)ncols, (unsigned long long)nnz);
-    DeviceGuard guard(device);
-    if (guard.status != SPAL_OK) return guard.status;
-
+static int csr_create_rows(int device, uint64_t r0, uint64_t r1, uint64_t ncols, const uint64_t *rowptr,
+                           const uint64_t *colind, const T *values, spal_csr **out) {
+    const uint64_t nrows = r1 - r0, e0 = rowptr[r0], nnz = rowptr[r1] - e0;
     // narrow usize -> u32 on the host (threads), then one upload per array
     std::vector<uint32_t> rp32(nrows + 1), ci32(nnz);
     parallel_for(nrows + 1, [&](uint64_t b, uint64_t e, unsigned) {
-        for (uint64_t i = b; i < e; ++i) rp32[i] = (uint32_t)rowptr[i];
+        for (uint64_t i = b; i < e; ++i) rp32[i] = (uint32_t)(rowptr[r0 + i] - e0);
     });
     parallel_for(nnz, [&](uint64_t b, uint64_t e, unsigned) {
-        for (uint64_t i = b; i < e; ++i) ci32[i] = (uint32_t)colind[i];
+        for (uint64_t i = b; i < e; ++i) ci32[i] = (uint32_t)colind[e0 + i];
     });
     uint32_t *d_rp = nullptr, *d_ci = nullptr;
     void *d_v = nullptr;
@@ -1358,7 +1352,7 @@ static int csr_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t
     if (e == hipSuccess) e = hipMemset((char *)d_v + nnz * sizeof(T), 0, kStreamPad * sizeof(T));
     if (e == hipSuccess) e = hipMemcpy(d_rp, rp32.data(), (nrows + 1) * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && nnz) e = hipMemcpy(d_ci, ci32.data(), nnz * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess && nnz) e = hipMemcpy(d_v, values, nnz * sizeof(T), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz) e = hipMemcpy(d_v, values + e0, nnz * sizeof(T), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         cleanup();
         return fail(e == hipErrorOutOfMemory ? SPAL_ERR_OUT_OF_MEMORY : SPAL_ERR_HIP,
@@ -1367,6 +1361,63 @@ static int csr_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t
     spal_csr *a = nullptr;
     int st = csr_adopt_device(device, (int)sizeof(T), nrows, ncols, nnz, cap, d_rp, d_ci, d_v, &a);
     if (st != SPAL_OK) { cleanup(); return st; }
+    *out = a;
+    return SPAL_OK;
+}
+
+// entries one set of 32-bit device offsets addresses; SPAL_CSR_PART_ENTRIES lowers it (tests of the row-block path)
+static uint64_t csr_part_entries() {
+    const char *s = getenv("SPAL_CSR_PART_ENTRIES");
+    const uint64_t u = s ? strtoull(s, nullptr, 10) : 0;
+    return u ? std::min<uint64_t>(u, kMaxEntries) : kMaxEntries;
+}
+
+template <typename T>
+static int csr_create(int device, uint64_t nrows, uint64_t ncols, const uint64_t *rowptr,
+                      uint64_t rowptr_len, const uint64_t *colind, uint64_t colind_len,
+                      const T *values, uint64_t values_len, spal_csr_t *out) {
+    if (!out) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_create: out is NULL");
+    *out = nullptr;
+    if (!rowptr || (!colind && colind_len) || (!values && values_len))
+        return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_create: null array");
+    int reason = 0;
+    SPAL_TRY(spal_csr_validate(nrows, ncols, rowptr, rowptr_len, colind, colind_len, values_len, &reason));
+    const uint64_t nnz = rowptr[nrows];
+    if (nrows >= 0xffffffffull || ncols > 0xffffffffull)
+        return fail(SPAL_ERR_UNSUPPORTED, "shape %llu x %llu does not fit 32-bit device indices",
+                    (unsigned long long)nrows, (unsigned long long)ncols);
+    DeviceGuard guard(device);
+    if (guard.status != SPAL_OK) return guard.status;
+    const uint64_t limit = csr_part_entries();
+    if (nnz <= limit) return csr_create_rows<T>(device, 0, nrows, ncols, rowptr, colind, values, out);
+
+    // more entries than 32-bit offsets address: row blocks of at most `limit` entries, cut at multiples of 1024
+    // rows (super-tiles stay whole) where that leaves a block non-empty
+    spal_csr *a = new spal_csr;
+    a->device = device;
+    a->elem_size = (int)sizeof(T);
+    a->nrows = nrows; a->ncols = ncols; a->nnz = nnz;
+    hipError_t e = stream_acquire(&a->stream);
+    if (e != hipSuccess) { csr_free(a); return fail(SPAL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    for (uint64_t r0 = 0; r0 < nrows;) {
+        // largest r1 with rowptr[r1] - rowptr[r0] <= limit
+        uint64_t r1 = (uint64_t)(std::upper_bound(rowptr + r0, rowptr + nrows + 1, rowptr[r0] + limit) - rowptr) - 1;
+        if (r1 <= r0) {   // (one row above the limit: impossible while columns are < 2^32 and strictly increasing)
+            csr_free(a);
+            return fail(SPAL_ERR_UNSUPPORTED, "row %llu alone holds more than %llu entries", (unsigned long long)r0,
+                        (unsigned long long)limit);
+        }
+        if (r1 < nrows && (r1 & ~1023ull) > r0) r1 &= ~1023ull;
+        spal_csr *part = nullptr;
+        const int st = csr_create_rows<T>(device, r0, r1, ncols, rowptr, colind, values, &part);
+        if (st != SPAL_OK) { csr_free(a); return st; }
+        a->parts.push_back(part);
+        a->part_row0.push_back(r0);
+        a->part_entry0.push_back(rowptr[r0]);
+        r0 = r1;
+    }
+    a->part_row0.push_back(nrows);
+    a->part_entry0.push_back(nnz);
     *out = a;
     return SPAL_OK;
 }
@@ -1422,6 +1473,14 @@ static int csr_download(spal_csr_t a, uint64_t *rowptr, uint64_t *colind, T *val
                     a->elem_size == 8 ? "f64" : "f32");
     if (a->nnz && (!colind || !values))
         return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_download: null array");
+    if (!a->parts.empty()) {   // row blocks: each fills its slices; offsets become absolute again
+        for (size_t b = 0; b < a->parts.size(); ++b) {
+            const uint64_t r0 = a->part_row0[b], e0 = a->part_entry0[b];
+            SPAL_TRY(csr_download<T>(a->parts[b], rowptr + r0, colind ? colind + e0 : nullptr, values ? values + e0 : nullptr));
+            for (uint64_t i = r0; i <= a->part_row0[b + 1]; ++i) rowptr[i] += e0;
+        }
+        return SPAL_OK;
+    }
     DeviceGuard guard(a->device);
     if (guard.status != SPAL_OK) return guard.status;
     std::vector<uint32_t> rp(a->nrows + 1), ci(a->nnz);
@@ -1451,6 +1510,11 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
         return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_autotune: handle holds %s values",
                     a->elem_size == 8 ? "f64" : "f32");
     if (!x_dev || !y_dev) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_autotune: null vector");
+    if (!a->parts.empty()) {   // row blocks: each tunes its own plan on its rows of y
+        for (size_t b = 0; b < a->parts.size(); ++b)
+            SPAL_TRY(csr_autotune<T>(a->parts[b], x_dev, y_dev + a->part_row0[b], stream, iters));
+        return SPAL_OK;
+    }
     if (iters < 1) iters = 1;
     DeviceGuard guard(a->device);
     if (guard.status != SPAL_OK) return guard.status;
@@ -1595,6 +1659,10 @@ int spal_csr_download_f32(spal_csr_t a, uint64_t *rowptr, uint64_t *colind, floa
 
 int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
     if (!a || !key) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_set_option: null argument");
+    if (!a->parts.empty()) {   // row blocks: every block takes the option (each plans for its own rows)
+        for (spal_csr *part : a->parts) SPAL_TRY(spal_csr_set_option(part, key, value));
+        return SPAL_OK;
+    }
     DeviceGuard guard(a->device);
     if (guard.status != SPAL_OK) return guard.status;
     std::lock_guard<std::mutex> lock(a->mu);
@@ -1738,6 +1806,19 @@ int spal_csr_autotune_f32(spal_csr_t a, const float *x_dev, float *y_dev, void *
 
 int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
     if (!a || !buf || !buf_len) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_describe: null argument");
+    if (!a->parts.empty()) {   // row blocks: the shape of the whole, the cuts, and the first block's plan
+        std::string rows = "[";
+        for (size_t b = 0; b < a->part_row0.size(); ++b) rows += (b ? ", " : "") + std::to_string(a->part_row0[b]);
+        rows += "]";
+        std::vector<char> first(buf_len);
+        SPAL_TRY(spal_csr_describe(a->parts[0], first.data(), first.size()));
+        snprintf(buf, buf_len,
+                 "{\"format\": \"csr\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"nnz\": %llu, "
+                 "\"kernel\": \"row_blocks\", \"parts\": %zu, \"part_rows\": %s, \"part0\": %s}",
+                 a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows, (unsigned long long)a->ncols,
+                 (unsigned long long)a->nnz, a->parts.size(), rows.c_str(), first.data());
+        return SPAL_OK;
+    }
     const CsrPlan &p = a->plan;
     snprintf(buf, buf_len,
              "{\"format\": \"csr\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"nnz\": %llu, "

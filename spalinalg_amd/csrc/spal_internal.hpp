@@ -64,6 +64,17 @@ constexpr uint64_t kMaxEntries = 0xffffffffull - 65536ull;
 
 hipError_t dev_alloc(void **ptr, size_t bytes);   // on the current device
 hipError_t dev_free(void *ptr);                   // on the current device; NULL is fine
+// a device block that returns to the allocator when it goes out of scope (early returns included)
+struct DevBuf {
+    void *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)dev_free(p); }
+    hipError_t alloc(size_t bytes) { return dev_alloc((void **)&p, bytes ? bytes : 1); }
+    template <typename U> U *as() { return reinterpret_cast<U *>(p); }
+    void *release() { void *q = p; p = nullptr; return q; }
+};
 void dev_cache_trim();                            // releases every cached block
 hipError_t stream_acquire(hipStream_t *out);      // a non-blocking stream of the current device (pooled)
 void stream_release(hipStream_t s);               // synchronises it and returns it to the pool
@@ -173,6 +184,12 @@ struct spal_csr {
     std::mutex mu;
     void *d_x = nullptr, *d_y = nullptr;
     hipStream_t stream = nullptr;
+    // More stored entries than 32-bit device offsets address (the reference's are usize, src/csr.rs:66-72): the
+    // handle is then a list of ROW BLOCKS, each a complete handle of its own (own plan, offsets relative to the
+    // block's first entry) over the same columns; this parent owns no matrix arrays.  A product launches the blocks
+    // one after the other on the caller's stream, block b writing y[part_row0[b] ...).
+    std::vector<spal_csr *> parts;
+    std::vector<uint64_t> part_row0, part_entry0;   // first row / first entry of every block, then nrows / nnz
 };
 
 struct spal_csc {

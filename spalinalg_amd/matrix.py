@@ -97,7 +97,7 @@ class _DeviceMatrix:
         check(self._fn("set_option")(self._h, key.encode(), C.c_int64(value)))
 
     def describe(self) -> dict:
-        buf = C.create_string_buffer(1024)
+        buf = C.create_string_buffer(16384)
         check(self._fn("describe")(self._h, buf, C.c_size_t(len(buf))))
         return json.loads(buf.value.decode())
 

@@ -918,3 +918,57 @@ def test_wide_bands_in_column_panels_bit_identical(oracle, dtype, window, gen, r
             dev.set_option(k, v)
         assert same(dev.spmv(x)), opts
     assert dev.describe()["panel_tiles"] == 0      # panel_pages = 0: no super-tile is flagged
+
+
+def test_row_blocks_beyond_32_bit_entry_offsets(oracle, monkeypatch):
+    """More stored entries than one set of 32-bit device offsets addresses (the reference's offsets are usize,
+    src/csr.rs:66-72): the handle keeps the matrix as row blocks.  SPAL_CSR_PART_ENTRIES lowers the limit so the path
+    runs on a small matrix: products (host and device entry points), download, options, autotune and the refusal of
+    the one conversion that cannot be split.  (The real limit: tools/lab_huge.py, 4.5e9 entries.)"""
+    import torch
+    monkeypatch.setenv("SPAL_CSR_PART_ENTRIES", "300000")
+    for dtype, gen in ((np.float64, "banded"), (np.float32, "ragged")):
+        n = 200_000 + 37
+        if gen == "banded":
+            rp, ci, va = synth.banded_csr(n, n, 14, 4096, 3, dtype=dtype)
+        else:
+            rp, ci, va = synth.ragged_csr(n, n, 4096, 3, dtype=dtype)
+        x = synth.vector(n, dtype=dtype)
+        y_ref = oracle.csr_spmv(rp, ci, va, x)
+        dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+        d = dev.describe()
+        nparts = -(-int(rp[-1]) // 300_000)
+        assert d["kernel"] == "row_blocks" and d["parts"] >= nparts and d["nnz"] == int(rp[-1])
+        cuts = d["part_rows"]
+        assert cuts[0] == 0 and cuts[-1] == n and all(b > a for a, b in zip(cuts, cuts[1:]))
+        assert all(int(rp[b]) - int(rp[a]) <= 300_000 for a, b in zip(cuts, cuts[1:]))
+        assert dev.shape() == (n, n, int(rp[-1]))
+        bits = np.uint64 if dtype == np.float64 else np.uint32
+        if gen == "banded":     # every block streams: bit-identical
+            assert np.array_equal(dev.spmv(x).view(bits), y_ref.view(bits))
+        else:
+            bound = oracle.csr_abs_bound(rp, ci, va, x)
+            assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-4)
+        xt = torch.from_numpy(x).cuda()
+        yt = torch.full((n,), float("nan"), dtype=xt.dtype, device="cuda")
+        dev.spmv_torch(xt, yt)
+        torch.cuda.synchronize()
+        assert np.array_equal(yt.cpu().numpy().view(bits), dev.spmv(x).view(bits))
+        rp2, ci2, va2 = dev.download()
+        assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(va2.view(bits), va.view(bits))
+        dev.set_option("rows_per_tile", 32)
+        assert dev.describe()["part0"]["rows_per_tile"] == 32
+        assert np.array_equal(dev.spmv(x).view(bits), yt.cpu().numpy().view(bits)) or gen == "ragged"
+        dev.autotune(xt, yt, iters=3)
+        torch.cuda.synchronize()
+        y3 = dev.spmv(x)
+        if gen == "banded":
+            assert np.array_equal(y3.view(bits), y_ref.view(bits))
+        with pytest.raises(sp.SpalError):
+            dev.to_csc()
+        dev.close()
+    monkeypatch.delenv("SPAL_CSR_PART_ENTRIES")
+    rp, ci, va = synth.banded_csr(50_000, 50_000, 14, 4096, 3)
+    one = sp.CsrMatrix(50_000, 50_000, rp, ci, va).device()
+    assert one.describe()["kernel"] == "stream"      # (the limit is back: one block)
+    one.close()

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Entry offsets above 2^31 (development check): 160M x 160M banded, 2.24e9 stored entries (18 GB of values).
-Row sums for x = 1 against numpy, random x on sampled rows, every kernel form."""
+"""Entry offsets above 2^31 / above 2^32 (development check): 160M x 160M banded, 2.24e9 stored entries (18 GB of
+values) by default; `lab_huge.py 330000000` = 4.62e9 entries, more than one set of 32-bit device offsets addresses:
+the handle then keeps row blocks (spal_csr_describe: "row_blocks").
+Row sums for x = 1 against numpy, random x on sampled rows (incl. the rows around every cut), every kernel form."""
 import os
 import sys
 import time
@@ -25,6 +27,10 @@ xr = torch.from_numpy(synth.vector(n)).cuda()
 xh = xr.cpu().numpy()
 rows = np.concatenate([np.arange(0, 2000), np.arange(n - 2000, n), np.random.default_rng(1).integers(0, n, 20000),
                        np.arange((2**31) // 14 - 1000, (2**31) // 14 + 1000), np.arange((2**32 - 2**30) // 14, (2**32 - 2**30) // 14 + 1000)])
+d = dev.describe()
+if d["kernel"] == "row_blocks":
+    print(f"row blocks: {d['parts']} parts, cuts at rows {d['part_rows']}", flush=True)
+    rows = np.concatenate([rows] + [np.arange(max(c - 1500, 0), min(c + 1500, n)) for c in d["part_rows"][1:-1]])
 rows = rows[rows < n]
 for opts in ((("persistent", 0),), (("persistent", 1),), (("kernel", 1),)):
     for k, v in opts:
