@@ -164,6 +164,16 @@ def test_dist_worker_rehearsal_two_ranks_on_one_gpu():
     assert "dist worker ok" in out.stdout
 
 
+def test_dist_worker_over_nccl_with_one_rank():
+    """what a 1-GPU box can run of spalinalg_amd/dist.py over the nccl backend (= RCCL): the process group, broadcast,
+    all-gather, gather, batched isend / irecv lists (empty with one rank) and the halo steps, against the oracle."""
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29712",
+                          os.path.join(ROOT, "tests", "dist_nccl_worker.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
+    assert "dist worker ok" in out.stdout
+
+
 @pytest.mark.parametrize("transport", ["rccl", "copy"])
 @pytest.mark.parametrize("ngpus", [pytest.param(2, marks=need_gpus(2)), pytest.param(4, marks=need_gpus(4)),
                                    pytest.param(8, marks=need_gpus(8))])
