@@ -240,7 +240,9 @@ def bench_small(args):
                       f"(BASELINE configs[0], the reference's CPU-sized case; launch-bound on a GPU), single GPU",
                       csr.describe())
     out["roofline"] = {"bound": "hbm", "achieved": round(B / (ms * 1e-3) / 1e9, 2), "peak": 8000.0, "unit": "GB/s",
-                       "frac": round(B / (ms * 1e-3) / 8e12, 5), "traffic": None, "kernel": "csr_spmv_" + csr.describe()["kernel"],
+                       "frac": round(B / (ms * 1e-3) / 8e12, 5), "traffic": None,
+                       "kernel": ("csr_spmv_slide" if csr.describe().get("slide") and csr.describe()["kernel"] == "stream"
+                                  else "csr_spmv_" + csr.describe()["kernel"]),
                        "kernel_ms": round(ms, 6), "algorithmic_bytes_per_launch": B,
                        "note": "1.4 MB of work: the launch itself is the cost"}
     out["assembly_ms"] = round(asm_ms, 4)
@@ -909,7 +911,7 @@ def main():
             "frac": round(achieved / peak, 4),
             "traffic": traffic,
             "traffic_source": "profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
-            "kernel": "csr_spmv_" + plan["kernel"],
+            "kernel": ("csr_spmv_slide" if plan.get("slide") and plan["kernel"] == "stream" else "csr_spmv_" + plan["kernel"]),
             "kernel_ms": round(kern_ms, 6),
             "kernel_ms_max_over_ranks": round(kern_ms_max, 6),
             "algorithmic_bytes_per_launch": local_bytes,
