@@ -186,9 +186,12 @@ def bench_csc(args):
     out["roofline"] = {"bound": "hbm", "achieved": round(B / (ms * 1e-3) / 1e9, 2), "peak": 8000.0,
                        "unit": "GB/s", "frac": round(B / (ms * 1e-3) / 8e12, 4),
                        "traffic": traffic_entry("config4_scatter_f64") if args.dtype == "f64" else None,
-                       "kernel": "csc_spmv_scatter (+ y memset)", "kernel_ms": round(ms, 6),
+                       "kernel": "csc_spmv_scatter" + (" (neighbour hand-off: no memset, no global atomics)"
+                                                       if dev.describe().get("flush") == "neighbour_handoff" else " (+ y zero fill)"),
+                       "kernel_ms": round(ms, 6),
                        "algorithmic_bytes_per_launch": B,
-                       "note": "bound in practice by LDS / global float-atomic rates, not by HBM"}
+                       "note": "LDS float atomics per entry; y rows stored once per super-tile, rows shared with the "
+                               "neighbouring super-tile updated behind a flag"}
     out["transposed_route"] = {"ms_per_step": round(ms_transposed, 6),
                                "gflops": round(synth.spmv_flops(nnz) / (ms_transposed * 1e-3) / 1e9, 2),
                                "roofline_frac": round(B / (ms_transposed * 1e-3) / 8e12, 4),

@@ -21,7 +21,7 @@
 namespace spal {
 
 #ifndef SPAL_CSC_U
-#define SPAL_CSC_U 4
+#define SPAL_CSC_U 2
 #endif
 #ifndef SPAL_CSC_BLOCK
 #define SPAL_CSC_BLOCK 1024
@@ -93,14 +93,17 @@ __global__ __launch_bounds__(kCscBlock, kCscBlock >= 1024 ? 1 : 2) void csc_spmv
     const uint32_t *__restrict__ colptr, const uint32_t *__restrict__ rowind,
     const uint32_t *__restrict__ meta, const T *__restrict__ vals, const T *__restrict__ x,
     T *__restrict__ y, const uint4 *__restrict__ desc, uint32_t ncols, uint32_t nblocks,
-    uint32_t per_xcd, uint32_t last_pair, T *__restrict__ windows) {
+    uint32_t per_xcd, uint32_t last_pair, T *__restrict__ windows, const uint32_t *__restrict__ prev_hi,
+    uint32_t *__restrict__ flags, uint32_t epoch, uint32_t nrows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
     using pair_t = typename Pair<T>::type;
     using u2_t = __attribute__((ext_vector_type(2))) uint32_t;
     T *xt = reinterpret_cast<T *>(spal_smem);  // x of the super-tile's columns
     T *yw = xt + kCscCols;                     // y window accumulators
 
-    const uint32_t b = xcd_contiguous_block(blockIdx.x, per_xcd);
+    // neighbour hand-off: super-tile b waits for b - 1, which must have been dispatched before it -> tile order =
+    // dispatch order; otherwise each XCD takes a contiguous run of super-tiles
+    const uint32_t b = prev_hi ? blockIdx.x : xcd_contiguous_block(blockIdx.x, per_xcd);
     if (b >= nblocks) return;
     const uint32_t k0 = b * kCscCols, k1 = min(k0 + (uint32_t)kCscCols, ncols);
     // desc and the two column pointers are independent loads: one round trip for the three
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(kCscBlock, kCscBlock >= 1024 ? 1 : 2) void csc_spmv
         static_assert(kCscCols % kCscBlock == 0 || kCscCols < kCscBlock, "whole x elements per thread");
         constexpr uint32_t XPT = kCscCols > kCscBlock ? kCscCols / kCscBlock : 1;   // x elements per thread
         uint32_t batch0 = p0 & ~1u;   // uniform: first entry of the current batch
+        const uint32_t tile_last_pair = min(last_pair, p1 ? (p1 - 1u) & ~1u : 0u);   // pair holding the super-tile's last entry
         pair_t v[U];
         u2_t m[U];
 #pragma unroll
@@ -134,21 +138,32 @@ __global__ __launch_bounds__(kCscBlock, kCscBlock >= 1024 ? 1 : 2) void csc_spmv
         for (uint32_t q = 0; q < XPT; ++q)
             if (threadIdx.x + q * kCscBlock < k1 - k0) xt[threadIdx.x + q * kCscBlock] = xk[q];
         __syncthreads();
+        // Two batches in flight: the next batch's loads are issued before this one's LDS adds (loads return in
+        // order, so the adds wait for the older batch only) -- with one batch the wave sat out a full memory
+        // round trip per batch, six times per super-tile of config 4.
         while (true) {
+            const uint32_t next0 = batch0 + kBatch;
+            const bool more = next0 < p1;   // uniform
+            pair_t vn[U];
+            u2_t mn[U];
+            // (unconditional: loads under a uniform branch make the compiler wait for ALL loads before the adds;
+            //  lanes past the super-tile's last pair re-read that pair: one line, no traffic)
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t e = min(next0 + threadIdx.x * 2 + u * (kCscBlock * 2), tile_last_pair);
+                vn[u] = __builtin_nontemporal_load(reinterpret_cast<const pair_t *>(vals + e));
+                mn[u] = __builtin_nontemporal_load(reinterpret_cast<const u2_t *>(meta + e));
+            }
 #pragma unroll
             for (uint32_t u = 0; u < U; ++u) {
                 const uint32_t e = batch0 + threadIdx.x * 2 + u * (kCscBlock * 2);
                 if (e >= p0 && e < p1) lds_add(&yw[m[u].x & 0xffffu], v[u].x * xt[m[u].x >> 16]);
                 if (e + 1 >= p0 && e + 1 < p1) lds_add(&yw[m[u].y & 0xffffu], v[u].y * xt[m[u].y >> 16]);
             }
-            batch0 += kBatch;
-            if (batch0 >= p1) break;   // uniform
+            if (!more) break;
+            batch0 = next0;
 #pragma unroll
-            for (uint32_t u = 0; u < U; ++u) {
-                const uint32_t e = min(batch0 + threadIdx.x * 2 + u * (kCscBlock * 2), last_pair);
-                v[u] = __builtin_nontemporal_load(reinterpret_cast<const pair_t *>(vals + e));
-                m[u] = __builtin_nontemporal_load(reinterpret_cast<const u2_t *>(meta + e));
-            }
+            for (uint32_t u = 0; u < U; ++u) { v[u] = vn[u]; m[u] = mn[u]; }
         }
         __syncthreads();
         if (windows) {
@@ -156,6 +171,40 @@ __global__ __launch_bounds__(kCscBlock, kCscBlock >= 1024 ? 1 : 2) void csc_spmv
             // stores); csc_window_reduce adds the overlapping windows row by row
             T *slot = windows + d.w;
             for (uint32_t i = threadIdx.x; i < d.y; i += kCscBlock) slot[i] = yw[i];
+            return;
+        }
+        if (prev_hi) {
+            // Neighbour hand-off (plan: windows ascend, only adjacent super-tiles overlap).  Rows from the end of
+            // the previous window on are this super-tile's own: STORED (written through, `sc1`), with zeros for
+            // rows no window covers; then a flag.  The rows shared with the previous super-tile are updated after
+            // ITS flag: y[r] = (previous tile's sum) + (this tile's) -- columns ascending, no atomics, no memset.
+            const uint32_t lo = d.x, hi = d.x + d.y, ph = prev_hi[b];       // ph <= hi; ph = 0 for b = 0
+            const uint32_t own0 = max(lo, ph);
+            for (uint32_t r = min(ph, lo) + threadIdx.x; r < lo; r += kCscBlock) y[r] = T(0);   // gap before the window
+            for (uint32_t r = own0 + threadIdx.x; r < hi; r += kCscBlock)
+                __hip_atomic_store(&y[r], yw[r - lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b + 1 == nblocks)
+                for (uint32_t r = hi + threadIdx.x; r < nrows; r += kCscBlock) y[r] = T(0);     // rows after the last window
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, before the barrier the flag sits behind
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(&flags[b], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ph > lo) {   // uniform: rows [lo, ph) also belong to super-tile b - 1, which stores them
+                if (threadIdx.x == 0) {
+                    uint32_t spins = 0;
+                    while (__hip_atomic_load(&flags[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                        if (++spins > (1u << 22)) {   // (a bound, so that the wave ends whatever happens)
+                            __hip_atomic_store(&flags[nblocks], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                }
+                __syncthreads();
+                for (uint32_t r = lo + threadIdx.x; r < min(ph, hi); r += kCscBlock) {
+                    const T before = __hip_atomic_load(&y[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    y[r] = before + yw[r - lo];
+                }
+            }
             return;
         }
         // flush: contiguous, one atomic per touched row (adding 0.0 changes nothing)
@@ -246,7 +295,7 @@ static int pick_lanes_csc(double mean) {
 }
 
 template <typename T, int COLS>
-static hipError_t csc_launch_c(const spal_csc *a, const void *x, void *y, hipStream_t st) {
+static hipError_t csc_launch_c(const spal_csc *a, const void *x, void *y, hipStream_t st, uint32_t epoch) {
     const uint32_t per_xcd = (a->nblocks + 7) / 8;
     // x tile + the y window; global-mode super-tiles keep their column pointers where the window would be
     const size_t lds = std::max(((size_t)COLS + a->lds_entries) * sizeof(T),
@@ -266,22 +315,58 @@ static hipError_t csc_launch_c(const spal_csc *a, const void *x, void *y, hipStr
                        a->d_meta, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc,
                        (uint32_t)a->ncols, a->nblocks, per_xcd,
                        (uint32_t)(((a->nnz + kStreamPad) & ~(uint64_t)1) - 2),
-                       (a->flush && a->d_windows) ? (T *)a->d_windows : (T *)nullptr);
+                       (a->flush == 1 && a->d_windows) ? (T *)a->d_windows : (T *)nullptr,
+                       epoch ? a->d_prev_hi : (const uint32_t *)nullptr, a->d_flags, epoch, (uint32_t)a->nrows);
     return hipGetLastError();
 }
 
 template <typename T>
-static hipError_t csc_launch_t(const spal_csc *a, const void *x, void *y, hipStream_t st) {
-    const bool two_phase = a->flush && a->d_windows;
+static hipError_t csc_launch_t(spal_csc *a, const void *x, void *y, hipStream_t st) {
+    const bool two_phase = a->flush == 1 && a->d_windows;
     const bool assign = two_phase && a->all_lds;   // the reduce writes every row of y: no memset
     hipError_t e = hipSuccess;
-    if (!assign || a->nnz == 0) e = hipMemsetAsync(y, 0, a->nrows * sizeof(T), st);
+    // Neighbour hand-off: the super-tiles of one launch talk through the handle's flags, so launches of one handle
+    // are chained (each waits for the event of the one before, whatever its stream).  Not while the stream is being
+    // captured into a graph (an event from outside the capture cannot be waited for): global atomics then.
+    bool ordered = a->flush == 0 && a->ordered && a->nnz != 0;
+    if (ordered) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) ordered = false;
+    }
+    std::unique_lock<std::mutex> chain(a->mu_launch, std::defer_lock);
+    uint32_t epoch = 0;
+    if (ordered) {
+        chain.lock();
+        if (!a->ev_last) {
+            e = hipEventCreateWithFlags(&a->ev_last, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        } else {
+            e = hipStreamWaitEvent(st, a->ev_last, 0);
+            if (e != hipSuccess) return e;
+        }
+        if (++a->epoch == 0) {   // (wrapped after 2^32 launches: the flags start over)
+            e = hipMemsetAsync(a->d_flags, 0, ((size_t)a->nblocks + 1) * 4, st);
+            if (e != hipSuccess) return e;
+            a->epoch = 1;
+        }
+        epoch = a->epoch;
+    }
+    if (!ordered && (!assign || a->nnz == 0)) {
+        // (a kernel, not hipMemsetAsync: as a node of a captured graph the memset zeroed every other element from
+        //  the second replay on -- ROCm 7.2, tools/lab_csc_capture.py)
+        hipLaunchKernelGGL(fill_zero<T>, dim3((uint32_t)((a->nrows + 255) / 256)), dim3(256), 0, st, (T *)y, a->nrows);
+        e = hipGetLastError();
+    }
     if (e != hipSuccess || a->nnz == 0) return e;
     switch (a->cols_per_block) {
-        case 1024: e = csc_launch_c<T, 1024>(a, x, y, st); break;
-        case 2048: e = csc_launch_c<T, 2048>(a, x, y, st); break;
-        case 4096: e = csc_launch_c<T, 4096>(a, x, y, st); break;
+        case 1024: e = csc_launch_c<T, 1024>(a, x, y, st, epoch); break;
+        case 2048: e = csc_launch_c<T, 2048>(a, x, y, st, epoch); break;
+        case 4096: e = csc_launch_c<T, 4096>(a, x, y, st, epoch); break;
         default: return hipErrorInvalidValue;
+    }
+    if (ordered) {
+        if (e == hipSuccess) e = hipEventRecord(a->ev_last, st);
+        return e;
     }
     if (e != hipSuccess || !two_phase) return e;
     if (assign)
@@ -314,6 +399,10 @@ static int csc_plan_build(spal_csc *a) {
     if (a->d_windows) { SPAL_HIP_TRY(dev_free(a->d_windows)); a->d_windows = nullptr; }
     if (a->d_chunk_ptr) { SPAL_HIP_TRY(dev_free(a->d_chunk_ptr)); a->d_chunk_ptr = nullptr; }
     if (a->d_chunk_blk) { SPAL_HIP_TRY(dev_free(a->d_chunk_blk)); a->d_chunk_blk = nullptr; }
+    if (a->d_prev_hi) { SPAL_HIP_TRY(dev_free(a->d_prev_hi)); a->d_prev_hi = nullptr; }
+    if (a->d_flags) { SPAL_HIP_TRY(dev_free(a->d_flags)); a->d_flags = nullptr; }
+    a->ordered = 0;
+    a->epoch = 0;
     a->windows_entries = 0;
     a->all_lds = 0;
     a->nchunks = 0;
@@ -392,6 +481,32 @@ static int csc_plan_build(spal_csc *a) {
             for (uint32_t c = desc[b].x / kCscChunk; c <= (desc[b].x + desc[b].y - 1) / kCscChunk; ++c)
                 cover[fill[c]++] = b;
         }
+        // Neighbour hand-off instead of atomics: every super-tile in LDS mode, windows ascending, and a window may
+        // overlap its neighbours' only (hi[b-1] <= lo[b+1]); rows no window covers are zero-filled by the next
+        // super-tile (the last one takes the tail), which must stay a small job.  A super-tile without entries
+        // becomes an empty window at the end of the previous one.
+        if (all_lds) {
+            std::vector<uint32_t> prev_hi(a->nblocks, 0);
+            bool ok = true;
+            uint32_t lo1 = 0, hi1 = 0, hi2 = 0;     // window of b - 1, end of the window of b - 2
+            const uint64_t fill_cap = 4ull * kCscCols;
+            for (uint32_t b = 0; b < a->nblocks && ok; ++b) {
+                if (desc[b].z != kCscModeLds) desc[b] = make_uint4(hi1, 0, kCscModeLds, 0);
+                const uint32_t lo = desc[b].x, hi = lo + desc[b].y;
+                prev_hi[b] = hi1;
+                ok = lo >= lo1 && hi >= hi1 && lo >= hi2 && (lo <= hi1 || (uint64_t)(lo - hi1) <= fill_cap);
+                hi2 = hi1; lo1 = lo; hi1 = hi;
+            }
+            if (ok && a->nrows - hi1 > fill_cap) ok = false;
+            if (ok) {
+                SPAL_HIP_TRY(dev_alloc((void **)&a->d_prev_hi, (size_t)a->nblocks * 4));
+                SPAL_HIP_TRY(dev_alloc((void **)&a->d_flags, ((size_t)a->nblocks + 1) * 4));
+                SPAL_HIP_TRY(hipMemcpyAsync(a->d_prev_hi, prev_hi.data(), (size_t)a->nblocks * 4, hipMemcpyHostToDevice, a->stream));
+                SPAL_HIP_TRY(hipMemsetAsync(a->d_flags, 0, ((size_t)a->nblocks + 1) * 4, a->stream));
+                SPAL_HIP_TRY(hipStreamSynchronize(a->stream));   // prev_hi goes out of scope
+                a->ordered = 1;
+            }
+        }
         a->windows_entries = slot;
         if (slot) {
             SPAL_HIP_TRY(dev_alloc(&a->d_windows, (size_t)slot * a->elem_size));
@@ -453,6 +568,7 @@ int csc_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, 
         a->d_colptr = nullptr; a->d_rowind = nullptr; a->d_values = nullptr;  // stay with the caller
         (void)dev_free(a->d_meta); (void)dev_free(a->d_desc);
         (void)dev_free(a->d_windows); (void)dev_free(a->d_chunk_ptr); (void)dev_free(a->d_chunk_blk);
+        (void)dev_free(a->d_prev_hi); (void)dev_free(a->d_flags);
         stream_release(a->stream);
         delete a;
         return st;
@@ -480,6 +596,9 @@ static void csc_free(spal_csc *a) {
     (void)dev_free(a->d_windows);
     (void)dev_free(a->d_chunk_ptr);
     (void)dev_free(a->d_chunk_blk);
+    (void)dev_free(a->d_prev_hi);
+    (void)dev_free(a->d_flags);
+    if (a->ev_last) (void)hipEventDestroy(a->ev_last);
     (void)dev_free(a->d_x);
     (void)dev_free(a->d_y);
     stream_release(a->stream);
@@ -723,7 +842,8 @@ int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value) {
         // 0 (default) = window rows flushed with global atomics; 1 = LDS windows stored per super-tile,
         // then an ordered reduce (no global atomics; measured 89.6 vs 80.1 us at config 4: the LDS
         // atomics, not the flush, bound the kernel)
-        if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "flush must be 0 or 1");
+        // 2 = global atomics even where the plan allows the neighbour hand-off (0: hand-off when allowed)
+        if (value < 0 || value > 2) return fail(SPAL_ERR_INVALID_ARGUMENT, "flush must be 0, 1 or 2");
         a->flush = (int)value;
         return SPAL_OK;
     }
@@ -753,7 +873,8 @@ int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len) {
              a->kernel == 2 ? "transposed_csr" : a->lds_entries ? "lds_privatised_scatter" : "atomic_scatter",
              a->cols_per_block, a->nblocks,
              a->lanes_per_col, (unsigned long long)a->lds_entries * (unsigned long long)a->elem_size,
-             a->lds_col_fraction, (a->flush && a->d_windows) ? "windows_then_reduce" : "global_atomics",
+             a->lds_col_fraction, (a->flush == 1 && a->d_windows) ? "windows_then_reduce"
+                                  : (a->flush == 0 && a->ordered) ? "neighbour_handoff" : "global_atomics",
              (unsigned long long)a->windows_entries * (unsigned long long)a->elem_size);
     return SPAL_OK;
 }

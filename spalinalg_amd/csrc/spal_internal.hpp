@@ -207,7 +207,15 @@ struct spal_csc {
     uint32_t *d_chunk_ptr = nullptr, *d_chunk_blk = nullptr;  // CSR-like cover lists: chunk -> super-tiles
     uint32_t nchunks = 0;
     uint64_t windows_entries = 0;
-    int flush = 0;                 // 0 = global atomics per window row (default: measured faster), 1 = windows + ordered reduce
+    int flush = 0;                 // 0 = neighbour hand-off when the plan allows it (else global atomics), 1 = windows + ordered reduce, 2 = global atomics
+    // neighbour hand-off (`ordered`): row windows ascend and only adjacent super-tiles overlap, so every row of y is
+    // STORED by the first super-tile that covers it and updated by the next one after a flag: no memset, no atomics
+    int ordered = 0;
+    uint32_t *d_prev_hi = nullptr; // per super-tile: end of the previous super-tile's window (where its own rows begin)
+    uint32_t *d_flags = nullptr;   // per super-tile: the launch number whose owned rows are in y; [nblocks] = spin bound hit
+    uint32_t epoch = 0;            // launch number (guarded by mu, with ev_last)
+    hipEvent_t ev_last = nullptr;  // launches of one handle run one after the other (they share d_flags)
+    std::mutex mu_launch;          // ... chained under this lock
     int all_lds = 0;               // every super-tile with entries is in LDS mode: y needs no memset
     int cols_per_block = 1024;     // columns of a super-tile: 4096 / 2048 / 1024 (the widest whose row windows fit LDS)
     int user_cols = 0;             // option "cols_per_block" (0 = automatic)

@@ -149,6 +149,100 @@ def test_csc_lds_and_global_paths(oracle):
         dev.set_option("cols_per_block", 512)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_csc_neighbour_handoff_flush(oracle, dtype):
+    """Banded columns: row windows ascend and only neighbours overlap, so the scatter kernel stores every row of y once
+    and hands the shared rows to the next super-tile behind a flag -- no memset, no global atomics.  Against the oracle
+    and against the two other flush forms; y pre-filled with NaN (every row must be written, also rows that no column
+    touches); launches back to back and on several streams (they chain on the handle's event); under graph capture the
+    atomics form runs."""
+    import torch
+    tol = 1e-10 if dtype == np.float64 else 1e-4
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    n = 300_000
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, 33, dtype=dtype)
+    # empty rows at the head, in the middle (wider than a window overlap) and at the tail; a stretch of empty columns
+    keep = np.ones(n, bool)
+    keep[:700] = False
+    keep[150_000:153_000] = False
+    keep[-1200:] = False
+    lens = np.diff(rp.astype(np.int64)) * keep
+    sel = np.repeat(keep, np.diff(rp.astype(np.int64)))
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    ci, va = ci[sel], va[sel]
+    colsel = (ci < 40_000) | (ci >= 49_000)            # columns 40 000 ... 48 999 hold nothing: super-tiles without entries
+    lens = np.bincount(np.repeat(np.arange(n), np.diff(rp.astype(np.int64)))[colsel], minlength=n)
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    ci, va = ci[colsel], va[colsel]
+    cp, ri, cv = oracle.transpose(n, n, rp, ci, va)
+    x = synth.vector(n, dtype=dtype)
+    y_ref = oracle.csc_spmv(n, cp, ri, cv, x)
+    bound = oracle.csr_abs_bound(rp, ci, va, x)
+    dev = sp.CscMatrix(n, n, cp, ri, cv).device()
+    dev.set_option("kernel", 1)
+    xt = torch.from_numpy(x).cuda()
+    for cols in (0, 1024, 2048, 4096):
+        dev.set_option("cols_per_block", cols)
+        d = dev.describe()
+        # (windows of 1024 / 2048 columns of this band reach beyond their neighbours: those widths keep the atomics)
+        handoff = cols in (0, 4096)
+        assert d["flush"] == ("neighbour_handoff" if handoff else "global_atomics") and d["lds_col_fraction"] > 0.95, d
+        yt = torch.full((n,), float("nan"), dtype=tdt, device="cuda")
+        for _ in range(3):                                   # back to back: launch numbers 1, 2, 3 in the flags
+            dev.spmv_torch(xt, yt)
+        torch.cuda.synchronize()
+        assert_spmv_close(yt.cpu().numpy(), y_ref, bound, tol)
+        assert np.all(yt.cpu().numpy()[:700] == 0) and np.all(yt.cpu().numpy()[-1200:] == 0)
+        for flush, name in ((2, "global_atomics"), (1, "windows_then_reduce"),
+                            (0, "neighbour_handoff" if handoff else "global_atomics")):
+            dev.set_option("flush", flush)
+            assert dev.describe()["flush"] == name
+            assert_spmv_close(dev.spmv(x), y_ref, bound, tol)
+    dev.set_option("cols_per_block", 0)
+    assert dev.describe()["flush"] == "neighbour_handoff"
+    # several streams at once on one handle
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = [torch.full((n,), float("nan"), dtype=tdt, device="cuda") for _ in streams]
+    torch.cuda.synchronize()
+    for _ in range(5):
+        for st, out in zip(streams, outs):
+            with torch.cuda.stream(st):
+                dev.spmv_torch(xt, out)
+    torch.cuda.synchronize()
+    for out in outs:
+        assert_spmv_close(out.cpu().numpy(), y_ref, bound, tol)
+    # captured into a graph: the hand-off's event chain cannot be captured, the atomics form runs (and replays)
+    g = torch.cuda.CUDAGraph()
+    yg = torch.zeros(n, dtype=tdt, device="cuda")
+    cap = torch.cuda.Stream()
+    with torch.cuda.stream(cap):
+        dev.spmv_torch(xt, yg)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=cap):
+            dev.spmv_torch(xt, yg)
+    for _ in range(2):
+        yg.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        assert_spmv_close(yg.cpu().numpy(), y_ref, bound, tol)
+    dev.spmv_torch(xt, yg)            # and the hand-off again afterwards
+    torch.cuda.synchronize()
+    assert_spmv_close(yg.cpu().numpy(), y_ref, bound, tol)
+
+
+def test_csc_handoff_not_taken_when_windows_interleave(oracle):
+    """rows anywhere: every super-tile's window covers most rows -- atomics (or the transposed route), as before"""
+    rng = np.random.default_rng(5)
+    n = 20_000
+    rp, ci, va = random_csr(rng, n, n, density=6.0 / n)
+    cp, ri, cv = oracle.transpose(n, n, rp, ci, va)
+    x = synth.vector(n)
+    dev = sp.CscMatrix(n, n, cp, ri, cv).device()
+    dev.set_option("kernel", 1)
+    assert dev.describe()["flush"] == "global_atomics"
+    assert_spmv_close(dev.spmv(x), oracle.csc_spmv(n, cp, ri, cv, x), oracle.csr_abs_bound(rp, ci, va, x), 1e-10)
+
+
 def test_csc_config4(oracle):
     """BASELINE config 4: CSC of the config-2 matrix, 1M x 1M."""
     n = 1_000_000

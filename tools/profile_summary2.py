@@ -86,8 +86,9 @@ def main():
     d2 = bench_json("fetch2")
     k2 = "csr_spmv_slide" if d2["config"]["plan"]["slide"] else "csr_spmv_stream"
     t.append(traffic_of("2", {k2: 1}, "config2_banded_f64_n1", f"bench.py --config 2 --copies 1, kernel {k2} (188 MB working set: the Infinity Cache serves part of it)"))
-    t.append(traffic_of("4", {"csc_spmv_scatter": 1, "__amd_rocclr_fillBufferAligned": 1}, "config4_scatter_f64",
-                        "bench.py --config 4 --copies 1: csc_spmv_scatter + the y memset"))
+    t.append(traffic_of("4", {"csc_spmv_scatter": 1, "fill_zero": 1}, "config4_scatter_f64",
+                        "bench.py --config 4 --copies 1: csc_spmv_scatter (neighbour hand-off: y is stored, no zero fill; "
+                        "a fill_zero line appears only where the atomics flush runs)"))
     f5 = pmc_means("fetch5")
     # kernels of ONE assembly: both radix scatters, the second pass's histogram and its scan, the group kernel, the
     # planning of the resulting CSR handle.  Not counted: what runs once per handle at upload (coo_group_hist,
