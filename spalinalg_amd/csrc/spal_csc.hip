@@ -162,7 +162,6 @@ __global__ __launch_bounds__(kCscBlock, kCscBlock >= 1024 ? 1 : 2) void csc_spmv
             }
             if (!more) break;
             batch0 = next0;
-#pragma unroll
             for (uint32_t u = 0; u < U; ++u) { v[u] = vn[u]; m[u] = mn[u]; }
         }
         __syncthreads();
