@@ -134,7 +134,9 @@ int spal_csr_download_f32(spal_csr_t a, uint64_t *rowptr, uint64_t *colind,
  * and its ring-addressed x window for band-like plans), "slide_on" (0 / 1:
  * launch it), "uniform_rows" (0 / 1: super-tiles whose rows all have one length
  * do not read rowptr), "prefetch" (1 / 2 tiles of loads ahead), "place_tries"
- * (autotune) (stream kernel).  Unknown key or a value
+ * (autotune), "split_tiles" (1 default / 0: the sliding kernel computes tiles
+ * above 1024 entries whose halves fit in two passes instead of leaving them to
+ * the overflow kernel) (stream kernel).  Unknown key or a value
  * the kernels are not instantiated for: SPAL_ERR_INVALID_ARGUMENT. */
 int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value);
 /* Setup-time autotune: runs the planned kernel's variants (the stream kernel

@@ -222,8 +222,23 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_slide(
             if (r0 + lane < nrows) y[r0 + lane] = sacc + T(t[K].rp1 - t[K].rp0);
         } else
 #endif
-        if (r0 < nrows && !((skip >> wave) & 1u))
+        if (r0 < nrows && !((skip >> wave) & 1u)) {
             stream_compute<T, RPT, false>(t[K], xw, wmax, prod, y, r0, nrows, lane, nt_store, flags);
+        } else if (r0 < nrows && ((d.y >> (20u + wave)) & 1u)) {
+            // More than the strip's 1024 entries, but each half of the rows fits (the plan checked): two passes
+            // through the strip, rows [r0, rm) then [rm, re) -- same loads, products and left-to-right sums as any
+            // tile, so these rows stay bit-identical too.  The slot's registers hold the tile's first 1024 entries,
+            // which nobody needs: they take the halves.  (Rare: the loads are waited for in place.)
+            const uint32_t re = min(r0 + (uint32_t)RPT, nrows), rm = min(r0 + (uint32_t)RPT / 2u, re);
+            const uint32_t eb = rowptr[r0], em = rowptr[rm], ee = rowptr[re];
+            slide_tile_load<T, RPT, S, false>(t[K], rowptr, col16, vals, r0, rm, eb, em, lane, 0u);
+            stream_compute<T, RPT, false>(t[K], xw, wmax, prod, y, r0, rm, lane, nt_store, flags);
+            if (rm < re) {
+                __builtin_amdgcn_wave_barrier();   // the strip is read by the first half's sums until here
+                slide_tile_load<T, RPT, S, false>(t[K], rowptr, col16, vals, rm, re, em, ee, lane, 0u);
+                stream_compute<T, RPT, false>(t[K], xw, wmax, prod, y, rm, re, lane, nt_store, flags);
+            }
+        }
 #pragma unroll
         for (uint32_t k = 0; k < kSlideAsyncVecs; ++k) {
             const uint32_t j = threadIdx.x + k * kStreamBlock;

@@ -464,13 +464,17 @@ __global__ __launch_bounds__(256) void csr_encode_col16(const uint32_t *__restri
 // ---- plan of the sliding-window kernel (csr_slide.hpp) -----------------------------------------------------
 // One workgroup per STEP of SR = 4 * rpt rows (SR <= 256: a row per thread): out[i] = {first column, one past the
 // last column (0: the step stores nothing), 1 + the length of every row if they are all equal else 0, the most
-// 128-entry steps one of its four tiles needs}.
+// 128-entry steps one of its four tiles needs | a bit per tile << 8 that can go through the strip in two HALVES}.
+// A tile above the strip's 1024 entries whose halves (rpt / 2 rows each) both fit and that holds no row longer
+// than row_max is such a tile: the sliding kernel takes it in two passes instead of leaving it to
+// csr_spmv_overflow (rows of 1 ... 27 entries: 2 % of the 64-row tiles).  Its halves count for the step number,
+// a tile that is left to the overflow kernel does not.
 __global__ __launch_bounds__(256) void csr_slide_scan(const uint32_t *__restrict__ rowptr,
                                                       const uint32_t *__restrict__ colind, uint32_t nrows,
-                                                      uint32_t rpt, uint4 *__restrict__ out) {
-    __shared__ uint32_t s_min, s_max, s_ragged, s_steps;
+                                                      uint32_t rpt, uint32_t row_max, uint4 *__restrict__ out) {
+    __shared__ uint32_t s_min, s_max, s_ragged, s_steps, s_long, s_split;
     const uint32_t t = threadIdx.x, SR = 4u * rpt;
-    if (t == 0) { s_min = 0xffffffffu; s_max = 0u; s_ragged = 0u; s_steps = 0u; }
+    if (t == 0) { s_min = 0xffffffffu; s_max = 0u; s_ragged = 0u; s_steps = 0u; s_long = 0u; s_split = 0u; }
     __syncthreads();
     const uint32_t row0 = blockIdx.x * SR, row1 = min(row0 + SR, nrows);
     const uint32_t len0 = rowptr[row0 + 1] - rowptr[row0];
@@ -481,13 +485,23 @@ __global__ __launch_bounds__(256) void csr_slide_scan(const uint32_t *__restrict
             atomicMax(&s_max, colind[a1 - 1] + 1u);
         }
         if (a1 - a0 != len0) s_ragged = 1u;
-    }
-    if (t < 4u && row0 + t * rpt < row1) {
-        const uint32_t b = rowptr[row0 + t * rpt], e = rowptr[min(row0 + (t + 1u) * rpt, row1)];
-        atomicMax(&s_steps, (e - (b & ~1u) + 127u) >> 7);
+        if (a1 - a0 > row_max) atomicOr(&s_long, 1u << (t / rpt));
     }
     __syncthreads();
-    if (t == 0) out[blockIdx.x] = make_uint4(s_min, s_max, (s_ragged == 0u && len0 < 4095u) ? len0 + 1u : 0u, s_steps);
+    if (t < 4u && row0 + t * rpt < row1) {
+        const uint32_t rb = row0 + t * rpt, re = min(rb + rpt, row1), rm = min(rb + rpt / 2u, re);
+        const uint32_t b = rowptr[rb], m = rowptr[rm], e = rowptr[re];
+        uint32_t steps = (e - (b & ~1u) + 127u) >> 7;
+        if (stream_tile_overflows(b, e)) {
+            const bool halves = rpt >= 2u && !((s_long >> t) & 1u) && !stream_tile_overflows(b, m) && !stream_tile_overflows(m, e);
+            steps = halves ? max((m - (b & ~1u) + 127u) >> 7, (e - (m & ~1u) + 127u) >> 7) : 0u;
+            if (halves) atomicOr(&s_split, 1u << t);
+        }
+        atomicMax(&s_steps, steps);
+    }
+    __syncthreads();
+    if (t == 0)
+        out[blockIdx.x] = make_uint4(s_min, s_max, (s_ragged == 0u && len0 < 4095u) ? len0 + 1u : 0u, s_steps | (s_split << 8));
 }
 
 // Decides whether the sliding kernel can run this stream plan and, if so, builds its step descriptors.
@@ -499,6 +513,9 @@ static int slide_plan(spal_csr *a, uint32_t R, uint32_t rpt, const std::vector<u
     p.slide = 0;
     p.ring_pages = 0;
     if (a->d_sdesc) { SPAL_HIP_TRY(dev_free(a->d_sdesc)); a->d_sdesc = nullptr; }
+    if (a->d_ovtiles_slide) { SPAL_HIP_TRY(dev_free(a->d_ovtiles_slide)); a->d_ovtiles_slide = nullptr; }
+    a->n_ovtiles_slide = 0;
+    a->n_split_tiles = 0;
     const uint32_t V = 16u / (uint32_t)a->elem_size;
     if (p.slide_user == 0 || p.tiles_per_wave != 4 || rpt > 64u || p.skew || a->ncols < kPageCols || a->nnz == 0) return SPAL_OK;
     for (const uint4 &d : desc)
@@ -508,7 +525,7 @@ static int slide_plan(spal_csr *a, uint32_t R, uint32_t rpt, const std::vector<u
     uint4 *d_scan = nullptr;
     SPAL_HIP_TRY(dev_alloc((void **)&d_scan, (size_t)nsteps * sizeof(uint4)));
     hipLaunchKernelGGL(csr_slide_scan, dim3(nsteps), dim3(256), 0, a->stream, a->d_rowptr, a->d_colind,
-                       (uint32_t)a->nrows, rpt, d_scan);
+                       (uint32_t)a->nrows, rpt, (uint32_t)p.stream_row_max, d_scan);
     std::vector<uint4> scan(nsteps);
     hipError_t e = hipMemcpyAsync(scan.data(), d_scan, (size_t)nsteps * sizeof(uint4), hipMemcpyDeviceToHost, a->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
@@ -516,6 +533,8 @@ static int slide_plan(spal_csr *a, uint32_t R, uint32_t rpt, const std::vector<u
     SPAL_HIP_TRY(e);
     // windows: a step that stores nothing keeps its predecessor's window (nothing enters)
     std::vector<uint2> sd(nsteps);
+    std::vector<uint32_t> left_over;     // first rows of the tiles csr_spmv_overflow computes when the sliding kernel runs
+    uint32_t n_split = 0;
     uint32_t S = 1, ulen = scan[0].z;
     bool uni = true;
     uint32_t pf = 0, pn = 1;
@@ -526,21 +545,23 @@ static int slide_plan(spal_csr *a, uint32_t R, uint32_t rpt, const std::vector<u
         }
         sd[i] = make_uint2(pf, pn);
         uni = uni && scan[i].z != 0u && scan[i].z == ulen;
-        // tiles the stream kernels skip (csr_spmv_overflow) do not bound S
+        // tiles the stream kernels skip: those that fit the strip in two halves stay with the sliding kernel (split),
+        // the others go to csr_spmv_overflow and do not bound S
         const uint32_t tile0 = i * 4u;
         uint32_t sk = 0;
         for (uint32_t w = 0; w < 4u; ++w) {
             const uint32_t tl = tile0 + w, b = tl / 16u;
             if (b < skip.size() && ((skip[b] >> (tl % 16u)) & 1u)) sk |= 1u << w;
         }
-        sd[i].y |= sk << 8;
-        if (sk != 0xfu) S = std::max(S, scan[i].w);
+        const uint32_t sp = p.split_tiles_on ? (sk & ((scan[i].w >> 8) & 0xfu)) : 0u;
+        sd[i].y |= (sk << 8) | (sp << 20);
+        S = std::max(S, scan[i].w & 0xffu);
+        for (uint32_t w = 0; w < 4u; ++w) {
+            if ((sp >> w) & 1u) ++n_split;
+            else if ((sk >> w) & 1u) left_over.push_back((tile0 + w) * rpt);
+        }
     }
-    if (S > (uint32_t)kStreamSteps) {
-        // an unskipped tile of more than 1024 entries cannot be: stream_tile_overflows marks those.  (A step whose
-        // tiles are partly skipped reports the largest of all four: clamp, the skipped ones are not computed.)
-        S = (uint32_t)kStreamSteps;
-    }
+    if (S > (uint32_t)kStreamSteps) S = (uint32_t)kStreamSteps;   // (cannot be: the scan counts fitting tiles and halves only)
     // ring size: what the largest super-tile stages, and room for the pages that enter with the next step
     const uint32_t page_bytes = kPageCols * (uint32_t)a->elem_size;
     const uint32_t strips = (uint32_t)kStreamWaves * (uint32_t)stream_strip<false>() * (uint32_t)a->elem_size;
@@ -568,7 +589,13 @@ static int slide_plan(spal_csr *a, uint32_t R, uint32_t rpt, const std::vector<u
     }
     SPAL_HIP_TRY(dev_alloc((void **)&a->d_sdesc, (size_t)nsteps * sizeof(uint2)));
     SPAL_HIP_TRY(hipMemcpyAsync(a->d_sdesc, sd.data(), (size_t)nsteps * sizeof(uint2), hipMemcpyHostToDevice, a->stream));
-    SPAL_HIP_TRY(hipStreamSynchronize(a->stream));   // `sd` goes out of scope
+    a->n_ovtiles_slide = (uint32_t)left_over.size();
+    a->n_split_tiles = n_split;
+    if (!left_over.empty()) {
+        SPAL_HIP_TRY(dev_alloc((void **)&a->d_ovtiles_slide, left_over.size() * 4));
+        SPAL_HIP_TRY(hipMemcpyAsync(a->d_ovtiles_slide, left_over.data(), left_over.size() * 4, hipMemcpyHostToDevice, a->stream));
+    }
+    SPAL_HIP_TRY(hipStreamSynchronize(a->stream));   // `sd`, `left_over` go out of scope
     p.slide = 1;
     p.ring_pages = (int)NP;
     p.slide_steps = nsteps;
@@ -713,32 +740,40 @@ static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, voi
     return hipGetLastError();
 }
 
-// rows of the tiles the stream kernels skipped (more than 1024 entries in one tile)
+// rows of the tiles the stream kernels skipped (more than 1024 entries in one tile, or a very long row)
 template <typename T>
-static hipError_t launch_overflow(const spal_csr *a, const void *x, void *y, hipStream_t st) {
-    hipLaunchKernelGGL(csr_spmv_overflow<T>, dim3(a->n_ovtiles), dim3(kStreamBlock), 0, st, a->d_rowptr,
-                       a->d_colind, (const T *)a->d_values, (const T *)x, (T *)y, a->d_ovtiles + 1,
-                       a->n_ovtiles, (uint32_t)std::min(a->plan.rows_per_tile, 64), (uint32_t)a->nrows);
+static hipError_t launch_overflow(const spal_csr *a, const void *x, void *y, hipStream_t st, const uint32_t *tiles,
+                                  uint32_t ntiles) {
+    hipLaunchKernelGGL(csr_spmv_overflow<T>, dim3(ntiles), dim3(kStreamBlock), 0, st, a->d_rowptr,
+                       a->d_colind, (const T *)a->d_values, (const T *)x, (T *)y, tiles,
+                       ntiles, (uint32_t)std::min(a->plan.rows_per_tile, 64), (uint32_t)a->nrows);
     return hipGetLastError();
 }
 
 template <typename T>
 static hipError_t launch_stream_main(const spal_csr *a, const void *x, void *y, hipStream_t st);
 
+static bool slide_runs(const spal_csr *a, const void *x) {   // (its page loads are 16-byte vectors of x)
+    return a->plan.slide && a->plan.slide_on && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+}
 
 template <typename T>
 static hipError_t launch_stream(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     hipError_t e = launch_stream_main<T>(a, x, y, st);
     if (e == hipSuccess && a->n_ptiles && panel_runs(a, x)) e = launch_panel(a, x, y, st);
-    if (e == hipSuccess && a->n_ovtiles) e = launch_overflow<T>(a, x, y, st);
+    // the sliding kernel keeps the tiles that fit the strip in halves: a shorter list is left over
+    if (e == hipSuccess && slide_runs(a, x)) {
+        if (a->n_ovtiles_slide) e = launch_overflow<T>(a, x, y, st, a->d_ovtiles_slide, a->n_ovtiles_slide);
+    } else if (e == hipSuccess && a->n_ovtiles) {
+        e = launch_overflow<T>(a, x, y, st, a->d_ovtiles + 1, a->n_ovtiles);
+    }
     return e;
 }
 
 template <typename T>
 static hipError_t launch_stream_main(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     const CsrPlan &p = a->plan;
-    // the sliding-window kernel (its page loads are 16-byte vectors of x)
-    if (p.slide && p.slide_on && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) return launch_slide(a, x, y, st);
+    if (slide_runs(a, x)) return launch_slide(a, x, y, st);   // the sliding-window kernel
     if (p.tiles_per_wave == 8) return launch_stream_tpw<T, 8, 64>(a, x, y, st);  // (64-row tiles only)
     // two tiles of loads ahead: instantiated for the plain form of the 64- / 32- / 16-row tiles without skew
     if (p.prefetch == 2 && !p.persistent && !p.skew) {
@@ -1267,6 +1302,7 @@ static void csr_free(spal_csr *a) {
     (void)dev_free(a->d_pages);
     (void)dev_free(a->d_ovtiles);
     (void)dev_free(a->d_sdesc);
+    (void)dev_free(a->d_ovtiles_slide);
     (void)dev_free(a->d_ptiles);
     (void)dev_free(a->d_pwin);
     (void)dev_free(a->d_x);
@@ -1765,6 +1801,11 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
     } else if (!strcmp(key, "slide_on")) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "slide_on must be 0 or 1");
         p.slide_on = (int)value;
+    } else if (!strcmp(key, "split_tiles")) {
+        // sliding kernel: tiles above 1024 entries whose two halves fit the strip are computed in two passes (1,
+        // default) or left to the overflow kernel like every other skipped tile (0)
+        if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "split_tiles must be 0 or 1");
+        p.split_tiles_on = (int)value;
     } else if (!strcmp(key, "place_tries")) {
         // autotune: fresh allocations tried for the values array (0 = leave it where it is)
         if (value < 0 || value > 16) return fail(SPAL_ERR_INVALID_ARGUMENT, "place_tries must be in [0, 16]");
@@ -1826,17 +1867,20 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "\"rows_per_block\": %d, \"rows_per_tile\": %d, \"blocks\": %u, \"threads_per_block\": %d, \"lds_x\": %d, "
              "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f, "
              "\"overflow_tiles\": %u, \"skew\": %d, \"persistent\": %d, \"nt_store\": %d, \"uniform_row_fraction\": %.4f, "
-             "\"prefetch\": %d, \"slide\": %d, \"ring_pages\": %d, \"tile_steps\": %d, \"panel_tiles\": %u, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f], \"placement_us\": [%.1f, %.1f], \"placement_tries\": %d, \"addr\": [\"%llx\", \"%llx\", \"%llx\"]}",
+             "\"prefetch\": %d, \"slide\": %d, \"ring_pages\": %d, \"tile_steps\": %d, \"split_tiles\": %u, \"panel_tiles\": %u, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f], \"placement_us\": [%.1f, %.1f], \"placement_tries\": %d, \"addr\": [\"%llx\", \"%llx\", \"%llx\"]}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, (p.kernel == 2 || p.vec_col16) ? 16 : 32,
              p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
              p.rows_per_block, p.kernel == 2 ? p.rows_per_tile : 0, p.nblocks, p.threads, p.lds_x,
              (unsigned long long)p.lds_entries * (unsigned long long)a->elem_size, p.lds_row_fraction,
-             p.stream_row_fraction, p.kernel == 2 ? a->n_ovtiles : 0u, (p.kernel == 2 && p.skew) ? 1 : 0,
+             p.stream_row_fraction,
+             p.kernel == 2 ? ((p.slide && p.slide_on) ? a->n_ovtiles_slide : a->n_ovtiles) : 0u,   // (tiles the overflow kernel runs)
+             (p.kernel == 2 && p.skew) ? 1 : 0,
              (p.kernel == 2 && p.persistent && p.tiles_per_wave == 4) ? 1 : 0,
              (p.kernel == 2 && p.nt_store) ? 1 : 0, p.kernel == 2 ? p.uniform_row_fraction : 0.0,
              p.kernel == 2 ? p.prefetch : 0, (p.kernel == 2 && p.slide && p.slide_on) ? 1 : 0,
              p.kernel == 2 ? p.ring_pages : 0, (p.kernel == 2 && p.slide) ? p.slide_S : 0,
+             (p.kernel == 2 && p.slide && p.slide_on) ? a->n_split_tiles : 0u,
              (p.kernel == 2 && p.panel_on) ? a->n_ptiles : 0u,
              (double)a->tuned_us[0], (double)a->tuned_us[1],
              (double)a->tuned_us[2], (double)a->tuned_us[3], (double)a->place_us[0], (double)a->place_us[1],

@@ -130,6 +130,7 @@ struct CsrPlan {
     int slide_S = 0;         // 128-entry steps of the largest streamed tile: every tile issues that many loads
     int slide_uniform = 0;   // 1 + the length of every row when all streamed rows have one length (rowptr is not read), else 0
     int place_tries = 3;     // autotune: fresh allocations tried for the values array (see csr_autotune)
+    int split_tiles_on = 1;  // sliding kernel: tiles above 1024 entries whose halves fit go through the strip twice
     int diag = 0;            // ablation builds (-DSPAL_DIAG) only: parts of the stream kernel switched off
     int persistent_blocks = 0;    // its grid; 0 = what the device holds at once (LDS per workgroup decides: f64 band 512)
     int rows_per_block = 0;  // R
@@ -170,7 +171,9 @@ struct spal_csr {
     uint32_t *d_ptiles = nullptr;  // panel kernel: the super-tiles it takes
     uint2 *d_pwin = nullptr;       // ... and {first page, pages} of their column spans
     uint32_t n_ptiles = 0;
-    uint2 *d_sdesc = nullptr;      // sliding kernel: per step {first page, pages | skip << 8 | flags << 16}
+    uint2 *d_sdesc = nullptr;      // sliding kernel: per step {first page, pages | skip << 8 | flags << 16 | split << 20}
+    uint32_t *d_ovtiles_slide = nullptr;   // first rows of the tiles left to csr_spmv_overflow when the sliding kernel runs
+    uint32_t n_ovtiles_slide = 0, n_split_tiles = 0;   // ... and the number it takes itself, in two halves
     uint4 *d_desc = nullptr;       // per row block: Stream {first page / offset into d_pages, pages, mode, contiguous};
                                    // VectorLds {window base column, window length, mode, 0}
     uint64_t cap_entries = 0;      // allocated entries of d_colind / d_values (>= nnz + pad)

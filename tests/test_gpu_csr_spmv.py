@@ -805,10 +805,13 @@ def test_sliding_window_kernel_bit_identical(oracle, dtype, gen, rpt):
     d = dev.describe()
     assert d["kernel"] == "stream" and d["slide"] == 1 and d["ring_pages"] > 0 and d["stream_row_fraction"] > 0.95
     assert (d["uniform_row_fraction"] == 1.0) == (gen != "ragged")
-    # (ragged rows at 64 per tile: the few tiles above 1024 entries go to the overflow kernel, whose rows are
+    # (ragged rows at 64 per tile: the few tiles above 1024 entries are taken in halves by the sliding kernel; on the
+    #  one-super-tile-per-workgroup kernels of the option sweep below they go to the overflow kernel, whose rows are
     #  tree-summed -- those rows to rounding, all others bit for bit)
     exact = d["stream_row_fraction"] == 1.0
-    assert exact or (gen == "ragged" and rpt == 0 and d["overflow_tiles"] > 0)
+    assert exact or (gen == "ragged" and rpt == 0 and d["split_tiles"] > 0 and d["overflow_tiles"] == 0)
+    if not exact:
+        assert np.array_equal(dev.spmv(x), y_ref)      # the sliding kernel: every row bit for bit
     bound = None if exact else oracle.csr_abs_bound(rp, ci, va, x)
 
     def same(y):
@@ -972,3 +975,61 @@ def test_row_blocks_beyond_32_bit_entry_offsets(oracle, monkeypatch):
     one = sp.CsrMatrix(50_000, 50_000, rp, ci, va).device()
     assert one.describe()["kernel"] == "stream"      # (the limit is back: one block)
     one.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_sliding_kernel_takes_oversized_tiles_in_halves(oracle, dtype):
+    """Rows of 1 ... 27 entries: 2 % of the 64-row tiles hold more than the strip's 1024 entries.  The sliding kernel
+    computes those in two passes of 32 rows (bit-identical, like every streamed row) instead of leaving them to the
+    overflow kernel (tree sums); tiles with a very long row still go there."""
+    n = 300_000 + 41                      # (the last tile is a partial one)
+    rp, ci, va = synth.ragged_csr(n, n, 4096, 12, dtype=dtype)
+    x = synth.vector(n, dtype=dtype)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    bits = np.uint64 if dtype == np.float64 else np.uint32
+    dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    d = dev.describe()
+    assert d["slide"] == 1 and d["split_tiles"] > 20 and d["overflow_tiles"] == 0, d
+    assert np.array_equal(dev.spmv(x).view(bits), y_ref.view(bits))           # every row, bit for bit
+    dev.set_option("split_tiles", 0)
+    d0 = dev.describe()
+    assert d0["split_tiles"] == 0 and d0["overflow_tiles"] == d["split_tiles"], d0
+    bound = oracle.csr_abs_bound(rp, ci, va, x)
+    assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10 if dtype == np.float64 else 1e-4)
+    dev.set_option("split_tiles", 1)
+    dev.set_option("slide_on", 0)         # one super-tile per workgroup: the overflow kernel takes all of them
+    assert dev.describe()["overflow_tiles"] == d["split_tiles"]
+    assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10 if dtype == np.float64 else 1e-4)
+    dev.close()
+    # a few rows of 200 ... 900 entries on top: their tiles cannot be halved (a lane per row would crawl)
+    rng = np.random.default_rng(3)
+    lens = np.diff(rp.astype(np.int64))
+    heavy = np.sort(rng.choice(n, 40, replace=False))
+    cols = [ci[int(rp[r]):int(rp[r + 1])] for r in range(n)] if n < 1 else None
+    new_cols = {}
+    for r in heavy:
+        lo, hi = max(0, int(r) - 2000), min(n, int(r) + 2000)
+        new_cols[int(r)] = np.unique(np.concatenate([ci[int(rp[r]):int(rp[r + 1])],
+                                                     rng.integers(lo, hi, int(rng.integers(200, 900))).astype(np.uint64)]))
+        lens[r] = new_cols[int(r)].size
+    rp2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    ci2 = np.empty(int(rp2[-1]), np.uint64)
+    prev = 0
+    for r in heavy:
+        a0, a1 = int(rp[prev]), int(rp[r])
+        ci2[int(rp2[prev]):int(rp2[prev]) + (a1 - a0)] = ci[a0:a1]
+        ci2[int(rp2[r]):int(rp2[r + 1])] = new_cols[int(r)]
+        prev = int(r) + 1
+    ci2[int(rp2[prev]):] = ci[int(rp[prev]):]
+    va2 = rng.uniform(-1, 1, int(rp2[-1])).astype(dtype)
+    dev = sp.CsrMatrix(n, n, rp2, ci2, va2).device()
+    d = dev.describe()
+    assert d["slide"] == 1 and d["split_tiles"] > 20 and 0 < d["overflow_tiles"] <= 40, d
+    y_ref = oracle.csr_spmv(rp2, ci2, va2, x)
+    bound = oracle.csr_abs_bound(rp2, ci2, va2, x)
+    y = dev.spmv(x)
+    assert_spmv_close(y, y_ref, bound, 1e-10 if dtype == np.float64 else 1e-4)
+    differ = np.flatnonzero(y.view(bits) != y_ref.view(bits))
+    tiles = set((differ // 64).tolist())
+    assert tiles <= set((heavy // 64).tolist())     # only rows of the tiles with a long row may differ (tree sums)
+    dev.close()
