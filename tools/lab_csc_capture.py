@@ -3,12 +3,14 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import spalinalg_amd as sp, spal_synth as synth
-import oracle
+import scipy.sparse as sps
 n = 100_000
 rp, ci, va = synth.banded_csr(n, n, 14, 4096, 33)
-cp, ri, cv = oracle.transpose(n, n, rp, ci, va)
+m = sps.csr_matrix((va, ci.astype(np.int64), rp.astype(np.int64)), shape=(n, n)).tocsc()
+m.sort_indices()
+cp, ri, cv = m.indptr.astype(np.uint64), m.indices.astype(np.uint64), m.data
 x = synth.vector(n)
-y_ref = oracle.csc_spmv(n, cp, ri, cv, x)
+y_ref = m @ x
 xt = torch.from_numpy(x).cuda()
 for flush in (2, 1, 0):
     dev = sp.CscMatrix(n, n, cp, ri, cv).device()
