@@ -194,8 +194,15 @@ int spal_csc_download_f32(spal_csc_t a, uint64_t *colptr, uint64_t *rowind,
  * matrix is converted to CSR on the device once and the CSR kernels run
  * (deterministic; bit-identical to the reference's k-ascending order), 0 = auto
  * (= 2).  "lds" 0/1, "cols_per_block" (0 auto / 1024 / 2048 / 4096 columns per
- * super-tile), "flush" (0 global atomics / 1 window stores + ordered reduce)
- * tune kernel 1. */
+ * super-tile), "flush" tune kernel 1.  flush 0 (default): where the super-tiles'
+ * row windows ascend and overlap their neighbours' only (bands), every row of y
+ * is stored by the first super-tile that covers it and completed by the next one
+ * behind a flag -- no zero fill of y, no global atomics; launches of one handle
+ * are then chained by an event (any streams), and on a stream that is being
+ * captured into a graph the atomics form runs instead.  Otherwise, or with flush
+ * 2: y is zeroed and window rows are added with global atomics.  flush 1: windows
+ * stored per super-tile, then an ordered reduce.  spal_csc_describe reports the
+ * form in "flush". */
 int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value);
 /* as spal_csr_autotune_* for the transposed route (kernel 2); no-op for kernel 1 */
 int spal_csc_autotune_f64(spal_csc_t a, const double *x_dev, double *y_dev,

@@ -675,8 +675,18 @@ static int csc_spmv_host(spal_csc_t a, const T *x, uint64_t x_len, T *y, uint64_
     if (!a->d_y) SPAL_HIP_TRY(dev_alloc((void **)&a->d_y, a->nrows * sizeof(T)));
     SPAL_HIP_TRY(hipMemcpyAsync(a->d_x, x, a->ncols * sizeof(T), hipMemcpyHostToDevice, a->stream));
     SPAL_TRY(csc_launch(a, a->d_x, a->d_y, a->stream));
+    uint32_t gave_up = 0;   // neighbour hand-off: a super-tile hit its spin bound (never observed; see csc_spmv_scatter)
+    const bool handoff = a->kernel == 1 && a->flush == 0 && a->ordered && a->d_flags;
+    if (handoff)
+        SPAL_HIP_TRY(hipMemcpyAsync(&gave_up, a->d_flags + a->nblocks, 4, hipMemcpyDeviceToHost, a->stream));
     SPAL_HIP_TRY(hipMemcpyAsync(y, a->d_y, a->nrows * sizeof(T), hipMemcpyDeviceToHost, a->stream));
     SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
+    if (handoff && gave_up) {   // this handle keeps to the atomics flush from now on; the product is repeated
+        a->ordered = 0;
+        SPAL_TRY(csc_launch(a, a->d_x, a->d_y, a->stream));
+        SPAL_HIP_TRY(hipMemcpyAsync(y, a->d_y, a->nrows * sizeof(T), hipMemcpyDeviceToHost, a->stream));
+        SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
+    }
     return SPAL_OK;
 }
 
