@@ -997,6 +997,14 @@ def test_sliding_kernel_takes_oversized_tiles_in_halves(oracle, dtype):
     bound = oracle.csr_abs_bound(rp, ci, va, x)
     assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10 if dtype == np.float64 else 1e-4)
     dev.set_option("split_tiles", 1)
+    # x not 16-byte aligned: the launch falls back to one super-tile per workgroup, and with it to the full overflow list
+    import torch
+    xpad = torch.zeros(n + 2, dtype=torch.float64 if dtype == np.float64 else torch.float32, device="cuda")
+    off = 1 if dtype == np.float64 else 1        # 8 / 4 bytes past a 16-byte boundary
+    xpad[off:off + n] = torch.from_numpy(x).cuda()
+    assert xpad[off:].data_ptr() % 16 != 0
+    y_un = dev.spmv_torch(xpad[off:off + n]).cpu().numpy()
+    assert_spmv_close(y_un, y_ref, bound, 1e-10 if dtype == np.float64 else 1e-4)
     dev.set_option("slide_on", 0)         # one super-tile per workgroup: the overflow kernel takes all of them
     assert dev.describe()["overflow_tiles"] == d["split_tiles"]
     assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10 if dtype == np.float64 else 1e-4)
