@@ -11,7 +11,8 @@
 // order.
 //
 // Pipeline (device only; one read-back at the end: the output size and the groups' column spans):
-//   0. at upload (functions of the uploaded indices alone, for rows and for columns): the first radix pass's
+//   0. at upload (functions of the uploaded indices alone; by rows at upload, by columns with the first CSC
+//      assembly): the first radix pass's
 //      per-tile digit offsets; the offsets of the groups of 2^gbits consecutive rows (about a thousand entries
 //      each) in the row-sorted order, and the fullest group, which decides the LDS capacity of step 2
 //      (512 ... 2048 entries).
@@ -901,8 +902,8 @@ struct Assembled {
 };
 
 // The first radix pass of an assembly reads the uploaded triplets as they are, so its per-tile digit counts are
-// a function of the handle alone: counted and scanned once, when the triplets arrive (for rows and for columns:
-// CSR and CSC assemblies), instead of in every assembly.
+// a function of the handle alone: counted and scanned once, when the triplets arrive (for rows; for columns when the
+// first CSC assembly needs them), instead of in every assembly.
 static hipError_t coo_first_pass_offsets(spal_coo *c, bool by_cols, hipStream_t st) {
     const uint64_t len = c->len, n_major = by_cols ? c->ncols : c->nrows;
     if (len == 0) return hipSuccess;
@@ -969,6 +970,7 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
     }
 
     std::lock_guard<std::mutex> lock(c->mu);  // one assembly at a time per handle (shared workspace)
+    if (!c->d_gstart[by_cols ? 1 : 0]) SPAL_HIP_TRY(coo_first_pass_offsets(c, by_cols, st));   // first assembly in this orientation
     const CooWorkspace ws = coo_workspace_layout(len, nrows, sizeof(T));
     if (!c->d_work || c->work_bytes < ws.bytes) {
         if (c->d_work) { (void)dev_free(c->d_work); c->d_work = nullptr; }
@@ -1242,9 +1244,9 @@ static int coo_upload(int device, uint64_t nrows, uint64_t ncols, uint64_t len, 
         c->work_bytes = coo_workspace_layout(len, nrows, sizeof(T)).bytes;
         e = dev_alloc((void **)&c->d_work, c->work_bytes);
     }
-    // ... and the first radix pass's tile offsets, for both orientations (see coo_first_pass_offsets)
+    // ... and the first radix pass's tile offsets + the groups' offsets (see coo_first_pass_offsets)
+    // (by rows now; by columns when the first CSC assembly asks for it)
     if (e == hipSuccess && len) e = coo_first_pass_offsets(c, false, nullptr);
-    if (e == hipSuccess && len) e = coo_first_pass_offsets(c, true, nullptr);
     if (e != hipSuccess) {
         coo_free(c);
         return fail(e == hipErrorOutOfMemory ? SPAL_ERR_OUT_OF_MEMORY : SPAL_ERR_HIP,
