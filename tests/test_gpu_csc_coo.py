@@ -243,6 +243,55 @@ def test_csc_handoff_not_taken_when_windows_interleave(oracle):
     assert_spmv_close(dev.spmv(x), oracle.csc_spmv(n, cp, ri, cv, x), oracle.csr_abs_bound(rp, ci, va, x), 1e-10)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SPAL_FUZZ_SEEDS", "12"))))
+def test_csc_scatter_randomised_bands(oracle, seed):
+    """Random band-like CSC matrices (width, column fill, empty column stretches, sections whose rows jump back): whether
+    the plan hands rows from super-tile to super-tile or falls back to atomics, y (pre-filled with NaN) must be the
+    oracle's, for every super-tile width."""
+    import torch
+    rng = np.random.default_rng(4000 + seed)
+    dtype = np.float64 if seed % 3 else np.float32
+    nrows = int(rng.choice([6_000, 40_000, 150_000]))
+    ncols = int(nrows * rng.choice([0.5, 1.0, 1.7]))
+    width = int(rng.choice([64, 700, 3000, 9000]))
+    per_col = rng.integers(0, int(rng.choice([3, 12, 30])) + 1, ncols)
+    for _ in range(int(rng.integers(0, 4))):          # stretches of empty columns
+        a = int(rng.integers(0, ncols))
+        per_col[a:a + int(rng.integers(1, 6000))] = 0
+    centre = (np.arange(ncols) * (nrows / ncols)).astype(np.int64)
+    if seed % 4 == 3:                                 # a section whose rows jump back: windows no longer ascend
+        a = ncols // 2
+        centre[a:] = np.maximum(centre[a:] - nrows // 3, 0)
+    cols = np.repeat(np.arange(ncols, dtype=np.int64), per_col)
+    rows = np.clip(centre[cols] - width // 2 + rng.integers(0, width, cols.size), 0, nrows - 1)
+    key = np.unique(cols * nrows + rows)              # sorted by (column, row), duplicates dropped
+    cols, rows = key // nrows, key % nrows
+    cp = np.concatenate([[0], np.cumsum(np.bincount(cols, minlength=ncols))]).astype(np.uint64)
+    ri = rows.astype(np.uint64)
+    cv = rng.uniform(-1, 1, ri.size).astype(dtype)
+    x = rng.uniform(-1, 1, ncols).astype(dtype)
+    y_ref = oracle.csc_spmv(nrows, cp, ri, cv, x)
+    rp, ci, va = oracle.transpose(ncols, nrows, cp, ri, cv)     # rows of A, for the error bound
+    bound = oracle.csr_abs_bound(rp, ci, va.astype(np.float64), x.astype(np.float64))
+    tol = 1e-10 if dtype == np.float64 else 1e-4
+    dev = sp.CscMatrix(nrows, ncols, cp, ri, cv).device()
+    dev.set_option("kernel", 1)
+    xt = torch.from_numpy(x).cuda()
+    seen = set()
+    for cols_opt in (0, 1024, 2048, 4096):
+        dev.set_option("cols_per_block", cols_opt)
+        seen.add(dev.describe()["flush"])
+        for _ in range(2):
+            yt = torch.full((nrows,), float("nan"), dtype=xt.dtype, device="cuda")
+            dev.spmv_torch(xt, yt)
+        torch.cuda.synchronize()
+        assert_spmv_close(yt.cpu().numpy(), y_ref, bound, tol)
+    assert seen <= {"neighbour_handoff", "global_atomics"}
+    if seed % 4 != 3 and width <= 700 and ncols >= 20_000:
+        assert "neighbour_handoff" in seen       # a narrow ascending band: some super-tile width hands rows over
+    dev.close()
+
+
 def test_csc_config4(oracle):
     """BASELINE config 4: CSC of the config-2 matrix, 1M x 1M."""
     n = 1_000_000
