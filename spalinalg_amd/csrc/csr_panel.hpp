@@ -3,7 +3,7 @@
 // A band of 16 384 or 65 536 columns under 1024 rows spans 68 / 260 pages of x: more than the 24 (48 KB) a
 // workgroup stages beside its product strips.  csr_spmv_stream then gathers x from global memory / L2, 128-byte
 // lines for 8-byte reads: 31 % of the HBM roofline at W = 16 384.  Here the workgroup keeps the ENTRIES of its 16
-// tiles in registers (4 tiles per wave, loaded once, coalesced) and walks the window in panels of 40 pages (80 KB:
+// tiles in registers (4 tiles per wave, loaded once, coalesced; 16-bit columns relative to the span's first column) and walks the window in panels of 40 pages (80 KB:
 // the panel and the product strips, needed only after the last panel, share the workgroup's LDS): stage panel p in LDS, multiply every entry whose column lies in it (the product replaces the value in its
 // register), next panel.  Every entry belongs to exactly one panel, so after the last one all products exist; they
 // then go through the wave's LDS strip tile by tile and lane l sums row l left to right -- the reference's order
@@ -20,7 +20,7 @@ constexpr int kPanelTiles = 4;   // tiles a wave holds in registers (= the strea
 
 template <typename T, int RPT>
 __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_panel(
-    const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind, const T *__restrict__ vals,
+    const uint32_t *__restrict__ rowptr, const uint16_t *__restrict__ col16, const T *__restrict__ vals,
     const T *__restrict__ x, T *__restrict__ y, const uint32_t *__restrict__ ptiles, const uint2 *__restrict__ pwin,
     const uint4 *__restrict__ desc, uint32_t npanel_tiles, uint32_t nrows, uint32_t ncols, uint32_t panel_pages,
     uint32_t flags) {
@@ -50,10 +50,10 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_panel(
     uint32_t tb[kPanelTiles + 1];
 #pragma unroll
     for (int k = 0; k <= kPanelTiles; ++k) tb[k] = __builtin_amdgcn_readlane(tb_lane, k);
-    StreamTileG<T> t[kPanelTiles];
+    StreamTile<T> t[kPanelTiles];   // (16-bit columns, relative to the first column of the super-tile's span)
 #pragma unroll
     for (int k = 0; k < kPanelTiles; ++k)
-        stream_load_g<T, RPT>(t[k], rowptr, colind, vals, min(wrow + k * (uint32_t)RPT, row1), row1, tb[k], tb[k + 1], lane, ulen);
+        stream_load<T, RPT>(t[k], rowptr, col16, vals, min(wrow + k * (uint32_t)RPT, row1), row1, tb[k], tb[k + 1], lane, ulen);
 
     // the panels of the window, ascending.  (Staging panel p + 1 asynchronously -- LDS-DMA into a second buffer --
     // was measured and lost: twice the panels at half the size, 553 vs 476 us at W = 16 384; the pass over the
@@ -75,13 +75,13 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_panel(
             }
         }
         __syncthreads();
-        const uint32_t base = f * kPageCols, width = np * kPageCols;
+        const uint32_t base = p0 * kPageCols, width = np * kPageCols;   // (columns are relative to the span's first page)
 #pragma unroll
         for (int k = 0; k < kPanelTiles; ++k) {
 #pragma unroll
             for (int j = 0; j < kStreamSteps; ++j) {
                 if ((uint32_t)j < t[k].steps) {           // uniform
-                    const uint32_t c0 = t[k].c[j].x - base, c1 = t[k].c[j].y - base;
+                    const uint32_t c0 = (t[k].c[j] & 0xffffu) - base, c1 = (t[k].c[j] >> 16) - base;
                     const T x0 = xw[min(c0, width - 1u)], x1 = xw[min(c1, width - 1u)];
                     // an entry's column lies in exactly one panel: its product is formed once, there
                     if (c0 < width) t[k].v[j].x = t[k].v[j].x * x0;

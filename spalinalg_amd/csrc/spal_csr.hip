@@ -461,6 +461,18 @@ __global__ __launch_bounds__(256) void csr_encode_col16(const uint32_t *__restri
     }
 }
 
+// Column-panel super-tiles (csr_panel.hpp): col16[p] = column - first column of the super-tile's span (at most 192
+// pages = 49 152 columns: 16 bits).  One workgroup per listed super-tile.
+__global__ __launch_bounds__(256) void csr_encode_col16_span(const uint32_t *__restrict__ rowptr,
+                                                             const uint32_t *__restrict__ colind,
+                                                             const uint32_t *__restrict__ ptiles,
+                                                             const uint2 *__restrict__ pwin, uint16_t *__restrict__ col16,
+                                                             uint32_t nrows, uint32_t R) {
+    const uint32_t b = ptiles[blockIdx.x], c0 = pwin[blockIdx.x].x * kPageCols;
+    const uint32_t e0 = rowptr[min(b * R, nrows)], e1 = rowptr[min(b * R + R, nrows)];
+    for (uint32_t p = e0 + threadIdx.x; p < e1; p += 256) col16[p] = (uint16_t)(colind[p] - c0);
+}
+
 // ---- plan of the sliding-window kernel (csr_slide.hpp) -----------------------------------------------------
 // One workgroup per STEP of SR = 4 * rpt rows (SR <= 256: a row per thread): out[i] = {first column, one past the
 // last column (0: the step stores nothing), 1 + the length of every row if they are all equal else 0, the most
@@ -1159,14 +1171,18 @@ int csr_plan_build(spal_csr *a) {
             // everywhere streams with the 32-bit ones: no 2 B/entry array to allocate and clear)
             bool any_stream = false;
             for (uint32_t b = 0; b < p.nblocks && !any_stream; ++b) any_stream = best_desc[b].z == kModeStream;
-            if (any_stream) {
+            if (any_stream || a->n_ptiles) {
                 if (!a->d_col16) {
                     SPAL_HIP_TRY(dev_alloc((void **)&a->d_col16, (size_t)a->cap_entries * sizeof(uint16_t)));
                     SPAL_HIP_TRY(hipMemsetAsync(a->d_col16, 0, (size_t)a->cap_entries * sizeof(uint16_t), a->stream));
                 }
-                hipLaunchKernelGGL(csr_encode_col16, dim3(p.nblocks), dim3(256), 0, a->stream, a->d_rowptr,
-                                   a->d_colind, a->d_desc, a->d_pages, a->d_col16, (uint32_t)a->nrows, R,
-                                   (uint32_t)p.ring_pages);
+                if (any_stream)
+                    hipLaunchKernelGGL(csr_encode_col16, dim3(p.nblocks), dim3(256), 0, a->stream, a->d_rowptr,
+                                       a->d_colind, a->d_desc, a->d_pages, a->d_col16, (uint32_t)a->nrows, R,
+                                       (uint32_t)p.ring_pages);
+                if (a->n_ptiles)   // the column-panel kernel's super-tiles: columns relative to the span's first column
+                    hipLaunchKernelGGL(csr_encode_col16_span, dim3(a->n_ptiles), dim3(256), 0, a->stream, a->d_rowptr,
+                                       a->d_colind, a->d_ptiles, a->d_pwin, a->d_col16, (uint32_t)a->nrows, R);
                 SPAL_HIP_TRY(hipGetLastError());
             }
             if (best_over) {   // the tiles the stream kernels skip: listed for csr_spmv_overflow
