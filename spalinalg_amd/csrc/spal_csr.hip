@@ -1635,6 +1635,8 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
             ++a->place_tried;
             if (rc == SPAL_OK && ms < 0.99f * cur_ms) { cur_ms = ms; rejects.push_back(old); }
             else { a->d_values = old; rejects.push_back(cand); }
+            // (two classes, 5 ... 14 % apart: once an allocation of the faster one is in hand, stop looking)
+            if (cur_ms * 1e3f < 0.96f * a->place_us[0]) break;
         }
         a->place_us[1] = cur_ms * 1e3f;
         // the rejected blocks are released only now, so that no try was handed one of them again

@@ -129,7 +129,7 @@ struct CsrPlan {
     int slide_run = 0;       // steps per run (0 = one run per workgroup: fully persistent)
     int slide_S = 0;         // 128-entry steps of the largest streamed tile: every tile issues that many loads
     int slide_uniform = 0;   // 1 + the length of every row when all streamed rows have one length (rowptr is not read), else 0
-    int place_tries = 3;     // autotune: fresh allocations tried for the values array (see csr_autotune)
+    int place_tries = 6;     // autotune: fresh allocations tried for the values array, at most (see csr_autotune)
     int split_tiles_on = 1;  // sliding kernel: tiles above 1024 entries whose halves fit go through the strip twice
     int diag = 0;            // ablation builds (-DSPAL_DIAG) only: parts of the stream kernel switched off
     int persistent_blocks = 0;    // its grid; 0 = what the device holds at once (LDS per workgroup decides: f64 band 512)
