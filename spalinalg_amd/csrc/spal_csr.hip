@@ -1614,35 +1614,41 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
     else p.persistent = best & 1;
     p.user_persistent = true;   // measured: a later re-plan keeps it
     p.nt_store = (best >> 1) & 1;
-    // ---- 2. the placement of the values array
-    const size_t vbytes = (size_t)a->cap_entries * (size_t)a->elem_size;
+    // ---- 2. the placement of the values array (72 % of the bytes), then of the 16-bit columns (18 %)
     int tries = p.place_tries;
     if (const char *e = getenv("SPAL_PLACE_TRIES")) tries = atoi(e);
-    if (rc == SPAL_OK && tries > 0 && vbytes >= ((size_t)64 << 20)) {
-        std::vector<void *> rejects;
+    struct Placed { void **ptr; size_t bytes; };
+    const Placed arrays[2] = {{&a->d_values, (size_t)a->cap_entries * (size_t)a->elem_size},
+                              {(void **)&a->d_col16, a->d_col16 ? (size_t)a->cap_entries * sizeof(uint16_t) : 0}};
+    std::vector<void *> rejects;
+    for (int which = 0; which < 2 && rc == SPAL_OK && tries > 0; ++which) {
+        const size_t vbytes = arrays[which].bytes;
+        if (vbytes < ((size_t)64 << 20)) continue;
         float cur_ms = 0.f;
         timed(iters, &cur_ms);
-        a->place_us[0] = cur_ms * 1e3f;
+        const float first_ms = cur_ms;
+        if (which == 0) a->place_us[0] = cur_ms * 1e3f;
         for (int k = 0; k < tries && rc == SPAL_OK; ++k) {
             void *cand = nullptr;
             if (dev_alloc(&cand, vbytes) != hipSuccess) { (void)hipGetLastError(); break; }   // out of memory: keep what we have
-            hipError_t e = hipMemcpyAsync(cand, a->d_values, vbytes, hipMemcpyDeviceToDevice, st);
+            hipError_t e = hipMemcpyAsync(cand, *arrays[which].ptr, vbytes, hipMemcpyDeviceToDevice, st);
             if (e != hipSuccess) { rejects.push_back(cand); rc = fail(SPAL_ERR_HIP, "spal_csr_autotune: %s", hipGetErrorString(e)); break; }
-            void *old = a->d_values;
-            a->d_values = cand;
+            void *old = *arrays[which].ptr;
+            *arrays[which].ptr = cand;
             float ms = 0.f;
             timed(iters, &ms);
             ++a->place_tried;
             if (rc == SPAL_OK && ms < 0.99f * cur_ms) { cur_ms = ms; rejects.push_back(old); }
-            else { a->d_values = old; rejects.push_back(cand); }
-            // (two classes, 5 ... 14 % apart: once an allocation of the faster one is in hand, stop looking)
-            if (cur_ms * 1e3f < 0.96f * a->place_us[0]) break;
+            else { *arrays[which].ptr = old; rejects.push_back(cand); }
+            // (classes 5 ... 14 % apart for the values: once an allocation of the faster one is in hand, stop looking;
+            //  the columns are a quarter of that)
+            if (cur_ms < (which == 0 ? 0.96f : 0.99f) * first_ms) break;
         }
         a->place_us[1] = cur_ms * 1e3f;
-        // the rejected blocks are released only now, so that no try was handed one of them again
-        (void)hipStreamSynchronize(st);
-        for (void *r : rejects) (void)dev_free(r);
     }
+    // the rejected blocks are released only now, so that no try was handed one of them again
+    (void)hipStreamSynchronize(st);
+    for (void *r : rejects) (void)dev_free(r);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return rc;
