@@ -144,9 +144,9 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value);
  * kernel on band-like plans, else the persistent form -- each with plain or
  * non-temporal y stores) `iters` times each on the caller's device vectors and
  * keeps the fastest; then tries up to "place_tries" fresh allocations for the
- * values array (and then for the 16-bit column array) (identical kernels ran 5-14 % apart depending on the allocation
- * that array lives in) and keeps the fastest.  All variants produce identical
- * y.  Synchronises `stream`. */
+ * values array, and after it for the 16-bit column array (identical kernels
+ * ran 5-14 % apart depending on the allocation the values live in), and keeps
+ * the fastest.  All variants produce identical y.  Synchronises `stream`. */
 int spal_csr_autotune_f64(spal_csr_t a, const double *x_dev, double *y_dev,
                           void *stream, int iters);
 int spal_csr_autotune_f32(spal_csr_t a, const float *x_dev, float *y_dev,
