@@ -990,7 +990,7 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
             // column panels by csr_spmv_panel (csr_panel.hpp), desc.w bit 1
             const uint32_t p_first = w.x >> kPageShift, p_span = ((w.y - 1u) >> kPageShift) - p_first + 1u;
             if (a->plan.panel_pages > 0 && rpt <= 64u && a->plan.tiles_per_wave == 4 && !a->plan.skew &&
-                p_span <= (uint32_t)a->plan.panel_pages) {
+                p_span <= std::min<uint32_t>((uint32_t)a->plan.panel_pages, 255u)) {   // (span-relative columns are 16-bit: < 65 536)
                 desc[b].w |= 2u;
                 panel_win[b] = make_uint2(p_first, p_span);
             }
@@ -1810,7 +1810,7 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
     } else if (!strcmp(key, "panel_pages")) {
         // super-tiles whose column span is at most this many 256-column pages (and wider than the LDS window) are
         // taken in column panels by csr_spmv_panel; 0 = never (x through L2)
-        if (value < 0 || value > 4096) return fail(SPAL_ERR_INVALID_ARGUMENT, "panel_pages must be in [0, 4096]");
+        if (value < 0 || value > 255) return fail(SPAL_ERR_INVALID_ARGUMENT, "panel_pages must be in [0, 255]");
         p.panel_pages = (int)value;
     } else if (!strcmp(key, "panel_window")) {
         if (value < 0 || value > 624) return fail(SPAL_ERR_INVALID_ARGUMENT, "panel_window must be in [0, 624] pages");

@@ -923,6 +923,24 @@ def test_wide_bands_in_column_panels_bit_identical(oracle, dtype, window, gen, r
     assert dev.describe()["panel_tiles"] == 0      # panel_pages = 0: no super-tile is flagged
 
 
+def test_column_panels_at_the_16_bit_limit(oracle):
+    """the panel kernel reads 16-bit columns relative to the first column of a super-tile's span: spans up to 255 pages
+    (65 280 columns) qualify, wider ones gather x through L2 -- both bit-identical"""
+    n = 200_000
+    x = synth.vector(n)
+    for window, panels in ((60_000, True), (66_000, False)):
+        rp, ci, va = synth.banded_csr(n, n, 14, window, 8)
+        y_ref = oracle.csr_spmv(rp, ci, va, x)
+        dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+        dev.set_option("panel_pages", 255)
+        d = dev.describe()
+        assert (d["panel_tiles"] > 0) == panels, d
+        assert np.array_equal(dev.spmv(x), y_ref)
+        with pytest.raises(sp.Panic):
+            dev.set_option("panel_pages", 256)
+        dev.close()
+
+
 def test_row_blocks_beyond_32_bit_entry_offsets(oracle, monkeypatch):
     """More stored entries than one set of 32-bit device offsets addresses (the reference's offsets are usize,
     src/csr.rs:66-72): the handle keeps the matrix as row blocks.  SPAL_CSR_PART_ENTRIES lowers the limit so the path
