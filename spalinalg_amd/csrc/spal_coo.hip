@@ -574,7 +574,7 @@ __device__ __forceinline__ uint32_t group_lookback(unsigned long long *state, ui
 }
 
 template <typename T, int CAP>
-__global__ __launch_bounds__(256) void coo_group_sort(const uint32_t *__restrict__ gstart,
+__global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void coo_group_sort(const uint32_t *__restrict__ gstart,
                                                       const uint32_t *__restrict__ sorted_row,
                                                       const uint32_t *__restrict__ cols, const T *__restrict__ vals,
                                                       uint32_t nrows, uint32_t gbits, uint32_t ngroups,
@@ -582,19 +582,25 @@ __global__ __launch_bounds__(256) void coo_group_sort(const uint32_t *__restrict
                                                       uint32_t *__restrict__ rowptr, uint32_t *__restrict__ out_col,
                                                       T *__restrict__ out_val, uint2 *__restrict__ gwin) {
     constexpr int K = CAP / 256;  // rounds per wave = sorted positions per thread
-    __shared__ T s_v2[CAP];
+    // LDS: the sorted values (written only after every rank is known) share their space with the per-wave row counters
+    // and the row starts of the counting sort, which are dead by then -- 21 instead of 26 KB at CAP = 1536 (f64): seven
+    // workgroups per CU instead of six.
+    constexpr size_t kCntBytes = 4 * 256 * sizeof(uint32_t), kRsBytes = 260 * sizeof(uint32_t);
+    constexpr size_t kRegion = CAP * sizeof(T) > kCntBytes + kRsBytes ? CAP * sizeof(T) : kCntBytes + kRsBytes;
+    __shared__ __attribute__((aligned(16))) unsigned char s_region[kRegion];
+    T *s_v2 = reinterpret_cast<T *>(s_region);
+    // volatile: lanes of a wave hand counts to each other through this array
+    // between two rounds; the compiler must re-read it every round
+    volatile uint32_t (*s_cnt)[256] = reinterpret_cast<volatile uint32_t (*)[256]>(s_region);
+    uint32_t *s_rs = reinterpret_cast<uint32_t *>(s_region + kCntBytes);   // 257 row starts
     __shared__ uint32_t s_c1[CAP];
     uint32_t *s_c2 = s_c1;   // (row, col) order replaces the row order in place (a barrier in between)
-    __shared__ uint32_t s_rs[257];
     __shared__ uint32_t s_rk[256];
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_wc[K * 4];
     __shared__ uint32_t s_cmin, s_cmax;   // columns of the survivors (the CSR planner's window input)
     __shared__ uint32_t s_base, s_total;  // survivors of the groups before this one / of this one
     __shared__ uint8_t s_r2[CAP];
-    // volatile: lanes of a wave hand counts to each other through this array
-    // between two rounds; the compiler must re-read it every round
-    __shared__ volatile uint32_t s_cnt[4][256];
 
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
