@@ -574,6 +574,7 @@ __device__ __forceinline__ uint32_t group_lookback(unsigned long long *state, ui
 }
 
 template <typename T, int CAP>
+// (waves per SIMD the LDS footprint allows; at CAP = 1536 eight would need 64 registers: 75 spilled, 2.4 ms per assembly)
 __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void coo_group_sort(const uint32_t *__restrict__ gstart,
                                                       const uint32_t *__restrict__ sorted_row,
                                                       const uint32_t *__restrict__ cols, const T *__restrict__ vals,
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
     constexpr int K = CAP / 256;  // rounds per wave = sorted positions per thread
     // LDS: the sorted values (written only after every rank is known) share their space with the per-wave row counters
     // and the row starts of the counting sort, which are dead by then -- 21 instead of 26 KB at CAP = 1536 (f64): seven
-    // workgroups per CU instead of six.
+    // workgroups per CU instead of six.  The survivors' row counters of step 4 live there as well.
     constexpr size_t kCntBytes = 4 * 256 * sizeof(uint32_t), kRsBytes = 260 * sizeof(uint32_t);
     constexpr size_t kRegion = CAP * sizeof(T) > kCntBytes + kRsBytes ? CAP * sizeof(T) : kCntBytes + kRsBytes;
     __shared__ __attribute__((aligned(16))) unsigned char s_region[kRegion];
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
     uint32_t *s_rs = reinterpret_cast<uint32_t *>(s_region + kCntBytes);   // 257 row starts
     __shared__ uint32_t s_c1[CAP];
     uint32_t *s_c2 = s_c1;   // (row, col) order replaces the row order in place (a barrier in between)
-    __shared__ uint32_t s_rk[256];
+    uint32_t *s_rk = reinterpret_cast<uint32_t *>(s_region);   // survivors per row: counted when the sorted values are dead too
     __shared__ uint32_t s_wsum[4];
     __shared__ uint32_t s_wc[K * 4];
     __shared__ uint32_t s_cmin, s_cmax;   // columns of the survivors (the CSR planner's window input)
@@ -639,7 +640,6 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
     }
     {
         for (uint32_t i = t; i < 4 * 256; i += 256) s_cnt[i >> 8][i & 255] = 0;
-        s_rk[t] = 0;
         if (t == 0) { s_cmin = 0xffffffffu; s_cmax = 0u; }
         __syncthreads();
         // 1. stable counting sort by row inside the group
@@ -750,6 +750,7 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
         __syncthreads();
         // 4. numbering in sorted order = (round, wave, lane); the group's place in the result (look-back over the
         // groups before it); survivors written at their FINAL offsets; rowptr of the group's rows
+        s_rk[t] = 0;   // (in the sorted values' space: the run sums above were their last readers)
         if (t < 64) {  // K * 4 <= 64 wave counts: one wave scans them
             const uint32_t kk = min(t, (uint32_t)(K * 4 - 1));
             const uint32_t c = (t < (uint32_t)(K * 4) && 256u * (kk >> 2) < cur_n) ? s_wc[kk] : 0u;
