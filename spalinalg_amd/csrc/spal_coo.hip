@@ -574,7 +574,7 @@ __device__ __forceinline__ uint32_t group_lookback(unsigned long long *state, ui
 }
 
 template <typename T, int CAP>
-// (waves per SIMD the LDS footprint allows; at CAP = 1536 eight would need 64 registers: 75 spilled, 2.4 ms per assembly)
+// (waves per SIMD the LDS footprint allows; eight at CAP = 1536 -- 63 registers, 2 spilled -- measured level with seven)
 __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void coo_group_sort(const uint32_t *__restrict__ gstart,
                                                       const uint32_t *__restrict__ sorted_row,
                                                       const uint32_t *__restrict__ cols, const T *__restrict__ vals,
@@ -629,14 +629,14 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
     // 0. one batch of loads (clamped lanes re-read the last entry: every load is issued unconditionally, back to
     // back); wave w owns the entries [w * chunk, (w + 1) * chunk)
     const uint32_t chunk = ((n + 255) / 256) * 64;        // entries per wave, a multiple of 64, <= 64 K
-    uint32_t rc[K], rid[K], pos[K];
+    uint32_t rc[K], pr[K];   // column; (row inside the group) << 16 | position (step 1: among the row's entries, then in the group)
     T rv[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const uint32_t ic = min(w * chunk + 64u * k + lane, n - 1);
         rc[k] = cols[e0 + ic];
         rv[k] = vals[e0 + ic];
-        rid[k] = sorted_row[e0 + ic] - r0;
+        pr[k] = (sorted_row[e0 + ic] - r0) << 16;
     }
     {
         for (uint32_t i = t; i < 4 * 256; i += 256) s_cnt[i >> 8][i & 255] = 0;
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
         for (int k = 0; k < K; ++k) {
             if (64u * k >= chunk) break;  // block-uniform
             const bool ok = w * chunk + 64u * k + lane < n;
-            const uint32_t d = rid[k];
+            const uint32_t d = pr[k] >> 16;
             uint64_t peers = __ballot(ok);   // lanes of this round with the same row
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
                 peers &= ((d >> b) & 1u) ? m : ~m;
             }
             const uint32_t before = ok ? s_cnt[w][d] : 0u;
-            pos[k] = before + (uint32_t)__popcll(peers & lt);
+            pr[k] |= before + (uint32_t)__popcll(peers & lt);
             // the lowest peer lane publishes the new count (one writer per row)
             if (ok && (peers & lt) == 0) s_cnt[w][d] = before + (uint32_t)__popcll(peers);
         }
@@ -683,8 +683,8 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
         for (int k = 0; k < K; ++k) {
             if (64u * k >= chunk) break;
             if (w * chunk + 64u * k + lane < n) {
-                pos[k] += s_rs[rid[k]] + s_cnt[w][rid[k]];   // place in row order, insertion order inside the row
-                s_c1[pos[k]] = rc[k];
+                pr[k] += s_rs[pr[k] >> 16] + s_cnt[w][pr[k] >> 16];   // place in row order, insertion order inside the row
+                s_c1[pr[k] & 0xffffu] = rc[k];
             }
         }
         __syncthreads();
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
         for (int k = 0; k < K; ++k) {
             if (64u * k >= chunk) break;
             if (w * chunk + 64u * k + lane < n) {
-                const uint32_t d = rid[k], a = s_rs[d], b = s_rs[d + 1], ci = rc[k], i = pos[k];
+                const uint32_t d = pr[k] >> 16, a = s_rs[d], b = s_rs[d + 1], ci = rc[k], i = pr[k] & 0xffffu;
                 uint32_t rank = 0, j = a;
                 for (; j + 4 <= b; j += 4) {
                     const uint32_t q0 = s_c1[j], q1 = s_c1[j + 1], q2 = s_c1[j + 2], q3 = s_c1[j + 3];
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
                     const uint32_t q = s_c1[j];
                     rank += (uint32_t)((q < ci) | ((q == ci) & (j < i)));
                 }
-                pos[k] = a + rank;
+                pr[k] = (pr[k] & 0xffff0000u) | (a + rank);
             }
         }
         __syncthreads();   // every rank is known: the row-ordered columns may be overwritten
@@ -714,19 +714,19 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
         for (int k = 0; k < K; ++k) {
             if (64u * k >= chunk) break;
             if (w * chunk + 64u * k + lane < n) {
-                s_c2[pos[k]] = rc[k];
-                s_v2[pos[k]] = rv[k];
-                s_r2[pos[k]] = (uint8_t)rid[k];
+                s_c2[pr[k] & 0xffffu] = rc[k];
+                s_v2[pr[k] & 0xffffu] = rv[k];
+                s_r2[pr[k] & 0xffffu] = (uint8_t)(pr[k] >> 16);
             }
         }
         __syncthreads();
         const uint32_t cur_n = n;
         // 3. heads and run sums; thread t takes the sorted positions t, t + 256, ...
         T acc[K];
-        uint64_t keepm[K];
+        uint32_t kinfo[K];   // bit 31: survivor; low bits: survivors of the same wave round before it
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            keepm[k] = 0;
+            kinfo[k] = 0;
             acc[k] = T(0);
             if (256u * k >= cur_n) continue;  // block-uniform
             const uint32_t p = 256u * k + t;
@@ -744,8 +744,9 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
             }
             const bool keep = head && a != T(0);
             acc[k] = a;
-            keepm[k] = __ballot(keep);
-            if (lane == 0) s_wc[k * 4 + w] = (uint32_t)__popcll(keepm[k]);
+            const uint64_t km = __ballot(keep);
+            if (keep) kinfo[k] = 0x80000000u | (uint32_t)__popcll(km & lt);
+            if (lane == 0) s_wc[k * 4 + w] = (uint32_t)__popcll(km);
         }
         __syncthreads();
         // 4. numbering in sorted order = (round, wave, lane); the group's place in the result (look-back over the
@@ -766,9 +767,9 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             if (256u * k >= cur_n) continue;
-            if ((keepm[k] >> lane) & 1ull) {
+            if (kinfo[k] >> 31) {
                 const uint32_t p = 256u * k + t;
-                const uint32_t o = before + s_wc[k * 4 + w] + (uint32_t)__popcll(keepm[k] & lt);
+                const uint32_t o = before + s_wc[k * 4 + w] + (kinfo[k] & 0x7fffffffu);
                 const uint32_t cp = s_c2[p];
                 out_col[o] = cp;
                 out_val[o] = acc[k];
