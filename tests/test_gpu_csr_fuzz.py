@@ -19,7 +19,7 @@ def _lengths(rng, kind, n):
     if kind == "const":
         lens = np.full(n, int(rng.choice([1, 3, 7, 16, 24, 32, 64, 65, 96, 100, 128])), np.int64)
     elif kind == "uniform":
-        lens = rng.integers(0, int(rng.choice([4, 20, 70, 130, 300])), n)
+        lens = rng.integers(0, int(rng.choice([4, 20, 28, 70, 130, 300])), n)   # (28: 64-row tiles just above the strip: halves)
     elif kind == "pareto":
         lens = np.minimum((rng.pareto(1.5, n) * rng.choice([2, 6, 20]) + 1).astype(np.int64), 6000)
     elif kind == "two_regions":      # half the matrix short rows, half long ones
