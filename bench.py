@@ -82,6 +82,9 @@ def parse():
                     help="--host mg: comma-separated device list; repeats (e.g. 0,0,0,0) put several shards on one "
                          "GPU over the copy transport -- a rehearsal of the multi-GPU path on a 1-GPU box")
     ap.add_argument("--transport", default=None, choices=["rccl", "copy"], help="--host mg: exchange transport")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run (config 3, banded, f64, one GPU): do not append the compact records of configs "
+                         "1, 2, 4, 5 and of config 3 in f32 (child processes of this script, ~40 s)")
     ap.add_argument("--extras", action="store_true",
                     help="N > 1, --exchange end: also time K steps with an all-gather after every step and "
                          "report it beside the headline (extra collectives; off by default)")
@@ -478,6 +481,46 @@ def bench_mg(args):
     mg.close()
 
 
+
+def other_configs(args):
+    """Compact records of the BASELINE configs the default line does not measure (1, 2, 4, 5) and of config 3 in f32:
+    each is this script run as a child process (`--config N`, its own CPU-baseline leg on a short budget), reduced to
+    the fields a reader needs to recompute its roofline fraction from profiles/r03/kernel_stats_configN.csv."""
+    import subprocess
+    runs = {"1": ["--config", "1", "--steps", "200", "--warmup", "20"],
+            "2": ["--config", "2", "--steps", "200", "--warmup", "20", "--cpu-seconds", "3", "--no-ceiling"],
+            "4": ["--config", "4", "--steps", "200", "--warmup", "20", "--cpu-seconds", "3"],
+            "5": ["--config", "5", "--steps", "10", "--warmup", "2"],
+            "3_f32": ["--config", "3", "--dtype", "f32", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                      "--no-cpu-baseline", "--no-ceiling", "--no-other-configs"]}
+    out = {}
+    for name, extra in runs.items():
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1"] + extra,
+                               capture_output=True, text=True, timeout=240)
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not line:
+                out[name] = {"error": (p.stderr or p.stdout)[-400:], "rc": p.returncode}
+                continue
+            r = json.loads(line[-1])
+        except Exception as exc:  # noqa: BLE001  (the headline must still be printed)
+            out[name] = {"error": str(exc)}
+            continue
+        rf, cb = r.get("roofline", {}), r.get("cpu_baseline") or {}
+        rec = {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+               "steps": r["steps"], "dtype": r["dtype"], "workload": r["config"]["workload"],
+               "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel",
+                                                   "kernel_ms", "algorithmic_bytes_per_launch")},
+               "cpu_baseline": {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample")} if cb else None,
+               "parity": {k: v for k, v in cb.items() if k.startswith("gpu_")} or None,
+               "wall_s": round(time.perf_counter() - t0, 1)}
+        for k in ("transposed_route", "spmv_on_result", "assembly_ms"):
+            if k in r:
+                rec[k] = r[k]
+        out[name] = rec
+    return out
+
 def base_record(args, metric, value, unit, ms, workload, plan):
     return {"metric": metric, "value": round(value, 3), "unit": unit, "n_gpus": 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 6), "higher_is_better": True, "scaling": "strong",
@@ -683,38 +726,53 @@ def main():
         else:
             op.spmv(x, y)
 
+    def timed_region(xm, ym):
+        """EXACTLY K steps between a barrier + device sync on both sides; with --exchange end the x distribution and
+        the y collection (forms xm / ym) are inside.  Returns the region's time in ms, MAX over ranks."""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t_wall0 = time.perf_counter()
+        e0.record()
+        if exchange == "end":       # "x broadcast once via RCCL": inside the timed region
+            if xm == "scatter_windows":
+                op.distribute_x(x, ncols, x_needs)
+            else:
+                op.broadcast_x(x)
+        for _ in range(args.steps):
+            step()
+        if exchange == "end" and ym == "gather_root":
+            op.gather_y_root(y)     # "per-GPU y slices gathered at the end": once, inside the timed region
+        elif exchange in ("halo", "end"):
+            op.gather_y(y)
+        e1.record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        wall_ms = (time.perf_counter() - t_wall0) * 1e3
+        ev_ms = e0.elapsed_time(e1)
+        elapsed = torch.tensor([wall_ms if world > 1 else ev_ms], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        return float(elapsed.item())
+
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t_wall0 = time.perf_counter()
-    e0.record()
-    if exchange == "end":       # "x broadcast once via RCCL": inside the timed region
-        if x_mode == "scatter_windows":
-            op.distribute_x(x, ncols, x_needs)
-        else:
-            op.broadcast_x(x)
-    for _ in range(args.steps):
-        step()
-    if exchange == "end" and y_mode == "gather_root":
-        op.gather_y_root(y)     # "per-GPU y slices gathered at the end": once, inside the timed region
-    elif exchange in ("halo", "end"):
-        op.gather_y(y)
-    e1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall_ms = (time.perf_counter() - t_wall0) * 1e3
-    ev_ms = e0.elapsed_time(e1)
-    elapsed = torch.tensor([wall_ms if world > 1 else ev_ms], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    total_ms = float(elapsed.item())
+    total_ms = timed_region(x_mode, y_mode)
     ms_per_step = total_ms / args.steps
+    # N > 1, --exchange end: the SAME region with the other pair of collectives, so that both end-to-end totals are
+    # headline fields: north_star's wording to the letter (ncclBroadcast of all of x, all-gather of the y slices) and
+    # the windows form (each GPU receives only the columns its rows read; y slices gathered on rank 0)
+    end_to_end = None
+    if world > 1 and exchange == "end":
+        end_to_end = {"windows_scatter_gather_root_ms": None, "broadcast_allgather_ms": None}
+        key = "windows_scatter_gather_root_ms" if x_mode == "scatter_windows" else "broadcast_allgather_ms"
+        end_to_end[key] = round(total_ms, 4)
+        if x_mode == "scatter_windows":
+            end_to_end["broadcast_allgather_ms"] = round(timed_region("broadcast", "allgather"), 4)
 
     # ---- for transparency: the same K steps with an all-gather of y after EVERY step
     allgather_ms = None
@@ -929,6 +987,12 @@ def main():
             "value": round(synth.spmv_flops(nnz) / (kern_ms_max * 1e-3) / 1e9, 3),
             "unit": "GFLOP/s",
         },
+        # N > 1: K steps + one x distribution + one y collection, barrier to barrier, max over ranks -- in both forms
+        # (`value` / `ms_per_step` are the region with `config.x_distribution` / `config.y_collection`)
+        "end_to_end_windows_ms": None if end_to_end is None else end_to_end["windows_scatter_gather_root_ms"],
+        "end_to_end_broadcast_allgather_ms": None if end_to_end is None else end_to_end["broadcast_allgather_ms"],
+        "end_to_end_broadcast_allgather_value": None if end_to_end is None or not end_to_end["broadcast_allgather_ms"] else
+            round(synth.spmv_flops(nnz) / (end_to_end["broadcast_allgather_ms"] / args.steps * 1e-3) / 1e9, 3),
         "comm_ms": comm_ms,
         "x_first_call_ms": round(x_bcast_ms, 4),   # (the first collective of the process: includes communicator warm-up)
         "allgather_every_step": None if allgather_ms is None else {
@@ -1030,6 +1094,10 @@ def main():
                 "same_result_as_1_thread": bool(np.array_equal(y_mt, yh))}
         except Exception as exc:  # noqa: BLE001  (informational only)
             out["cpu_baseline_all_cores"] = {"error": str(exc)}
+    if (world == 1 and args.config == 3 and args.dist == "banded" and args.dtype == "f64" and not args.opt
+            and not args.no_other_configs):
+        # the driver runs only this default line: every other BASELINE config rides along as a compact record
+        out["other_configs"] = other_configs(args)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -334,13 +334,10 @@ static size_t sort_lds_bytes() {
 // Sorts by bits [lo_bit, lo_bit + nbits) of key, stably.  The first pass reads
 // (k_in, a_in, v_in) when given (the caller's arrays, left untouched), else
 // buffer set `cur`; `cur` is updated to the set that holds the result.
-// first_offs: the scanned per-tile digit counts of the FIRST pass over (k_in ...), when the caller has them
-// (the COO handle computes them for its uploaded triplets at upload time: coo_first_pass_offsets).
 template <typename T>
 static hipError_t radix_sort_bits(SortBuffers<T> &b, uint64_t len, uint32_t lo_bit, uint32_t nbits,
                                   int &cur, hipStream_t st, const uint32_t *k_in = nullptr,
-                                  const uint32_t *a_in = nullptr, const T *v_in = nullptr,
-                                  const uint32_t *first_offs = nullptr) {
+                                  const uint32_t *a_in = nullptr, const T *v_in = nullptr) {
     if (len == 0) return hipSuccess;
     const uint32_t nblk = (uint32_t)((len + kSortTile - 1) / kSortTile);
     const uint64_t ncounts = 256ull * nblk;
@@ -356,9 +353,7 @@ static hipError_t radix_sort_bits(SortBuffers<T> &b, uint64_t len, uint32_t lo_b
         const T *vi = k_in ? v_in : b.val[cur];
         const int dst = k_in ? cur : (cur ^ 1);
         const uint32_t *offs = b.counts;
-        if (k_in && first_offs && shift == lo_bit) {
-            offs = first_offs;   // counted and scanned when the triplets were uploaded
-        } else {
+        {
             hipLaunchKernelGGL(radix_hist, dim3(nblk), dim3(kHistThreads), 0, st, ki, len, shift, b.counts,
                                nblk);
             hipError_t e = exclusive_scan_u32(b.counts, b.counts, ncounts, b.sums, nullptr, st);
@@ -444,24 +439,6 @@ static void launch_row_starts(const uint32_t *sorted_row, uint32_t n, uint32_t n
 
 constexpr int kGroupCap = 2048;  // entries a group of rows may hold for the LDS local sort
 
-// counts[key >> shift] += 1 for every uploaded index (upload time, once per handle and orientation).  Sorted or
-// clustered input puts a whole wave on one counter: such a wave adds its lane count once.
-__global__ __launch_bounds__(256) void coo_group_hist(const uint32_t *__restrict__ keys, uint64_t len, uint32_t shift,
-                                                      uint32_t *__restrict__ counts) {
-    for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < len; i0 += (uint64_t)gridDim.x * 256) {
-        const uint64_t i = i0 + threadIdx.x;
-        const bool ok = i < len;
-        const uint32_t g = ok ? keys[i] >> shift : 0xffffffffu;
-        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-        if (__all(g == g0 || !ok)) {
-            const uint64_t m = __ballot(ok && g == g0);
-            if (m && (threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) atomicAdd(&counts[g0], (uint32_t)__popcll(m));
-        } else if (ok) {
-            atomicAdd(&counts[g], 1u);
-        }
-    }
-}
-
 // part[blk] = entries of the fullest group among those this workgroup visits
 // (no atomics: thousands of waves raising one shared maximum serialise on it;
 // groups_check_final folds the partial results)
@@ -522,23 +499,30 @@ __global__ __launch_bounds__(256) void groups_check_final(const uint32_t *__rest
 // state[g] of the look-back below: (status << 32) | count, status 0 = nothing yet, 1 = the group's own number of
 // survivors, 2 = survivors of groups 0 ... g inclusive.
 constexpr unsigned long long kGroupOwn = 1ull << 32, kGroupUpTo = 2ull << 32;
-constexpr uint32_t kLookbackSpins = 1u << 21;   // (seconds: a bound, so that every wave reaches its exit)
+constexpr uint32_t kLookbackSpins = 1u << 21;   // (seconds: a bound, so that every wave reaches its exit; SPAL_COO_LOOKBACK_SPINS overrides)
 
 // Survivors in all groups before `grp`, for the group that holds `total` of its own: decoupled look-back over the
 // groups' 8-byte state words (wave 0 of the workgroup, all 64 lanes: 64 predecessors per round).  The count travels
 // IN the word that flags it (relaxed agent-scope stores / loads: written through, read past L1), so no release /
 // acquire fence is paid -- with fences (an L2 write-back per group) this form lost to a separate pack kernel.
-// Progress: workgroups are dispatched in blockIdx order (XCD x takes the workgroups = x mod 8, in order), so the
-// lowest unfinished group is always resident and waits for nobody.  Should that ever not hold, the spin bound
-// raises *err and the host repeats the assembly on the general route.  (A resident grid whose workgroups walk the
-// groups b, b + grid, ... with the next group's loads in flight during the look-back needs no such assumption; it
+// Progress: a group waits only for groups with a SMALLER id, and ids are handed out by a device ticket (one atomicAdd
+// per workgroup, coo_group_sort) in the order in which workgroups actually start: whoever holds id g started after the
+// holders of 0 ... g - 1, which are therefore resident or finished -- the lowest unfinished group waits for nobody,
+// whatever order the dispatcher takes the workgroups in.  The spin bound stays as a backstop (a wave that gives up
+// raises *err bit 0, publishes nothing further and the host repeats the assembly on the general route; forced by
+// SPAL_COO_LOOKBACK_SPINS=0 in tests/test_gpu_csc_coo.py).  (A resident grid whose workgroups walk the
+// groups b, b + grid, ... with the next group's loads in flight during the look-back needs no ticket either; it
 // was measured and is slower: 1.93 vs 1.68 ms per assembly, the static order keeps a fast workgroup from running ahead.)
+// Memory order: the only data a successor reads from a predecessor is the count, and it travels in the SAME 8-byte
+// word as the status (single-copy atomic 8-byte store / load at agent scope: sc1, written through to / read from the
+// memory side of the per-XCD L2s) -- there is no second location whose visibility would have to be ordered against
+// the flag, hence relaxed suffices and no release / acquire fence (an L2 write-back per group) is paid.
 // Measured (config 5, profiles/r02/coo_lookback.txt): the wait costs 174 us of coo_group_sort's 750 (groups finish in
 // order, so a workgroup also waits out every slower predecessor still in flight) against 193 + 32 us for the pack
 // kernel and row scan it replaces, and 1.2 GB less traffic.  Polling 128 or 512 predecessors per round trip is slower
 // (1.86 / 1.98 vs 1.75 ms per assembly), the sleep between polls does not matter (1 ... 64: 1.75 - 1.79 ms).
 __device__ __forceinline__ uint32_t group_lookback(unsigned long long *state, uint32_t grp, uint32_t total,
-                                                   uint32_t lane, uint32_t *err) {
+                                                   uint32_t lane, uint32_t *err, uint32_t spin_bound) {
     if (lane == 0)
         __hip_atomic_store(&state[grp], (grp ? kGroupOwn : kGroupUpTo) | total, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
@@ -554,7 +538,7 @@ __device__ __forceinline__ uint32_t group_lookback(unsigned long long *state, ui
         // the nearest predecessor that knows its inclusive count ends the walk; everyone nearer must have reported
         const uint64_t need = upto ? ((2ull << __builtin_ctzll(upto)) - 1ull) : ~0ull;
         if (missing & need) {
-            if (++spins > kLookbackSpins) {
+            if (++spins > spin_bound) {
                 if (lane == 0) atomicOr(err, 1u);
                 break;
             }
@@ -580,6 +564,7 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
                                                       const uint32_t *__restrict__ cols, const T *__restrict__ vals,
                                                       uint32_t nrows, uint32_t gbits, uint32_t ngroups,
                                                       unsigned long long *__restrict__ state, uint32_t *__restrict__ err,
+                                                      uint32_t *__restrict__ ticket, uint32_t spin_bound,
                                                       uint32_t *__restrict__ rowptr, uint32_t *__restrict__ out_col,
                                                       T *__restrict__ out_val, uint2 *__restrict__ gwin) {
     constexpr int K = CAP / 256;  // rounds per wave = sorted positions per thread
@@ -605,14 +590,26 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
 
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
-    const uint32_t grp = blockIdx.x;                      // < ngroups
+    // the group this workgroup takes: its ticket (start order), not its blockIdx (see group_lookback)
+    if (t == 0) s_base = ticket ? atomicAdd(ticket, 1u) : blockIdx.x;
+    __syncthreads();
+    const uint32_t grp = s_base;                          // < ngroups (ngroups workgroups, one ticket each)
+    __syncthreads();                                      // (s_base is written again below)
     const uint32_t r0 = grp << gbits;                     // < nrows (there are ceil(nrows / 2^gbits) groups)
     const uint32_t nr = min(1u << gbits, nrows - r0);     // rows of this group, <= 256
-    const uint32_t e0 = gstart[grp], n = gstart[grp + 1] - e0;  // n <= CAP (checked by the host)
+    const uint32_t e0 = gstart[grp];
+    uint32_t n = gstart[grp + 1] - e0;
     const bool last = grp + 1 == ngroups;
+    // The capacity is the host's guess (the last assembly's fullest group, or mean + 6 sigma): a group that does not
+    // fit raises *err bit 1, takes part in the look-back as an empty group (nobody waits for it) and the host runs
+    // the kernel again at the capacity the fullest group needs -- the device computes that beside (groups_check).
+    if (n > (uint32_t)CAP) {
+        if (t == 0) atomicOr(err, 2u);
+        n = 0;
+    }
     if (n == 0) {  // block-uniform: no entries, but the group's rows start where the groups before it end
         if (w == 0) {
-            const uint32_t before = group_lookback(state, grp, 0u, lane, err);
+            const uint32_t before = group_lookback(state, grp, 0u, lane, err, spin_bound);
             if (lane == 0) s_base = before;
         }
         __syncthreads();
@@ -758,7 +755,7 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
             const uint32_t inc = wave_inclusive_scan(c);
             if (t < (uint32_t)(K * 4)) s_wc[t] = inc - c;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            const uint32_t before = group_lookback(state, grp, total, lane, err);
+            const uint32_t before = group_lookback(state, grp, total, lane, err, spin_bound);
             if (t == 0) { s_base = before; s_total = total; }
         }
         __syncthreads();
@@ -854,7 +851,7 @@ struct DevView {
 // when the COO matrix is uploaded (setup, not the timed path).
 struct CooWorkspace {
     size_t bytes = 0;
-    size_t off_key[2], off_aux[2], off_val[2], off_counts, off_sums, off_state, off_total, off_gwin;
+    size_t off_key[2], off_aux[2], off_val[2], off_counts, off_sums, off_state, off_total, off_gwin, off_gstart, off_part;
 };
 
 #ifndef SPAL_COO_GROUP_TARGET
@@ -889,9 +886,11 @@ static CooWorkspace coo_workspace_layout(uint64_t len, uint64_t nrows, size_t el
     }
     w.off_counts = take(ncounts * 4);
     w.off_sums = take(((scan_n + kScanTile - 1) / kScanTile) * 4);
-    w.off_state = take(ngroups * 8 + 16);   // the look-back words of coo_group_sort, then its error flag
+    w.off_state = take(ngroups * 8 + 16);   // the look-back words of coo_group_sort, then {error flags, ticket, fullest group, -}
     w.off_total = take(4);
     w.off_gwin = take(ngroups * 8);         // one uint2 per group of rows
+    w.off_gstart = take((ngroups + 1) * 4); // first sorted entry of every group
+    w.off_part = take((size_t)kCheckBlocks * 4);
     w.bytes = o;
     return w;
 }
@@ -908,53 +907,6 @@ struct Assembled {
     // sort produced it on the way (saves the CSR planner its own pass over the matrix)
     std::vector<uint2> win256;
 };
-
-// The first radix pass of an assembly reads the uploaded triplets as they are, so its per-tile digit counts are
-// a function of the handle alone: counted and scanned once, when the triplets arrive (for rows; for columns when the
-// first CSC assembly needs them), instead of in every assembly.
-static hipError_t coo_first_pass_offsets(spal_coo *c, bool by_cols, hipStream_t st) {
-    const uint64_t len = c->len, n_major = by_cols ? c->ncols : c->nrows;
-    if (len == 0) return hipSuccess;
-    const uint32_t shift = coo_group_bits(len, n_major);
-    const uint32_t nblk = (uint32_t)((len + kSortTile - 1) / kSortTile);
-    const uint64_t ncounts = 256ull * nblk;
-    const uint32_t ngroups = coo_group_count(len, n_major);
-    const uint32_t *keys = by_cols ? c->d_cols : c->d_rows;
-    uint32_t *d = nullptr, *sums = nullptr, *gs = nullptr, *part = nullptr;
-    const uint64_t scan_n = std::max<uint64_t>(ncounts, ngroups);
-    hipError_t e = dev_alloc((void **)&d, ncounts * 4);
-    if (e == hipSuccess) e = dev_alloc((void **)&sums, ((scan_n + kScanTile - 1) / kScanTile + 1) * 4);
-    if (e == hipSuccess) e = dev_alloc((void **)&gs, ((size_t)ngroups + 1) * 4);
-    if (e == hipSuccess) e = dev_alloc((void **)&part, (size_t)(kCheckBlocks + 4) * 4);
-    uint32_t fullest = 0;
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(radix_hist, dim3(nblk), dim3(kHistThreads), 0, st, keys, len, shift, d, nblk);
-        e = exclusive_scan_u32(d, d, ncounts, sums, nullptr, st);
-    }
-    // the groups: entries per group of 2^shift majors (a histogram of the uploaded indices), their offsets, the fullest
-    if (e == hipSuccess) e = hipMemsetAsync(gs, 0, ((size_t)ngroups + 1) * 4, st);
-    if (e == hipSuccess) {
-        const uint32_t blocks = (uint32_t)std::min<uint64_t>((len + 1023) / 1024, 4096);
-        hipLaunchKernelGGL(coo_group_hist, dim3(blocks), dim3(256), 0, st, keys, len, shift, gs);
-        e = exclusive_scan_u32(gs, gs, ngroups, sums, nullptr, st, true);
-    }
-    if (e == hipSuccess) {
-        const uint32_t nparts = std::max<uint32_t>(std::min<uint32_t>((ngroups + 255) / 256, (uint32_t)kCheckBlocks), 1u);
-        hipLaunchKernelGGL(groups_check, dim3(nparts), dim3(256), 0, st, gs, ngroups, part + 4);
-        hipLaunchKernelGGL(groups_check_final, dim3(1), dim3(256), 0, st, part + 4, nparts, part);
-        e = hipMemcpyAsync(&fullest, part, 4, hipMemcpyDeviceToHost, st);
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)dev_free(sums);
-    (void)dev_free(part);
-    if (e != hipSuccess) { (void)dev_free(d); (void)dev_free(gs); return e; }
-    const int o = by_cols ? 1 : 0;
-    c->d_first_offs[o] = d;
-    c->first_shift[o] = (int)shift;
-    c->d_gstart[o] = gs;
-    c->fullest[o] = fullest;
-    return hipSuccess;
-}
 
 template <typename T>
 static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &res) {
@@ -978,7 +930,6 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
     }
 
     std::lock_guard<std::mutex> lock(c->mu);  // one assembly at a time per handle (shared workspace)
-    if (!c->d_gstart[by_cols ? 1 : 0]) SPAL_HIP_TRY(coo_first_pass_offsets(c, by_cols, st));   // first assembly in this orientation
     const CooWorkspace ws = coo_workspace_layout(len, nrows, sizeof(T));
     if (!c->d_work || c->work_bytes < ws.bytes) {
         if (c->d_work) { (void)dev_free(c->d_work); c->d_work = nullptr; }
@@ -996,22 +947,35 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
     sb.counts = (uint32_t *)(wb + ws.off_counts);
     sb.sums = sums.as<uint32_t>();
 
-    // The groups of 2^gbits rows (about a thousand entries on average) that are finished in LDS, their offsets in
-    // the row-sorted triplets and the fullest one: known since the upload (coo_first_pass_offsets).
-    // LDS of the group kernel is 17 B per entry of capacity: the smallest capacity that holds the fullest group
+    // The groups of 2^gbits rows (about a thousand entries on average) that are finished in LDS.  EVERYTHING that
+    // depends on the triplets is computed here, in the assembly (the reference's `from` counts and scans inside the
+    // call too, src/csr/conv/coo.rs:9-22; a `push` would invalidate anything kept from an earlier one): both passes'
+    // digit counts, the groups' offsets (from the sorted keys) and the fullest group.  Only a HINT survives on the
+    // handle: the fullest group of the last assembly, which picks the LDS capacity of the group kernel without a host
+    // round trip in the middle; the kernel checks it (a group that does not fit raises a flag) and the device computes
+    // the true maximum beside, so a wrong hint costs a second launch of that kernel, never a wrong result.
+    // LDS of the group kernel is 13 B per entry of capacity: the smallest capacity that holds the fullest group
     // (more workgroups per CU); none -> general route
     const double mean = (double)len / (double)nrows;
     const uint32_t gbits = coo_group_bits(len, n_major);
     const uint32_t ngroups = coo_group_count(len, n_major);
     const int o = by_cols ? 1 : 0;
-    const uint32_t fullest = c->fullest[o];
-    int group_cap = !c->d_gstart[o] ? 0 : fullest <= 512 ? 512 : fullest <= 1024 ? 1024 : fullest <= 1536 ? 1536
-                    : fullest <= (uint32_t)kGroupCap ? kGroupCap : 0;
-    c->last_group_rows = group_cap ? (int)(1u << gbits) : 0;
-    c->last_group_cap = group_cap;
-    if (getenv("SPAL_COO_DEBUG"))
-        fprintf(stderr, "[spal coo] %.2f entries/row -> groups of %u rows, fullest %u -> capacity %d%s\n", mean,
-                1u << gbits, fullest, group_cap, group_cap ? "" : " (general route)");
+    auto cap_for = [](uint32_t fullest) {
+        return fullest <= 512 ? 512 : fullest <= 1024 ? 1024 : fullest <= 1536 ? 1536 : fullest <= (uint32_t)kGroupCap ? kGroupCap : 0;
+    };
+    uint32_t guess = c->cap_hint[o];
+    if (!guess) {   // first assembly: indices spread evenly would give Poisson counts per group -- mean + 6 sigma
+        const double gmean = (double)len / (double)ngroups;
+        guess = (uint32_t)std::min<double>(gmean + 6.0 * std::sqrt(gmean) + 16.0, (double)kGroupCap);
+    }
+    int group_cap = cap_for(guess);
+    if (const char *e = getenv("SPAL_COO_ROUTE")) if (!strcmp(e, "general")) group_cap = 0;
+    uint32_t spin_bound = kLookbackSpins;
+    if (const char *e = getenv("SPAL_COO_LOOKBACK_SPINS")) spin_bound = (uint32_t)strtoul(e, nullptr, 10);
+    const bool use_ticket = !(getenv("SPAL_COO_TICKET") && getenv("SPAL_COO_TICKET")[0] == '0');
+    c->last_group_rows = 0;
+    c->last_group_cap = 0;
+    c->last_relaunches = 0;
 
     uint32_t nnz = 0;
     DevBuf ocol, oval;
@@ -1019,31 +983,56 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
     if (group_cap) {
         // ---- 1. stable sort by the row bits above gbits, (col, value) carried along; the first pass reads the
         // uploaded triplets directly (they stay untouched)
-        SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, gbits, rbits - gbits, cur, st, d_major, d_minor, (const T *)c->d_vals,
-                                        (c->d_first_offs[o] && c->first_shift[o] == (int)gbits) ? c->d_first_offs[o] : nullptr));
-        // ---- 2. per group: rows, columns, run sums, zero drop in LDS; its place in the result by look-back over
-        // the groups before it; survivors and rowptr written at their final offsets.  The result arrays are sized
-        // for no entry dropped (the count is only known afterwards) and trimmed when a quarter or more is unused.
-        auto k_sort = group_cap == 512 ? coo_group_sort<T, 512> : group_cap == 1024 ? coo_group_sort<T, 1024>
-                      : group_cap == 1536 ? coo_group_sort<T, 1536> : coo_group_sort<T, kGroupCap>;
+        SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, gbits, rbits - gbits, cur, st, d_major, d_minor, (const T *)c->d_vals));
+        // ---- 2. the groups' offsets in the sorted triplets (one streaming pass over the sorted keys) and the fullest
+        uint32_t *d_gstart = reinterpret_cast<uint32_t *>(wb + ws.off_gstart);
+        uint32_t *d_part = reinterpret_cast<uint32_t *>(wb + ws.off_part);
         uint2 *d_gwin = reinterpret_cast<uint2 *>(wb + ws.off_gwin);
         unsigned long long *d_state = reinterpret_cast<unsigned long long *>(wb + ws.off_state);
-        uint32_t *d_err = reinterpret_cast<uint32_t *>(d_state + ngroups);
+        uint32_t *d_err = reinterpret_cast<uint32_t *>(d_state + ngroups);   // {flags, ticket, fullest, -}
+        launch_row_starts(sb.key[cur], (uint32_t)len, ngroups, d_gstart, st, gbits);
+        SPAL_HIP_TRY(hipMemsetAsync(d_state, 0, (size_t)ngroups * 8 + 16, st));
+        {
+            const uint32_t nparts = std::max<uint32_t>(std::min<uint32_t>((ngroups + 255) / 256, (uint32_t)kCheckBlocks), 1u);
+            hipLaunchKernelGGL(groups_check, dim3(nparts), dim3(256), 0, st, d_gstart, ngroups, d_part);
+            hipLaunchKernelGGL(groups_check_final, dim3(1), dim3(256), 0, st, d_part, nparts, d_err + 2);
+        }
+        // ---- 3. per group: rows, columns, run sums, zero drop in LDS; its place in the result by look-back over
+        // the groups before it; survivors and rowptr written at their final offsets.  The result arrays are sized
+        // for no entry dropped (the count is only known afterwards) and trimmed when a quarter or more is unused.
         uint64_t cap = len + 256;  // + the stream kernel's over-read margin
         SPAL_HIP_TRY(ocol.alloc(cap * 4));
         SPAL_HIP_TRY(oval.alloc(cap * sizeof(T)));
-        SPAL_HIP_TRY(hipMemsetAsync(d_state, 0, (size_t)ngroups * 8 + 16, st));
-        hipLaunchKernelGGL(k_sort, dim3(ngroups), dim3(256), 0, st, c->d_gstart[o], sb.key[cur], sb.aux[cur],
-                           sb.val[cur], nrows, gbits, ngroups, d_state, d_err, rowptr.as<uint32_t>(),
-                           ocol.as<uint32_t>(), oval.as<T>(), d_gwin);
-        SPAL_HIP_TRY(hipGetLastError());
         std::vector<uint2> gwin(ngroups);
-        unsigned long long tail[2] = {0, 0};   // the last group's state word (survivors of all groups), the error flag
-        SPAL_HIP_TRY(hipMemcpyAsync(tail, d_state + (ngroups - 1), 16, hipMemcpyDeviceToHost, st));
-        SPAL_HIP_TRY(hipMemcpyAsync(gwin.data(), d_gwin, (size_t)ngroups * sizeof(uint2), hipMemcpyDeviceToHost, st));
-        SPAL_HIP_TRY(hipStreamSynchronize(st));
-        if ((uint32_t)tail[1] == 0 && (tail[0] >> 32) == 2) {
+        unsigned long long tail[3] = {0, 0, 0};   // the last group's state word (survivors of all groups); {flags, ticket}; {fullest, -}
+        for (int attempt = 0; attempt < 2 && group_cap; ++attempt) {
+            auto k_sort = group_cap == 512 ? coo_group_sort<T, 512> : group_cap == 1024 ? coo_group_sort<T, 1024>
+                          : group_cap == 1536 ? coo_group_sort<T, 1536> : coo_group_sort<T, kGroupCap>;
+            hipLaunchKernelGGL(k_sort, dim3(ngroups), dim3(256), 0, st, d_gstart, sb.key[cur], sb.aux[cur],
+                               sb.val[cur], nrows, gbits, ngroups, d_state, d_err, use_ticket ? d_err + 1 : nullptr, spin_bound,
+                               rowptr.as<uint32_t>(), ocol.as<uint32_t>(), oval.as<T>(), d_gwin);
+            SPAL_HIP_TRY(hipGetLastError());
+            SPAL_HIP_TRY(hipMemcpyAsync(tail, d_state + (ngroups - 1), 24, hipMemcpyDeviceToHost, st));
+            SPAL_HIP_TRY(hipMemcpyAsync(gwin.data(), d_gwin, (size_t)ngroups * sizeof(uint2), hipMemcpyDeviceToHost, st));
+            SPAL_HIP_TRY(hipStreamSynchronize(st));
+            const uint32_t flags = (uint32_t)tail[1], fullest = (uint32_t)tail[2];
+            c->cap_hint[o] = std::max<uint32_t>(fullest, 1u);
+            if (getenv("SPAL_COO_DEBUG"))
+                fprintf(stderr, "[spal coo] %.2f entries/row -> groups of %u rows, guessed %u, fullest %u, capacity %d, flags %u\n",
+                        mean, 1u << gbits, guess, fullest, group_cap, flags);
+            if (!(flags & 2u)) break;              // every group fitted
+            // the guess was too small: once more at the capacity the fullest group needs (the sorted triplets and
+            // the groups' offsets stand), or the general route when no capacity holds it
+            group_cap = (flags & 1u) ? 0 : cap_for(fullest);
+            c->last_relaunches++;
+            if (group_cap) {
+                SPAL_HIP_TRY(hipMemsetAsync(d_state, 0, (size_t)ngroups * 8 + 8, st));   // states, flags, ticket (not the maximum)
+            }
+        }
+        if (group_cap && (uint32_t)tail[1] == 0 && (tail[0] >> 32) == 2) {
             nnz = (uint32_t)tail[0];
+            c->last_group_rows = (int)(1u << gbits);
+            c->last_group_cap = group_cap;
             {   // fold the groups (2^gbits <= 256 rows each) into windows of 256 rows
                 const uint32_t per = 256u >> gbits;
                 res.win256.assign(((size_t)nrows + 255) / 256, make_uint2(0xffffffffu, 0u));
@@ -1069,10 +1058,10 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
             res.val = oval.release(); res.nnz = nnz; res.cap = cap;
             return SPAL_OK;
         }
-        // the look-back gave up waiting (never observed: see group_lookback) -> the general route below
-        if (getenv("SPAL_COO_DEBUG")) fprintf(stderr, "[spal coo] look-back timed out, general route\n");
-        c->last_group_rows = 0;
-        c->last_group_cap = 0;
+        // a group beyond every capacity, or the look-back gave up waiting (its backstop: see group_lookback)
+        // -> the general route below
+        if (getenv("SPAL_COO_DEBUG")) fprintf(stderr, "[spal coo] flags %u: general route\n", (uint32_t)tail[1]);
+        c->last_lookback_gave_up += ((uint32_t)tail[1] & 1u) ? 1 : 0;
         (void)dev_free(ocol.release());
         (void)dev_free(oval.release());
     }
@@ -1202,10 +1191,6 @@ int transpose_device(int device, int elem_size, uint64_t nmajor, uint64_t nminor
 static void coo_free(spal_coo *c) {
     if (!c) return;
     (void)dev_free(c->d_work);
-    (void)dev_free(c->d_first_offs[0]);
-    (void)dev_free(c->d_first_offs[1]);
-    (void)dev_free(c->d_gstart[0]);
-    (void)dev_free(c->d_gstart[1]);
     (void)dev_free(c->d_rows);
     (void)dev_free(c->d_cols);
     (void)dev_free(c->d_vals);
@@ -1252,9 +1237,6 @@ static int coo_upload(int device, uint64_t nrows, uint64_t ncols, uint64_t len, 
         c->work_bytes = coo_workspace_layout(len, nrows, sizeof(T)).bytes;
         e = dev_alloc((void **)&c->d_work, c->work_bytes);
     }
-    // ... and the first radix pass's tile offsets + the groups' offsets (see coo_first_pass_offsets)
-    // (by rows now; by columns when the first CSC assembly asks for it)
-    if (e == hipSuccess && len) e = coo_first_pass_offsets(c, false, nullptr);
     if (e != hipSuccess) {
         coo_free(c);
         return fail(e == hipErrorOutOfMemory ? SPAL_ERR_OUT_OF_MEMORY : SPAL_ERR_HIP,
@@ -1300,10 +1282,11 @@ int spal_coo_describe(spal_coo_t c, char *buf, size_t buf_len) {
     if (!c || !buf || !buf_len) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_coo_describe: null argument");
     snprintf(buf, buf_len,
              "{\"format\": \"coo\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"len\": %llu, "
-             "\"last_route\": \"%s\", \"group_rows\": %d, \"group_cap\": %d}",
+             "\"last_route\": \"%s\", \"group_rows\": %d, \"group_cap\": %d, \"group_relaunches\": %d, "
+             "\"lookback_gave_up\": %d}",
              c->elem_size == 8 ? "f64" : "f32", (unsigned long long)c->nrows, (unsigned long long)c->ncols,
              (unsigned long long)c->len, c->last_group_rows ? "local_sort" : "general", c->last_group_rows,
-             c->last_group_cap);
+             c->last_group_cap, c->last_relaunches, c->last_lookback_gave_up);
     return SPAL_OK;
 }
 int spal_coo_assemble_csr(spal_coo_t c, void *stream, spal_csr_t *out) {

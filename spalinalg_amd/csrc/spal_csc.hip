@@ -26,6 +26,9 @@ namespace spal {
 #ifndef SPAL_CSC_BLOCK
 #define SPAL_CSC_BLOCK 1024
 #endif
+#ifndef SPAL_CSC_FENCES
+#define SPAL_CSC_FENCES 0   // 1: release / acquire fences around the hand-off's flag (see csc_spmv_scatter)
+#endif
 
 constexpr int kCscBlock = SPAL_CSC_BLOCK;      // threads of the scatter kernel
 // Columns per super-tile: the widest of 4096 / 2048 / 1024 whose row windows fit LDS (csc_plan_build).  Wider
@@ -94,16 +97,35 @@ __global__ __launch_bounds__(kCscBlock, kCscBlock >= 1024 ? 1 : 2) void csc_spmv
     const uint32_t *__restrict__ meta, const T *__restrict__ vals, const T *__restrict__ x,
     T *__restrict__ y, const uint4 *__restrict__ desc, uint32_t ncols, uint32_t nblocks,
     uint32_t per_xcd, uint32_t last_pair, T *__restrict__ windows, const uint32_t *__restrict__ prev_hi,
-    uint32_t *__restrict__ flags, uint32_t epoch, uint32_t nrows) {
+    uint32_t *__restrict__ flags, uint32_t epoch, uint32_t nrows, uint32_t ticket_base, uint32_t use_ticket,
+    uint32_t spin_bound, uint32_t *__restrict__ gave_up) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
     using pair_t = typename Pair<T>::type;
     using u2_t = __attribute__((ext_vector_type(2))) uint32_t;
     T *xt = reinterpret_cast<T *>(spal_smem);  // x of the super-tile's columns
     T *yw = xt + kCscCols;                     // y window accumulators
 
-    // neighbour hand-off: super-tile b waits for b - 1, which must have been dispatched before it -> tile order =
-    // dispatch order; otherwise each XCD takes a contiguous run of super-tiles
-    const uint32_t b = prev_hi ? blockIdx.x : xcd_contiguous_block(blockIdx.x, per_xcd);
+    // Neighbour hand-off: super-tile b waits for b - 1, which must therefore have STARTED before it.  The super-tile a
+    // workgroup takes is its ticket -- one atomicAdd on flags[nblocks + 1] per workgroup, ticket_base = the counter's
+    // value when this launch began (launches of one handle are chained) -- i.e. the order in which workgroups actually
+    // start, not their blockIdx: the holder of b started after the holders of 0 ... b - 1, which are resident or
+    // done, so the wait below always ends, whatever order the dispatcher takes the workgroups in.  (use_ticket = 0:
+    // blockIdx order, option "ticket"; enough when all workgroups of the launch are resident together.)
+    // Without the hand-off each XCD takes a contiguous run of super-tiles.
+    uint32_t b;
+    if (prev_hi) {
+        b = blockIdx.x;
+        if (use_ticket) {
+            // (through the first word of the dynamic LDS: the kernel may use all 160 KiB of it, a static variable would not fit)
+            uint32_t *s_ticket = reinterpret_cast<uint32_t *>(spal_smem);
+            if (threadIdx.x == 0) *s_ticket = atomicAdd(&flags[nblocks + 1], 1u) - ticket_base;
+            __syncthreads();
+            b = *s_ticket;
+            __syncthreads();   // before the x tile is written there
+        }
+    } else {
+        b = xcd_contiguous_block(blockIdx.x, per_xcd);
+    }
     if (b >= nblocks) return;
     const uint32_t k0 = b * kCscCols, k1 = min(k0 + (uint32_t)kCscCols, ncols);
     // desc and the two column pointers are independent loads: one round trip for the three
@@ -184,19 +206,37 @@ __global__ __launch_bounds__(kCscBlock, kCscBlock >= 1024 ? 1 : 2) void csc_spmv
                 __hip_atomic_store(&y[r], yw[r - lo], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (b + 1 == nblocks)
                 for (uint32_t r = hi + threadIdx.x; r < nrows; r += kCscBlock) y[r] = T(0);     // rows after the last window
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave, before the barrier the flag sits behind
+            // Publication.  Every access that takes part is an agent-scope atomic (sc1): the stores of y above are
+            // written through to the device's point of coherence and acknowledged from there, and `s_waitcnt vmcnt(0)`
+            // holds every storing wave until its acknowledgements are in -- the rows are PERFORMED at agent scope before
+            // the barrier, the flag is stored after it.  The consumer reads the flag, then (control dependency + the
+            // barrier) the rows, again with sc1 loads, which are served from the point of coherence, never from a line
+            // its XCD's L2 happens to hold.  That is the ISA-level contract (gfx942 / gfx950 memory model: agent-scope
+            // atomics bypass the non-coherent levels); what release / acquire would ADD is a write-back of the L2's
+            // dirty non-atomic lines (`buffer_wbl2 sc1`) and an invalidate (`buffer_inv sc1`) -- there are no
+            // non-atomic lines in this exchange.  Measured (-DSPAL_CSC_FENCES=1: flag stored with release, acquire fence
+            // after the spin): 44.9 instead of 39.0 us per product at config 4, +15 % (profiles/r03/csc_handoff.txt),
+            // hence off by default; tests/test_gpu_csc_coo.py runs 600 checked products back to back either way.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+#if SPAL_CSC_FENCES
+            if (threadIdx.x == 0) __hip_atomic_store(&flags[b], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
             if (threadIdx.x == 0) __hip_atomic_store(&flags[b], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             if (ph > lo) {   // uniform: rows [lo, ph) also belong to super-tile b - 1, which stores them
                 if (threadIdx.x == 0) {
                     uint32_t spins = 0;
                     while (__hip_atomic_load(&flags[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-                        if (++spins > (1u << 22)) {   // (a bound, so that the wave ends whatever happens)
-                            __hip_atomic_store(&flags[nblocks], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (++spins > spin_bound) {   // a backstop, so that the wave ends whatever happens: the host is told
+                            __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (host memory)
                             break;
                         }
                         __builtin_amdgcn_s_sleep(8);
                     }
+#if SPAL_CSC_FENCES
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
                 }
                 __syncthreads();
                 for (uint32_t r = lo + threadIdx.x; r < min(ph, hi); r += kCscBlock) {
@@ -294,7 +334,7 @@ static int pick_lanes_csc(double mean) {
 }
 
 template <typename T, int COLS>
-static hipError_t csc_launch_c(const spal_csc *a, const void *x, void *y, hipStream_t st, uint32_t epoch) {
+static hipError_t csc_launch_c(const spal_csc *a, const void *x, void *y, hipStream_t st, uint32_t epoch, uint32_t ticket_base) {
     const uint32_t per_xcd = (a->nblocks + 7) / 8;
     // x tile + the y window; global-mode super-tiles keep their column pointers where the window would be
     const size_t lds = std::max(((size_t)COLS + a->lds_entries) * sizeof(T),
@@ -315,7 +355,8 @@ static hipError_t csc_launch_c(const spal_csc *a, const void *x, void *y, hipStr
                        (uint32_t)a->ncols, a->nblocks, per_xcd,
                        (uint32_t)(((a->nnz + kStreamPad) & ~(uint64_t)1) - 2),
                        (a->flush == 1 && a->d_windows) ? (T *)a->d_windows : (T *)nullptr,
-                       epoch ? a->d_prev_hi : (const uint32_t *)nullptr, a->d_flags, epoch, (uint32_t)a->nrows);
+                       epoch ? a->d_prev_hi : (const uint32_t *)nullptr, a->d_flags, epoch, (uint32_t)a->nrows,
+                       ticket_base, (uint32_t)(a->use_ticket < 0 ? a->ticket_auto : a->use_ticket), a->spin_bound, a->d_gave_up);
     return hipGetLastError();
 }
 
@@ -333,9 +374,19 @@ static hipError_t csc_launch_t(spal_csc *a, const void *x, void *y, hipStream_t 
         if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) ordered = false;
     }
     std::unique_lock<std::mutex> chain(a->mu_launch, std::defer_lock);
-    uint32_t epoch = 0;
+    uint32_t epoch = 0, ticket_base = 0;
     if (ordered) {
         chain.lock();
+        // A super-tile of an EARLIER launch hit the hand-off's spin bound (the backstop; the kernel reports it through
+        // host memory, so looking costs nothing): that product's y is invalid.  The caller is told here, once, and the
+        // handle flushes with global atomics from now on.  (The host-vector path sees it after its own
+        // synchronisation and repeats the product itself, csc_spmv_host.)
+        if (a->h_gave_up && __atomic_load_n(a->h_gave_up, __ATOMIC_RELAXED)) {
+            __atomic_store_n(a->h_gave_up, 0u, __ATOMIC_RELAXED);
+            a->ordered = 0;
+            a->handoff_timeouts++;
+            return hipErrorLaunchTimeOut;
+        }
         if (!a->ev_last) {
             e = hipEventCreateWithFlags(&a->ev_last, hipEventDisableTiming);
             if (e != hipSuccess) return e;
@@ -343,24 +394,27 @@ static hipError_t csc_launch_t(spal_csc *a, const void *x, void *y, hipStream_t 
             e = hipStreamWaitEvent(st, a->ev_last, 0);
             if (e != hipSuccess) return e;
         }
-        if (++a->epoch == 0) {   // (wrapped after 2^32 launches: the flags start over)
-            e = hipMemsetAsync(a->d_flags, 0, ((size_t)a->nblocks + 1) * 4, st);
+        if (++a->epoch == 0) {   // (wrapped after 2^32 launches: the flags and the ticket counter start over)
+            e = hipMemsetAsync(a->d_flags, 0, ((size_t)a->nblocks + 2) * 4, st);
             if (e != hipSuccess) return e;
             a->epoch = 1;
+            a->ticket_next = 0;
         }
         epoch = a->epoch;
+        ticket_base = a->ticket_next;               // every workgroup of the grid takes one ticket
+        a->ticket_next += ((a->nblocks + 7) / 8) * 8;
     }
     if (!ordered && (!assign || a->nnz == 0)) {
         // (a kernel, not hipMemsetAsync: as a node of a captured graph the memset zeroed every other element from
-        //  the second replay on -- ROCm 7.2, tools/lab_csc_capture.py)
+        //  the second replay on -- ROCm 7.2, tools/lab.py csc_capture)
         hipLaunchKernelGGL(fill_zero<T>, dim3((uint32_t)((a->nrows + 255) / 256)), dim3(256), 0, st, (T *)y, a->nrows);
         e = hipGetLastError();
     }
     if (e != hipSuccess || a->nnz == 0) return e;
     switch (a->cols_per_block) {
-        case 1024: e = csc_launch_c<T, 1024>(a, x, y, st, epoch); break;
-        case 2048: e = csc_launch_c<T, 2048>(a, x, y, st, epoch); break;
-        case 4096: e = csc_launch_c<T, 4096>(a, x, y, st, epoch); break;
+        case 1024: e = csc_launch_c<T, 1024>(a, x, y, st, epoch, ticket_base); break;
+        case 2048: e = csc_launch_c<T, 2048>(a, x, y, st, epoch, ticket_base); break;
+        case 4096: e = csc_launch_c<T, 4096>(a, x, y, st, epoch, ticket_base); break;
         default: return hipErrorInvalidValue;
     }
     if (ordered) {
@@ -388,6 +442,10 @@ static int csc_launch(spal_csc *a, const void *x, void *y, hipStream_t st) {
     }
     hipError_t e = a->elem_size == 8 ? csc_launch_t<double>(a, x, y, st)
                                      : csc_launch_t<float>(a, x, y, st);
+    if (e == hipErrorLaunchTimeOut)
+        return fail(SPAL_ERR_HIP, "csc spmv: an earlier product of this handle gave up waiting in the neighbour hand-off "
+                    "(spin bound reached): that product's y is invalid; nothing was launched now, and the handle flushes "
+                    "with global atomics from here on");
     if (e != hipSuccess) return fail(SPAL_ERR_HIP, "csc spmv launch failed: %s", hipGetErrorString(e));
     return SPAL_OK;
 }
@@ -402,6 +460,10 @@ static int csc_plan_build(spal_csc *a) {
     if (a->d_flags) { SPAL_HIP_TRY(dev_free(a->d_flags)); a->d_flags = nullptr; }
     a->ordered = 0;
     a->epoch = 0;
+    a->ticket_next = 0;
+    a->ticket_auto = 0;
+    a->spin_bound = 1u << 22;
+    if (const char *e = getenv("SPAL_CSC_HANDOFF_SPINS")) a->spin_bound = (uint32_t)strtoul(e, nullptr, 10);   // (tests: 0 forces the backstop)
     a->windows_entries = 0;
     a->all_lds = 0;
     a->nchunks = 0;
@@ -499,11 +561,30 @@ static int csc_plan_build(spal_csc *a) {
             if (ok && a->nrows - hi1 > fill_cap) ok = false;
             if (ok) {
                 SPAL_HIP_TRY(dev_alloc((void **)&a->d_prev_hi, (size_t)a->nblocks * 4));
-                SPAL_HIP_TRY(dev_alloc((void **)&a->d_flags, ((size_t)a->nblocks + 1) * 4));
+                SPAL_HIP_TRY(dev_alloc((void **)&a->d_flags, ((size_t)a->nblocks + 2) * 4));   // flags, -, ticket counter
                 SPAL_HIP_TRY(hipMemcpyAsync(a->d_prev_hi, prev_hi.data(), (size_t)a->nblocks * 4, hipMemcpyHostToDevice, a->stream));
-                SPAL_HIP_TRY(hipMemsetAsync(a->d_flags, 0, ((size_t)a->nblocks + 1) * 4, a->stream));
+                SPAL_HIP_TRY(hipMemsetAsync(a->d_flags, 0, ((size_t)a->nblocks + 2) * 4, a->stream));
+                if (!a->h_gave_up) {   // one word of mapped host memory: the kernel's "gave up" report
+                    SPAL_HIP_TRY(hipHostMalloc((void **)&a->h_gave_up, 64, hipHostMallocMapped));
+                    *a->h_gave_up = 0;
+                    SPAL_HIP_TRY(hipHostGetDevicePointer((void **)&a->d_gave_up, a->h_gave_up, 0));
+                }
                 SPAL_HIP_TRY(hipStreamSynchronize(a->stream));   // prev_hi goes out of scope
                 a->ordered = 1;
+                // Which super-tile a workgroup takes: when the device holds ALL workgroups of the launch at once
+                // (config 4: 245 workgroups, 256 CUs x 1), every one of them becomes resident whatever the dispatch
+                // order and a waiting workgroup never keeps its predecessor off the device: blockIdx will do, and the
+                // ticket's round trip at the start of every workgroup (+ 4 us of 39 at config 4) is saved.  Larger
+                // launches take their super-tile from the start-order ticket (see csc_spmv_scatter).
+                {
+                    int dev_id = 0, cus = 0, per_cu = 0;
+                    (void)hipGetDevice(&dev_id);
+                    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
+                    const size_t lds = std::max(((size_t)kCscCols + a->lds_entries) * (size_t)a->elem_size,
+                                                (size_t)kCscCols * (size_t)a->elem_size + ((size_t)kCscCols + 2) * 4);
+                    per_cu = lds > 80u * 1024u ? 1 : 2;       // (1024-thread workgroups: at most two per CU)
+                    a->ticket_auto = (uint64_t)((a->nblocks + 7) / 8) * 8 > (uint64_t)cus * (uint64_t)per_cu ? 1 : 0;
+                }
             }
         }
         a->windows_entries = slot;
@@ -568,6 +649,7 @@ int csc_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, 
         (void)dev_free(a->d_meta); (void)dev_free(a->d_desc);
         (void)dev_free(a->d_windows); (void)dev_free(a->d_chunk_ptr); (void)dev_free(a->d_chunk_blk);
         (void)dev_free(a->d_prev_hi); (void)dev_free(a->d_flags);
+        if (a->h_gave_up) (void)hipHostFree(a->h_gave_up);
         stream_release(a->stream);
         delete a;
         return st;
@@ -598,6 +680,7 @@ static void csc_free(spal_csc *a) {
     (void)dev_free(a->d_prev_hi);
     (void)dev_free(a->d_flags);
     if (a->ev_last) (void)hipEventDestroy(a->ev_last);
+    if (a->h_gave_up) (void)hipHostFree(a->h_gave_up);
     (void)dev_free(a->d_x);
     (void)dev_free(a->d_y);
     stream_release(a->stream);
@@ -675,14 +758,17 @@ static int csc_spmv_host(spal_csc_t a, const T *x, uint64_t x_len, T *y, uint64_
     if (!a->d_y) SPAL_HIP_TRY(dev_alloc((void **)&a->d_y, a->nrows * sizeof(T)));
     SPAL_HIP_TRY(hipMemcpyAsync(a->d_x, x, a->ncols * sizeof(T), hipMemcpyHostToDevice, a->stream));
     SPAL_TRY(csc_launch(a, a->d_x, a->d_y, a->stream));
-    uint32_t gave_up = 0;   // neighbour hand-off: a super-tile hit its spin bound (never observed; see csc_spmv_scatter)
-    const bool handoff = a->kernel == 1 && a->flush == 0 && a->ordered && a->d_flags;
-    if (handoff)
-        SPAL_HIP_TRY(hipMemcpyAsync(&gave_up, a->d_flags + a->nblocks, 4, hipMemcpyDeviceToHost, a->stream));
     SPAL_HIP_TRY(hipMemcpyAsync(y, a->d_y, a->nrows * sizeof(T), hipMemcpyDeviceToHost, a->stream));
     SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
-    if (handoff && gave_up) {   // this handle keeps to the atomics flush from now on; the product is repeated
-        a->ordered = 0;
+    // neighbour hand-off: a super-tile hit its spin bound (the backstop; see csc_spmv_scatter) -- this handle keeps to
+    // the atomics flush from now on and the product is repeated
+    if (a->h_gave_up && __atomic_load_n(a->h_gave_up, __ATOMIC_RELAXED)) {
+        {
+            std::lock_guard<std::mutex> chain(a->mu_launch);
+            __atomic_store_n(a->h_gave_up, 0u, __ATOMIC_RELAXED);
+            a->ordered = 0;
+            a->handoff_timeouts++;
+        }
         SPAL_TRY(csc_launch(a, a->d_x, a->d_y, a->stream));
         SPAL_HIP_TRY(hipMemcpyAsync(y, a->d_y, a->nrows * sizeof(T), hipMemcpyDeviceToHost, a->stream));
         SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
@@ -863,6 +949,13 @@ int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value) {
         a->user_cols = (int)value;
         return csc_plan_build(a);
     }
+    if (!strcmp(key, "ticket")) {
+        // neighbour hand-off: 1 = a workgroup's super-tile is its start-order ticket, 0 = its blockIdx, -1 (default) =
+        // the ticket unless the device holds all workgroups of the launch at once
+        if (value < -1 || value > 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "ticket must be -1 (auto), 0 or 1");
+        a->use_ticket = (int)value;
+        return SPAL_OK;
+    }
     if (!strcmp(key, "lds")) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "lds must be 0 or 1");
         a->use_lds = (int)value;
@@ -876,7 +969,7 @@ int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len) {
              "{\"format\": \"csc\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"nnz\": %llu, "
              "\"kernel\": \"%s\", \"cols_per_block\": %d, \"blocks\": %u, \"lanes_per_col\": %d, "
              "\"lds_window_bytes\": %llu, \"lds_col_fraction\": %.4f, \"flush\": \"%s\", "
-             "\"window_store_bytes\": %llu}",
+             "\"window_store_bytes\": %llu, \"ticket\": %d, \"handoff_timeouts\": %d}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz,
              a->kernel == 2 ? "transposed_csr" : a->lds_entries ? "lds_privatised_scatter" : "atomic_scatter",
@@ -884,7 +977,8 @@ int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len) {
              a->lanes_per_col, (unsigned long long)a->lds_entries * (unsigned long long)a->elem_size,
              a->lds_col_fraction, (a->flush == 1 && a->d_windows) ? "windows_then_reduce"
                                   : (a->flush == 0 && a->ordered) ? "neighbour_handoff" : "global_atomics",
-             (unsigned long long)a->windows_entries * (unsigned long long)a->elem_size);
+             (unsigned long long)a->windows_entries * (unsigned long long)a->elem_size, a->use_ticket < 0 ? a->ticket_auto : a->use_ticket,
+             a->handoff_timeouts + ((a->h_gave_up && __atomic_load_n(a->h_gave_up, __ATOMIC_RELAXED)) ? 1 : 0));
     return SPAL_OK;
 }
 

@@ -813,6 +813,7 @@ static hipError_t launch_stream_main(const spal_csr *a, const void *x, void *y, 
 
 template <typename T>
 static hipError_t launch_lanes(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    if (a->plan.cblock && a->plan.cblock_on) return launch_cblock(a, x, y, st);   // columns anywhere: csr_cblock.hpp
     if (a->plan.kernel == 2) return launch_stream<T>(a, x, y, st);
     switch (a->plan.lanes_per_row) {
 #define SPAL_LANES_CASE(LL) \
@@ -1038,10 +1039,10 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
 int csr_plan_build(spal_csr *a) {
     CsrPlan &p = a->plan;
     const double mean = a->nrows ? (double)a->nnz / (double)a->nrows : 0.0;
-    // vector kernel geometry, from measurements (tools/lab_ab.py): one lane per entry
+    // vector kernel geometry, from measurements (tools/lab.py ab): one lane per entry
     // up to 64 entries per row; longer rows loop in batches of 4 L entries per
     // lane group, which 16 lanes per row keep busiest (128/row: 65 %, L = 64: 38 %)
-    // rows longer than a wave (tools/lab_longrows.py, 70 ... 1500 entries per row): a whole wave per row,
+    // rows longer than a wave (tools/lab.py longrows, 70 ... 1500 entries per row): a whole wave per row,
     // one row group in flight, and few rows per workgroup (below) beat 16 lanes per row everywhere
     // (100/row 56 % against 37 %, 400/row 67 % against 17 %, 1500/row 54 % against 23 %)
     if (!p.user_lanes) p.lanes_per_row = mean > 85.0 ? 64 : mean > 64.0 ? 32 : pick_lanes(mean);
@@ -1057,6 +1058,7 @@ int csr_plan_build(spal_csr *a) {
     p.slide = 0;
     p.ring_pages = 0;
     if (a->nnz == 0) {
+        cblock_free(a);
         p.kernel = 1;
         p.rows_per_block = 1024;
         p.nblocks = (uint32_t)((a->nrows + 1023) / 1024);
@@ -1067,7 +1069,7 @@ int csr_plan_build(spal_csr *a) {
 
     // ---- stream kernel: rows short enough that 64 / 32 / 24 / 16 / 12 / 8 of them fit a tile (auto: at least half
     // the rows in tiles that stream; fuller strips pay: 33/row 24 rows per tile 100 us vs 16 rows 109 us, 70/row
-    // 12 rows 143 us vs 8 rows 159 us, 81/row 155 vs 187 us).  Measured against the vector kernel on bands (tools/lab_rpt8.py): 54/row 82 % vs
+    // 12 rows 143 us vs 8 rows 159 us, 81/row 155 vs 187 us).  Measured against the vector kernel on bands (tools/lab.py rpt8): 54/row 82 % vs
     // 51 %, 63/row 84 % vs 47 %, 64/row 80 % (skewed strips) vs 50 %, 81/row 67 % vs 46 %, 100/row 71 % vs 54 %,
     // 120/row 68 % vs 56 %; 4-row tiles for 150 ... 250/row were level with or behind the vector kernel.
     if ((p.user_kernel == 0 && mean <= 120.0) || p.user_kernel == 2) {
@@ -1204,9 +1206,23 @@ int csr_plan_build(spal_csr *a) {
                 a->n_ovtiles = listed;
             }
             SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
+            // columns anywhere (most rows sit in super-tiles that gather x from global memory over a span no panel
+            // holds): the column-blocked kernel and its tiled copy of the matrix (csr_cblock.hpp)
+            {
+                uint64_t far_rows = 0;
+                for (uint32_t b = 0; b < p.nblocks; ++b)
+                    if (best_desc[b].z == kModeStreamGlobal && !(best_desc[b].w & 2u))
+                        far_rows += std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
+                p.nonlocal_row_fraction = (double)far_rows / (double)a->nrows;
+                if (p.cblock_user == 1 || (p.cblock_user < 0 && p.nonlocal_row_fraction >= 0.5))
+                    SPAL_TRY(cblock_plan(a, p.cblock_user == 1));
+                else
+                    cblock_free(a);
+            }
             return SPAL_OK;
         }
     }
+    cblock_free(a);
 
     // ---- vector kernel
     p.kernel = 1;
@@ -1224,7 +1240,7 @@ int csr_plan_build(spal_csr *a) {
         while (r0 > 64 && (double)r0 * mean > 131072.0) r0 >>= 1;
         // ... and a number of workgroups that fills whole rounds of the 512 the device holds at once (two of 1024
         // threads per CU): these launches are two or three rounds long, and 1250 workgroups (2.44 rounds) ran at
-        // 60 ... 67 % where 980 (1.9 rounds) ran at 73 ... 78 % (tools/lab_longrows.py threads).  R need not be
+        // 60 ... 67 % where 980 (1.9 rounds) ran at 73 ... 78 % (tools/lab.py longrows threads).  R need not be
         // a power of two.
         if (p.threads == 1024) {
             const double want = std::max(1.0, (double)a->nnz / 100000.0);              // workgroups of ~100 000 entries
@@ -1321,6 +1337,7 @@ static void csr_free(spal_csr *a) {
     (void)dev_free(a->d_ovtiles_slide);
     (void)dev_free(a->d_ptiles);
     (void)dev_free(a->d_pwin);
+    cblock_free(a);
     (void)dev_free(a->d_x);
     (void)dev_free(a->d_y);
     stream_release(a->stream);
@@ -1593,6 +1610,22 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
         if (e != hipSuccess) rc = fail(SPAL_ERR_HIP, "spal_csr_autotune: %s", hipGetErrorString(e));
         *ms_per_launch = ms / (float)n;
     };
+    // ---- 0. columns anywhere: the column-blocked kernel against the stream kernels (results are bit-identical)
+    a->cblock_us[0] = a->cblock_us[1] = 0.f;
+    if (p.cblock) {
+        float ms[2] = {0.f, 0.f};
+        for (int round = 0; round < 2 && rc == SPAL_OK; ++round)
+            for (int on = 0; on < 2 && rc == SPAL_OK; ++on) { p.cblock_on = on; timed(std::max(3, iters / 3), &ms[on]); }
+        if (rc == SPAL_OK) {
+            a->cblock_us[0] = ms[0] * 1e3f; a->cblock_us[1] = ms[1] * 1e3f;
+            p.cblock_on = ms[1] <= ms[0] ? 1 : 0;
+        }
+        if (p.cblock_on) {   // nothing of the stream kernels' forms to choose
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            return rc;
+        }
+    }
     // ---- 1. the form.  candidate c: bit 0 = walking form (sliding kernel / persistent), bit 1 = non-temporal y stores
     const bool walking_is_slide = p.slide != 0;
     int best = ((walking_is_slide ? p.slide_on : p.persistent) ? 1 : 0) | (p.nt_store ? 2 : 0);
@@ -1849,6 +1882,19 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
 #else
         return fail(SPAL_ERR_INVALID_ARGUMENT, "diag: this library is not an ablation build (-DSPAL_DIAG)");
 #endif
+    } else if (!strcmp(key, "cblock")) {
+        // the column-blocked kernel (csr_cblock.hpp): -1 = when most rows gather x from beyond L2, 0 = never, 1 = always
+        if (value < -1 || value > 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "cblock must be -1 (auto), 0 or 1");
+        p.cblock_user = (int)value;
+        p.cblock_on = 1;
+    } else if (!strcmp(key, "cblock_rpt")) {
+        if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "cblock_rpt (rows per thread; a row block holds 256 times as many) must be 0 (auto), 2, 4, 8 or 16");
+        p.cblock_rpt_user = (int)value;
+    } else if (!strcmp(key, "cblock_shift")) {
+        if (value != 0 && (value < 8 || value > 24))
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "cblock_shift (log2 of the columns of a column block) must be 0 (auto: 2 MB of x) or in [8, 24]");
+        p.cblock_shift_user = (int)value;
     } else if (!strcmp(key, "threads")) {
         if (value == 0) p.user_threads = false;
         else if (value != 512 && value != 1024)
@@ -1891,10 +1937,11 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "\"rows_per_block\": %d, \"rows_per_tile\": %d, \"blocks\": %u, \"threads_per_block\": %d, \"lds_x\": %d, "
              "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f, "
              "\"overflow_tiles\": %u, \"skew\": %d, \"persistent\": %d, \"nt_store\": %d, \"uniform_row_fraction\": %.4f, "
-             "\"prefetch\": %d, \"slide\": %d, \"ring_pages\": %d, \"tile_steps\": %d, \"split_tiles\": %u, \"panel_tiles\": %u, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f], \"placement_us\": [%.1f, %.1f], \"placement_tries\": %d, \"addr\": [\"%llx\", \"%llx\", \"%llx\"]}",
+             "\"prefetch\": %d, \"slide\": %d, \"ring_pages\": %d, \"tile_steps\": %d, \"split_tiles\": %u, \"panel_tiles\": %u, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f], \"placement_us\": [%.1f, %.1f], \"placement_tries\": %d, \"addr\": [\"%llx\", \"%llx\", \"%llx\"], "
+             "\"nonlocal_row_fraction\": %.4f, \"cblock\": %d, \"cblock_rows\": %d, \"cblock_cols\": %llu, \"cblock_col_blocks\": %d, \"cblock_row_blocks\": %u, \"cblock_us\": [%.1f, %.1f]}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, (p.kernel == 2 || p.vec_col16) ? 16 : 32,
-             p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
+             (p.cblock && p.cblock_on) ? "cblock" : p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
              p.rows_per_block, p.kernel == 2 ? p.rows_per_tile : 0, p.nblocks, p.threads, p.lds_x,
              (unsigned long long)p.lds_entries * (unsigned long long)a->elem_size, p.lds_row_fraction,
              p.stream_row_fraction,
@@ -1909,7 +1956,10 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              (double)a->tuned_us[0], (double)a->tuned_us[1],
              (double)a->tuned_us[2], (double)a->tuned_us[3], (double)a->place_us[0], (double)a->place_us[1],
              a->place_tried, (unsigned long long)(uintptr_t)a->d_values,
-             (unsigned long long)(uintptr_t)a->d_col16, (unsigned long long)(uintptr_t)a->d_rowptr);
+             (unsigned long long)(uintptr_t)a->d_col16, (unsigned long long)(uintptr_t)a->d_rowptr,
+             p.kernel == 2 ? p.nonlocal_row_fraction : 0.0, (p.cblock && p.cblock_on) ? 1 : 0, p.cblock ? 256 * p.cblock_rpt : 0,
+             p.cblock ? (1ull << p.cblock_shift) : 0ull, p.cblock ? p.cblock_nbc : 0, p.cblock ? p.cblock_nrb : 0u,
+             (double)a->cblock_us[0], (double)a->cblock_us[1]);
     return SPAL_OK;
 }
 

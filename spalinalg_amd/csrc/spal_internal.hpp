@@ -127,6 +127,16 @@ struct CsrPlan {
     int panel_window_pages = 0;  // pages of one panel (LDS)
     int panel_window_user = 0;   // option "panel_window" (0 = 80 KB)
     int slide_run = 0;       // steps per run (0 = one run per workgroup: fully persistent)
+    // the column-blocked kernel (csr_cblock.hpp): matrices whose columns are not local
+    int cblock_user = -1;    // option "cblock": -1 = when the plan finds most rows gathering x from beyond L2, 0 never, 1 always (tests)
+    int cblock = 0;          // the tiled copy is built
+    int cblock_on = 1;       // launch it (autotune: 0 when the stream kernels measured faster)
+    int cblock_rpt = 0;      // rows per thread: a row block holds 256 * cblock_rpt rows
+    int cblock_rpt_user = 0, cblock_shift_user = 0;   // options "cblock_rpt", "cblock_shift"
+    int cblock_shift = 0;    // a column block holds 2^shift columns
+    int cblock_nbc = 0;      // column blocks
+    uint32_t cblock_nrb = 0; // row blocks = workgroups
+    double nonlocal_row_fraction = 0.0;   // rows of super-tiles that gather x from global memory over a span no panel holds
     int slide_S = 0;         // 128-entry steps of the largest streamed tile: every tile issues that many loads
     int slide_uniform = 0;   // 1 + the length of every row when all streamed rows have one length (rowptr is not read), else 0
     int place_tries = 6;     // autotune: fresh allocations tried for the values array, at most (see csr_autotune)
@@ -177,6 +187,11 @@ struct spal_csr {
     uint4 *d_desc = nullptr;       // per row block: Stream {first page / offset into d_pages, pages, mode, contiguous};
                                    // VectorLds {window base column, window length, mode, 0}
     uint64_t cap_entries = 0;      // allocated entries of d_colind / d_values (>= nnz + pad)
+    // column-blocked copy (csr_cblock.hpp): entries ordered (row block, column block, row, column)
+    void *d_cb_val = nullptr;
+    uint32_t *d_cb_col = nullptr, *d_cb_tile = nullptr;   // columns; first entry of every tile (+ the end)
+    uint8_t *d_cb_cnt = nullptr;   // entries per (tile, row)
+    float cblock_us[2] = {0.f, 0.f};   // autotune: per launch {stream kernels, column-blocked kernel}
     // autotune: microseconds per launch of {plain, persistent} x {plain, non-temporal y stores}
     float tuned_us[4] = {0.f, 0.f, 0.f, 0.f};
     float place_us[2] = {0.f, 0.f};   // autotune: per launch before / after re-placing the values array
@@ -215,7 +230,13 @@ struct spal_csc {
     // STORED by the first super-tile that covers it and updated by the next one after a flag: no memset, no atomics
     int ordered = 0;
     uint32_t *d_prev_hi = nullptr; // per super-tile: end of the previous super-tile's window (where its own rows begin)
-    uint32_t *d_flags = nullptr;   // per super-tile: the launch number whose owned rows are in y; [nblocks] = spin bound hit
+    uint32_t *d_flags = nullptr;   // per super-tile: the launch number whose owned rows are in y; [nblocks + 1] = the ticket counter
+    uint32_t *h_gave_up = nullptr, *d_gave_up = nullptr;   // one word of mapped host memory: a super-tile hit its spin bound
+    uint32_t ticket_next = 0;      // value of the ticket counter when the next launch begins (guarded by mu_launch)
+    uint32_t spin_bound = 1u << 22;
+    int use_ticket = -1;           // option "ticket": -1 = ticket_auto
+    int ticket_auto = 0;           // plan: the launch has more workgroups than the device holds at once
+    int handoff_timeouts = 0;      // products of this handle that hit the spin bound (their y was invalid)
     uint32_t epoch = 0;            // launch number (guarded by mu, with ev_last)
     hipEvent_t ev_last = nullptr;  // launches of one handle run one after the other (they share d_flags)
     std::mutex mu_launch;          // ... chained under this lock
@@ -241,16 +262,15 @@ struct spal_coo {
     uint32_t *d_rows = nullptr, *d_cols = nullptr;
     void *d_vals = nullptr;
     void *d_work = nullptr;   // sort buffers + scratch of the assembly, allocated at upload
-    // scanned per-tile digit counts of the first radix pass over the uploaded triplets, by rows [0] / by columns [1]
-    uint32_t *d_first_offs[2] = {nullptr, nullptr};
-    int first_shift[2] = {-1, -1};
-    // ... and the offsets of the groups of rows (columns) the local sort takes, with the fullest group's entries:
-    // functions of the uploaded indices alone as well
-    uint32_t *d_gstart[2] = {nullptr, nullptr};
-    uint32_t fullest[2] = {0, 0};
+    // a HINT only: the fullest group of rows [0] / columns [1] the last assembly met (it picks the group kernel's LDS
+    // capacity without a host round trip; the kernel verifies it, see coo_assemble_t).  Nothing else about the triplets
+    // is kept between assemblies.
+    uint32_t cap_hint[2] = {0, 0};
     size_t work_bytes = 0;
     std::mutex mu;            // serialises assemblies on one handle (shared workspace)
     int last_group_rows = 0, last_group_cap = 0;  // geometry of the last assembly's local sort (0 = general route)
+    int last_relaunches = 0;        // group kernel launched again because the capacity hint was too small
+    int last_lookback_gave_up = 0;  // assemblies of this handle whose look-back hit its spin bound (backstop taken)
 };
 
 namespace spal {
@@ -261,6 +281,10 @@ int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream);
 hipError_t launch_slide(const spal_csr *a, const void *x, void *y, hipStream_t st);
 // ... and the column-panel kernel over a->d_ptiles
 hipError_t launch_panel(const spal_csr *a, const void *x, void *y, hipStream_t st);
+// implemented in spal_csr_cblock.hip: the column-blocked kernel (tiled copy of the matrix, x slices kept in L2)
+int cblock_plan(spal_csr *a, bool force);
+void cblock_free(spal_csr *a);
+hipError_t launch_cblock(const spal_csr *a, const void *x, void *y, hipStream_t st);
 // builds a handle around device arrays it takes ownership of (used by the COO
 // assembly, which produces CSR directly on the device)
 // (cap_entries = allocated entries of d_colind / d_values; re-allocated with

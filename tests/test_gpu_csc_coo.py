@@ -230,6 +230,83 @@ def test_csc_neighbour_handoff_flush(oracle, dtype):
     assert_spmv_close(yg.cpu().numpy(), y_ref, bound, tol)
 
 
+def _band_csc(oracle, n, dtype=np.float64, seed=41):
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, seed, dtype=dtype)
+    cp, ri, cv = oracle.transpose(n, n, rp, ci, va)
+    x = synth.vector(n, dtype=dtype)
+    return cp, ri, cv, x, oracle.csc_spmv(n, cp, ri, cv, x), oracle.csr_abs_bound(rp, ci, va, x)
+
+
+@pytest.mark.parametrize("ticket", [1, 0])
+def test_csc_handoff_tile_ids_by_ticket_or_block_index(oracle, ticket):
+    """Neighbour hand-off with the super-tile taken from the start-order ticket or from blockIdx: 600 products
+    back to back on one handle (the ticket counter and the flags run on from launch to launch), more super-tiles than
+    the device holds at once (two rounds of workgroups), y pre-filled with NaN each time."""
+    import torch
+    n = 2_200_000                                   # 538 super-tiles of 4096 columns: more than 256 CUs x 1
+    cp, ri, cv, x, y_ref, bound = _band_csc(oracle, n)
+    dev = sp.CscMatrix(n, n, cp, ri, cv).device()
+    dev.set_option("kernel", 1)
+    dev.set_option("ticket", ticket)
+    d = dev.describe()
+    assert d["flush"] == "neighbour_handoff" and d["ticket"] == ticket and d["blocks"] > 512, d
+    xt = torch.from_numpy(x).cuda()
+    yt = torch.empty(n, dtype=torch.float64, device="cuda")
+    ref_t, bound_t = torch.from_numpy(y_ref).cuda(), torch.from_numpy(bound).cuda()
+    bad = torch.zeros((), dtype=torch.int64, device="cuda")
+    for it in range(600):                            # every product is checked (on the device: no host round trip)
+        yt.fill_(float("nan"))
+        dev.spmv_torch(xt, yt)
+        bad += (~((yt - ref_t).abs() <= 1e-10 * bound_t + 1e-300)).sum()      # (NaN counts as bad)
+        if it in (0, 1, 599):
+            assert_spmv_close(yt.cpu().numpy(), y_ref, bound, 1e-10)
+    assert int(bad.item()) == 0
+    assert dev.describe()["handoff_timeouts"] == 0
+
+
+def test_csc_handoff_backstop_is_reported(oracle, monkeypatch):
+    """The hand-off's spin bound forced to 0 (SPAL_CSC_HANDOFF_SPINS, read when the plan is built): a super-tile that finds
+    its predecessor's flag missing gives up at once.  Host-vector path: the library sees the report after its own
+    synchronisation and repeats the product with atomics -- the caller gets the right y.  Device path: the NEXT call on
+    the handle fails loudly (that earlier y was invalid), the handle then flushes with atomics and is right again."""
+    import torch
+    n = 1_200_000
+    cp, ri, cv, x, y_ref, bound = _band_csc(oracle, n, seed=43)
+    monkeypatch.setenv("SPAL_CSC_HANDOFF_SPINS", "0")
+    # host-vector path
+    dev = sp.CscMatrix(n, n, cp, ri, cv).device()
+    dev.set_option("kernel", 1)
+    assert dev.describe()["flush"] == "neighbour_handoff"
+    for _ in range(30):                              # (all super-tiles finish together: some find a flag missing soon)
+        assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10)
+        if dev.describe()["handoff_timeouts"]:
+            break
+    d = dev.describe()
+    assert d["handoff_timeouts"] == 1 and d["flush"] == "global_atomics", d
+    assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10)
+    # device path
+    dev = sp.CscMatrix(n, n, cp, ri, cv).device()
+    dev.set_option("kernel", 1)
+    xt = torch.from_numpy(x).cuda()
+    yt = torch.empty(n, dtype=torch.float64, device="cuda")
+    raised = False
+    for _ in range(60):
+        try:
+            dev.spmv_torch(xt, yt)
+        except sp.SpalError as e:
+            raised = True
+            assert "hand-off" in str(e), e
+            break
+        torch.cuda.synchronize()
+    assert raised, "no super-tile ever took the backstop"
+    d = dev.describe()
+    assert d["handoff_timeouts"] == 1 and d["flush"] == "global_atomics", d
+    yt.fill_(float("nan"))
+    dev.spmv_torch(xt, yt)
+    torch.cuda.synchronize()
+    assert_spmv_close(yt.cpu().numpy(), y_ref, bound, 1e-10)
+
+
 def test_csc_handoff_not_taken_when_windows_interleave(oracle):
     """rows anywhere: every super-tile's window covers most rows -- atomics (or the transposed route), as before"""
     rng = np.random.default_rng(5)
@@ -488,6 +565,7 @@ def test_coo_local_sort_geometries(oracle, dtype):
     zeros in every case."""
     rng = np.random.default_rng(77)
     seen = set()
+    relaunched = 0
     for nr, per_row in [(20_000, 1), (20_000, 3), (20_000, 6), (20_000, 12), (12_000, 24),
                         (8_000, 45), (4_000, 100), (300_000, 0.01), (20_001, 7), (20_000, 10),
                         (200, 600), (64, 1500), (300, 850)]:   # the last three: groups of 2 rows / 1 row, long rows
@@ -501,19 +579,77 @@ def test_coo_local_sort_geometries(oracle, dtype):
         v = rng.integers(-3, 4, n).astype(dtype) * dtype(0.37)    # sums that cancel exactly do occur
         coo = sp.CooMatrix.with_triplets(nr, nc, r, c, v)
         dev = coo.upload()
-        got = dev.assemble_csr()
-        d = dev.describe()
-        seen.add((d["last_route"], d["group_rows"], d["group_cap"]))
         p, i, w = oracle.coo_to_csr(nr, nc, r, c, v)
-        gp, gi, gw = got.download()
         bits = np.uint64 if dtype == np.float64 else np.uint32
-        assert np.array_equal(gp, p) and np.array_equal(gi, i), d
-        assert np.array_equal(gw.view(bits), w.view(bits)), d
-        got.close()
+        # twice: the first assembly GUESSES the group kernel's capacity (mean + 6 sigma; too small a guess is caught
+        # on the device and the kernel launched again), the second one knows the fullest group of the first
+        for attempt in range(2):
+            got = dev.assemble_csr()
+            d = dev.describe()
+            seen.add((d["last_route"], d["group_rows"], d["group_cap"]))
+            relaunched += d["group_relaunches"]
+            assert attempt == 0 or d["group_relaunches"] == 0, d
+            gp, gi, gw = got.download()
+            assert np.array_equal(gp, p) and np.array_equal(gi, i), d
+            assert np.array_equal(gw.view(bits), w.view(bits)), d
+            got.close()
         dev.close()
+    assert relaunched >= 1, "no case took the too-small-guess path"
     assert ("general", 0, 0) in seen
     assert len({g[1] for g in seen}) >= 5, seen                  # 256, 128, 64, 32, ... rows per group
     assert {g[2] for g in seen} >= {512, 1024, 1536, 2048}, seen
+
+
+
+def _coo_case(seed, n=1_500_000, nr=150_000, nc=90_000):
+    rng = np.random.default_rng(seed)
+    r = rng.integers(0, nr, n).astype(np.uint64)
+    c = rng.integers(0, nc, n).astype(np.uint64)
+    v = rng.integers(-3, 4, n).astype(np.float64) * 0.37
+    src = rng.integers(0, n, n)
+    dup = rng.random(n) < 0.05
+    return nr, nc, np.where(dup, r[src], r), np.where(dup, c[src], c), v
+
+
+def test_coo_lookback_backstop_takes_the_general_route(oracle, monkeypatch):
+    """The look-back's spin bound forced to 0 (SPAL_COO_LOOKBACK_SPINS): the first group that has to wait gives up, the
+    error flag comes back and the host repeats the assembly on the general route -- the result must still equal the
+    oracle's bit for bit, and describe() must say which route produced it."""
+    nr, nc, r, c, v = _coo_case(123)
+    p, i, w = oracle.coo_to_csr(nr, nc, r, c, v)
+    dev = sp.CooMatrix.with_triplets(nr, nc, r, c, v).upload()
+    monkeypatch.setenv("SPAL_COO_LOOKBACK_SPINS", "0")
+    got = dev.assemble_csr()
+    d = dev.describe()
+    assert d["last_route"] == "general" and d["lookback_gave_up"] == 1, d
+    gp, gi, gw = got.download()
+    assert np.array_equal(gp, p) and np.array_equal(gi, i) and np.array_equal(gw.view(np.uint64), w.view(np.uint64))
+    got.close()
+    monkeypatch.delenv("SPAL_COO_LOOKBACK_SPINS")
+    got = dev.assemble_csr()                                   # the same handle, bound restored: the local sort again
+    d = dev.describe()
+    assert d["last_route"] == "local_sort" and d["lookback_gave_up"] == 1, d
+    gp, gi, gw = got.download()
+    assert np.array_equal(gp, p) and np.array_equal(gi, i) and np.array_equal(gw.view(np.uint64), w.view(np.uint64))
+    got.close()
+    dev.close()
+
+
+@pytest.mark.parametrize("ticket", ["1", "0"])
+def test_coo_group_ids_by_ticket_or_by_block_index(oracle, monkeypatch, ticket):
+    """Groups are handed out by a device ticket (start order) by default; SPAL_COO_TICKET=0 takes blockIdx (the
+    dispatch-order assumption of round 2).  Both must give the oracle's arrays; 20 assemblies of one handle agree."""
+    monkeypatch.setenv("SPAL_COO_TICKET", ticket)
+    nr, nc, r, c, v = _coo_case(321, n=3_000_000, nr=400_000)
+    p, i, w = oracle.coo_to_csr(nr, nc, r, c, v)
+    dev = sp.CooMatrix.with_triplets(nr, nc, r, c, v).upload()
+    for _ in range(20):
+        got = dev.assemble_csr()
+        assert dev.describe()["last_route"] == "local_sort"
+        gp, gi, gw = got.download()
+        assert np.array_equal(gp, p) and np.array_equal(gi, i) and np.array_equal(gw.view(np.uint64), w.view(np.uint64))
+        got.close()
+    dev.close()
 
 
 def test_assembled_handle_plans_like_an_uploaded_one(oracle):

@@ -945,7 +945,7 @@ def test_row_blocks_beyond_32_bit_entry_offsets(oracle, monkeypatch):
     """More stored entries than one set of 32-bit device offsets addresses (the reference's offsets are usize,
     src/csr.rs:66-72): the handle keeps the matrix as row blocks.  SPAL_CSR_PART_ENTRIES lowers the limit so the path
     runs on a small matrix: products (host and device entry points), download, options, autotune and the refusal of
-    the one conversion that cannot be split.  (The real limit: tools/lab_huge.py, 4.5e9 entries.)"""
+    the one conversion that cannot be split.  (The real limit: tools/lab.py huge, 4.5e9 entries.)"""
     import torch
     monkeypatch.setenv("SPAL_CSR_PART_ENTRIES", "300000")
     for dtype, gen in ((np.float64, "banded"), (np.float32, "ragged")):

@@ -8,6 +8,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <algorithm>
 #include <cstdlib>
 #include <string>
@@ -104,6 +105,100 @@ __global__ __launch_bounds__(256, 2) void footprint(const double *__restrict__ v
         if (XWIN) s += reinterpret_cast<const double *>(smem)[(lane * 37 + k) & 4095];
         if (r0 + lane < nrows) y[r0 + lane] = s;
     }
+}
+
+
+// footprint with the 8 XCDs interleaved in chunks of C consecutive super-tiles (XCD x takes chunks x, x + 8, ...): all
+// XCDs stay inside one moving window of 8 * C super-tiles instead of walking 8 runs an eighth of the arrays apart.
+template <int PF, bool XWIN>
+__global__ __launch_bounds__(256, 2) void footprint_chunk(const double *__restrict__ vals, const uint16_t *__restrict__ col16,
+                                                          const uint32_t *__restrict__ rowptr, const double *__restrict__ x,
+                                                          double *__restrict__ y, uint32_t nrows, uint32_t nblocks, uint32_t C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t b = ((slot / C) * 8u + xcd) * C + slot % C;
+    if (b >= nblocks) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t wrow = b * 1024 + wave * 256;
+    Tile t[4];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+        if (wrow + p * 64 < nrows) tile_load(t[p], vals, col16, rowptr, wrow + p * 64, lane);
+    if (XWIN) {
+        u32x4 *d4 = reinterpret_cast<u32x4 *>(smem);
+        const uint32_t c0 = b * 1024 > 2048 ? b * 1024 - 2048 : 0;
+        const u32x4 *s4 = reinterpret_cast<const u32x4 *>(x + min(c0, nrows - 5120));
+        u32x4 r[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) r[k] = s4[threadIdx.x + k * 256];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) d4[threadIdx.x + k * 256] = r[k];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t r0 = wrow + k * 64;
+        if (r0 >= nrows) break;
+        if (k + PF < 4 && r0 + PF * 64 < nrows) tile_load(t[(k + PF) & 3], vals, col16, rowptr, r0 + PF * 64, lane);
+        double s = tile_use(t[k & 3]);
+        if (XWIN) s += reinterpret_cast<const double *>(smem)[(lane * 37 + k) & 4095];
+        if (r0 + lane < nrows) y[r0 + lane] = s;
+    }
+}
+
+
+// Which second stream does the values array's "class" need?  The chunk-interleaved footprint (C = 64) with parts
+// switched off: MASK bit 0 = the 16-bit columns are read, bit 1 = the row pointers, bit 2 = y is written, bit 3 = the
+// x window is staged.
+template <int MASK>
+__global__ __launch_bounds__(256, 2) void footprint_parts(const double *__restrict__ vals, const uint16_t *__restrict__ col16,
+                                                          const uint32_t *__restrict__ rowptr, const double *__restrict__ x,
+                                                          double *__restrict__ y, uint32_t nrows, uint32_t nblocks, uint32_t C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t b = ((slot / C) * 8u + xcd) * C + slot % C;
+    if (b >= nblocks) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t wrow = b * 1024 + wave * 256;
+    f64x2 v[2][7];
+    uint32_t c[2][7], r0v[2], r1v[2];
+    auto load = [&](int s, uint32_t row) {
+        const size_t e0 = (size_t)row * 14 + lane * 2;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            v[s][j] = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(vals + e0 + j * 128));
+            c[s][j] = (MASK & 1) ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(col16 + e0 + j * 128)) : 0u;
+        }
+        r0v[s] = (MASK & 2) ? rowptr[row + lane] : 0u;
+        r1v[s] = (MASK & 2) ? rowptr[row + lane + 1] : 1u;
+    };
+    load(0, wrow);
+    if (MASK & 8) {
+        u32x4 *d4 = reinterpret_cast<u32x4 *>(smem);
+        const uint32_t c0 = b * 1024 > 2048 ? b * 1024 - 2048 : 0;
+        const u32x4 *s4 = reinterpret_cast<const u32x4 *>(x + min(c0, nrows - 5120));
+        u32x4 r[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) r[k] = s4[threadIdx.x + k * 256];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) d4[threadIdx.x + k * 256] = r[k];
+        __syncthreads();
+    }
+    double keep = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t r0 = wrow + k * 64;
+        if (r0 >= nrows) break;
+        if (k + 1 < 4 && r0 + 64 < nrows) load((k + 1) & 1, r0 + 64);
+        double s = 0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) s += v[k & 1][j].x + v[k & 1][j].y + (double)c[k & 1][j];
+        s += (double)(r1v[k & 1] - r0v[k & 1]);
+        if (MASK & 8) s += reinterpret_cast<const double *>(smem)[(lane * 37 + k) & 4095];
+        if (MASK & 4) { if (r0 + lane < nrows) y[r0 + lane] = s; }
+        else keep += s;
+    }
+    if (!(MASK & 4) && keep == 1.2345e300) y[0] = keep;
 }
 
 // The same loads, but a fixed grid of workgroups each walking a contiguous run of super-tiles (what the sliding
@@ -330,7 +425,265 @@ static int walk_main() {
     return 0;
 }
 
+
+// --map [gb]: a speed map of the device's memory.  Value arrays of 1.12 GB are allocated one after the other until
+// `gb` GB are held (default: 85 % of the free memory), each is timed as the VALUES stream of the config-3 footprint
+// (columns, row pointers, x, y fixed) and with a plain read; then everything is freed, allocated again in the same
+// order and timed again (does the pattern belong to the position in the allocation order, i.e. to the physical place?).
+// For the slowest and the fastest array: the footprint over each eighth of the rows alone (512 MB flushed through the
+// caches in between), i.e. whether a slow array is slow everywhere.
+static int map_main(double gb) {
+    const uint32_t nrows = 10'000'000;
+    const size_t nnz = (size_t)nrows * 14 + 4096;
+    size_t fre = 0, tot = 0;
+    CK(hipMemGetInfo(&fre, &tot));
+    double *x, *y;
+    uint16_t *col16;
+    uint32_t *rowptr, *flag;
+    u32x4 *flush;
+    const size_t flush_n16 = (size_t)(512u << 20) / 16;
+    CK(hipMalloc(&col16, nnz * 2)); CK(hipMemset(col16, 1, nnz * 2));
+    CK(hipMalloc(&rowptr, ((size_t)nrows + 65) * 4)); CK(hipMemset(rowptr, 0, ((size_t)nrows + 65) * 4));
+    CK(hipMalloc(&x, (size_t)nrows * 8)); CK(hipMalloc(&y, (size_t)nrows * 8)); CK(hipMalloc(&flag, 64));
+    CK(hipMalloc(&flush, flush_n16 * 16)); CK(hipMemset(flush, 0, flush_n16 * 16));
+    CK(hipMemset(x, 0, (size_t)nrows * 8));
+    if (gb <= 0) gb = fre * 0.85 / 1e9;
+    const int K = (int)std::min<double>(gb * 1e9 / (nnz * 8.0), 260.0);
+    printf("free %.1f GB of %.1f GB; %d value arrays of %.2f GB\n", fre / 1e9, tot / 1e9, K, nnz * 8 / 1e9);
+    const uint32_t nblocks = (nrows + 1023) / 1024, per_xcd = (nblocks + 7) / 8;
+    auto kern = footprint<2, true>;
+    CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    std::vector<double *> vals(K, nullptr);
+    std::vector<double> us_fp(K), us_rd(K);
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = 0; i < K; ++i) { CK(hipMalloc(&vals[i], nnz * 8)); }
+        for (int i = 0; i < K; ++i) CK(hipMemsetAsync(vals[i], 1, nnz * 8, 0));
+        CK(hipDeviceSynchronize());
+        printf("pass %d: index  address         footprint us   read16 us\n", pass);
+        for (int i = 0; i < K; ++i) {
+            us_fp[i] = time_us([&] {
+                hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(256), 72 * 1024, 0, vals[i], col16, rowptr, x, y, nrows, nblocks, per_xcd);
+            }, 12);
+            us_rd[i] = time_us([&] { hipLaunchKernelGGL(read16, dim3(8192), dim3(256), 0, 0, (const u32x4 *)vals[i], flag, nnz * 8 / 16); }, 8);
+            printf("  %3d  %p  %7.1f  %7.1f\n", i, (void *)vals[i], us_fp[i], us_rd[i]);
+            fflush(stdout);
+        }
+        int lo = 0, hi = 0;
+        for (int i = 0; i < K; ++i) { if (us_fp[i] < us_fp[lo]) lo = i; if (us_fp[i] > us_fp[hi]) hi = i; }
+        printf("pass %d: fastest %d (%.1f us), slowest %d (%.1f us)\n", pass, lo, us_fp[lo], hi, us_fp[hi]);
+        for (int which : {lo, hi}) {
+            printf("  array %d by eighths of the rows (us):", which);
+            hipEvent_t e0, e1;
+            CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            for (int s8 = 0; s8 < 8; ++s8) {
+                const uint32_t r0 = (nrows / 8 / 1024) * 1024 * s8, nr = (nrows / 8 / 1024) * 1024;
+                const uint32_t nb = nr / 1024, px = (nb + 7) / 8;
+                double sum = 0;
+                for (int it = 0; it < 6; ++it) {
+                    hipLaunchKernelGGL(read16, dim3(8192), dim3(256), 0, 0, (const u32x4 *)flush, flag, flush_n16);
+                    CK(hipEventRecord(e0));
+                    hipLaunchKernelGGL(kern, dim3(px * 8), dim3(256), 72 * 1024, 0, vals[which] + (size_t)r0 * 14, col16 + (size_t)r0 * 14,
+                                       rowptr + r0, x + r0, y + r0, nr, nb, px);
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (it) sum += ms * 1e3;
+                }
+                printf(" %6.1f", sum / 5);
+            }
+            printf("\n");
+            CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+        }
+        for (int i = 0; i < K; ++i) CK(hipFree(vals[i]));
+        fflush(stdout);
+    }
+    return 0;
+}
+
+// --map-vmm <align_mb> <offset_mb> <piece_mb> [gb]: the same map with the value arrays built through the virtual-memory
+// API: virtual range reserved at `align_mb` alignment, the array mapped at + offset_mb, physical memory created in
+// pieces of piece_mb (0 = one handle for the whole array; pieces are power-of-two sized, so the buddy allocator hands
+// out naturally aligned blocks).  Theory under test: the class of an array is the alignment of (virtual - physical)
+// address, i.e. the largest page-table fragment the driver can use for it.
+static int map_vmm_main(size_t align_mb, size_t offset_mb, size_t piece_mb, double gb) {
+    const uint32_t nrows = 10'000'000;
+    const size_t nnz = (size_t)nrows * 14 + 4096;
+    size_t fre = 0, tot = 0;
+    CK(hipMemGetInfo(&fre, &tot));
+    double *x, *y;
+    uint16_t *col16;
+    uint32_t *rowptr, *flag;
+    CK(hipMalloc(&col16, nnz * 2)); CK(hipMemset(col16, 1, nnz * 2));
+    CK(hipMalloc(&rowptr, ((size_t)nrows + 65) * 4)); CK(hipMemset(rowptr, 0, ((size_t)nrows + 65) * 4));
+    CK(hipMalloc(&x, (size_t)nrows * 8)); CK(hipMalloc(&y, (size_t)nrows * 8)); CK(hipMalloc(&flag, 64));
+    CK(hipMemset(x, 0, (size_t)nrows * 8));
+    if (gb <= 0) gb = 100;
+    const size_t MB = (size_t)1 << 20;
+    const size_t piece = piece_mb ? piece_mb * MB : ((nnz * 8 + 2 * MB - 1) / (2 * MB)) * (2 * MB);
+    const size_t mapped = ((nnz * 8 + piece - 1) / piece) * piece;
+    const int K = (int)std::min<double>(gb * 1e9 / (double)mapped, 260.0);
+    printf("vmm: alignment %zu MB, offset %zu MB, pieces of %zu MB (%zu per array), %d arrays\n", align_mb, offset_mb, piece / MB,
+           mapped / piece, K);
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof prop);
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    hipMemAccessDesc acc;
+    memset(&acc, 0, sizeof acc);
+    acc.location.type = hipMemLocationTypeDevice;
+    acc.location.id = 0;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    const uint32_t nblocks = (nrows + 1023) / 1024, per_xcd = (nblocks + 7) / 8;
+    auto kern = footprint<2, true>;
+    CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    std::vector<void *> bases(K, nullptr);
+    std::vector<std::vector<hipMemGenericAllocationHandle_t>> handles(K);
+    const size_t reserve = mapped + offset_mb * MB;
+    for (int i = 0; i < K; ++i) {
+        CK(hipMemAddressReserve(&bases[i], reserve, align_mb * MB, nullptr, 0));
+        char *at = (char *)bases[i] + offset_mb * MB;
+        for (size_t off = 0; off < mapped; off += piece) {
+            hipMemGenericAllocationHandle_t h;
+            CK(hipMemCreate(&h, piece, &prop, 0));
+            handles[i].push_back(h);
+            CK(hipMemMap(at + off, piece, 0, h, 0));
+        }
+        CK(hipMemSetAccess(at, mapped, &acc, 1));
+        CK(hipMemsetAsync(at, 1, nnz * 8, 0));
+    }
+    CK(hipDeviceSynchronize());
+    double lo = 1e9, hi = 0;
+    for (int i = 0; i < K; ++i) {
+        double *v = (double *)((char *)bases[i] + offset_mb * MB);
+        const double us = time_us([&] {
+            hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(256), 72 * 1024, 0, v, col16, rowptr, x, y, nrows, nblocks, per_xcd);
+        }, 12);
+        const double rd = time_us([&] { hipLaunchKernelGGL(read16, dim3(8192), dim3(256), 0, 0, (const u32x4 *)v, flag, nnz * 8 / 16); }, 8);
+        printf("  %3d  %p  %7.1f  %7.1f\n", i, (void *)v, us, rd);
+        lo = std::min(lo, us); hi = std::max(hi, us);
+        fflush(stdout);
+    }
+    printf("vmm: alignment %zu MB, offset %zu MB, pieces %zu MB: footprint %.1f ... %.1f us over %d arrays\n", align_mb, offset_mb,
+           piece / MB, lo, hi, K);
+    for (int i = 0; i < K; ++i) {
+        CK(hipMemUnmap((char *)bases[i] + offset_mb * MB, mapped));
+        for (auto h : handles[i]) CK(hipMemRelease(h));
+        CK(hipMemAddressFree(bases[i], reserve));
+    }
+    return 0;
+}
+
+// --map-chunk [gb]: per value array (hipMalloc, as --map): the footprint with 8 XCD runs (the library's order), with the
+// XCDs interleaved in chunks of C = 1, 4, 16, 64, 256 super-tiles, and the sliding kernel's walk (512 workgroups, a run each).
+static int map_chunk_main(double gb) {
+    const uint32_t nrows = 10'000'000;
+    const size_t nnz = (size_t)nrows * 14 + 4096;
+    double *x, *y;
+    uint16_t *col16;
+    uint32_t *rowptr;
+    CK(hipMalloc(&col16, nnz * 2)); CK(hipMemset(col16, 1, nnz * 2));
+    CK(hipMalloc(&rowptr, ((size_t)nrows + 65) * 4)); CK(hipMemset(rowptr, 0, ((size_t)nrows + 65) * 4));
+    CK(hipMalloc(&x, (size_t)nrows * 8)); CK(hipMalloc(&y, (size_t)nrows * 8));
+    CK(hipMemset(x, 0, (size_t)nrows * 8));
+    if (gb <= 0) gb = 60;
+    const int K = (int)std::min<double>(gb * 1e9 / (nnz * 8.0), 260.0);
+    const uint32_t nblocks = (nrows + 1023) / 1024, per_xcd = (nblocks + 7) / 8;
+    const uint32_t nsteps = (nrows + 255) / 256, per_xcd_s = (nsteps + 7) / 8;
+    auto k0 = footprint<2, true>;
+    auto kc = footprint_chunk<2, true>;
+    auto kw = footprint_walk<2>;
+    CK(hipFuncSetAttribute((const void *)k0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void *)kc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void *)kw, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    std::vector<double *> vals(K, nullptr);
+    for (int i = 0; i < K; ++i) { CK(hipMalloc(&vals[i], nnz * 8)); CK(hipMemsetAsync(vals[i], 1, nnz * 8, 0)); }
+    CK(hipDeviceSynchronize());
+    printf("index  8 runs | chunks of 1, 4, 16, 64, 256 | walk 512 x run, 512 x (8 interleaved), 512 x (64 interleaved)   (us)\n");
+    for (int i = 0; i < K; ++i) {
+        printf("  %3d  %6.1f |", i, time_us([&] {
+            hipLaunchKernelGGL(k0, dim3(per_xcd * 8), dim3(256), 72 * 1024, 0, vals[i], col16, rowptr, x, y, nrows, nblocks, per_xcd); }, 12));
+        for (uint32_t C : {1u, 4u, 16u, 64u, 256u})
+            printf(" %6.1f", time_us([&] {
+                hipLaunchKernelGGL(kc, dim3(per_xcd * 8 + 8 * C), dim3(256), 72 * 1024, 0, vals[i], col16, rowptr, x, y, nrows, nblocks, C); }, 12));
+        printf(" |");
+        for (uint32_t G : {1u, 8u, 64u}) {
+            const uint32_t slots = 64, chunk = (per_xcd_s + slots - 1) / slots;
+            printf(" %6.1f", time_us([&] {
+                hipLaunchKernelGGL(kw, dim3(slots * 8), dim3(256), 72 * 1024, 0, vals[i], col16, rowptr, y, nrows, nsteps, per_xcd_s, chunk, G); }, 12));
+        }
+        printf("\n");
+        fflush(stdout);
+    }
+    return 0;
+}
+
+template <int MASK>
+static double parts_us(const double *vals, const uint16_t *col16, const uint32_t *rowptr, const double *x, double *y, uint32_t nrows) {
+    const uint32_t nblocks = (nrows + 1023) / 1024, per_xcd = (nblocks + 7) / 8, C = 64;
+    auto k = footprint_parts<MASK>;
+    CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return time_us([&] { hipLaunchKernelGGL(k, dim3(per_xcd * 8 + 8 * C), dim3(256), 72 * 1024, 0, vals, col16, rowptr, x, y, nrows, nblocks, C); }, 12);
+}
+// --map-parts [gb]: per value array, the chunk-interleaved footprint with its parts switched on one by one; then, for
+// the first slow and the first fast array, the full footprint against 6 different allocations of y / of the columns.
+static int map_parts_main(double gb, int method) {   // method 0 hipMalloc, 1 hipExtMallocWithFlags(Uncached), 2 (Finegrained), 3 (Contiguous)
+    const uint32_t nrows = 10'000'000;
+    const size_t nnz = (size_t)nrows * 14 + 4096;
+    double *x, *y;
+    uint16_t *col16;
+    uint32_t *rowptr;
+    CK(hipMalloc(&col16, nnz * 2)); CK(hipMemset(col16, 1, nnz * 2));
+    CK(hipMalloc(&rowptr, ((size_t)nrows + 65) * 4)); CK(hipMemset(rowptr, 0, ((size_t)nrows + 65) * 4));
+    CK(hipMalloc(&x, (size_t)nrows * 8)); CK(hipMalloc(&y, (size_t)nrows * 8));
+    CK(hipMemset(x, 0, (size_t)nrows * 8));
+    if (gb <= 0) gb = 60;
+    const int K = (int)std::min<double>(gb * 1e9 / (nnz * 8.0), 260.0);
+    std::vector<double *> vals(K, nullptr);
+    for (int i = 0; i < K; ++i) {
+        if (method == 0) CK(hipMalloc(&vals[i], nnz * 8));
+        else CK(hipExtMallocWithFlags((void **)&vals[i], nnz * 8, method == 1 ? hipDeviceMallocUncached : method == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocContiguous));
+        CK(hipMemsetAsync(vals[i], 1, nnz * 8, 0));
+    }
+    CK(hipDeviceSynchronize());
+    printf("values arrays: %s\n", method == 0 ? "hipMalloc" : method == 1 ? "hipExtMallocWithFlags(Uncached)" : method == 2 ? "hipExtMallocWithFlags(Finegrained)" : "hipExtMallocWithFlags(Contiguous)");
+    printf("index  values only | + columns | + row pointers | + y written | + x window (all) | values + y | values + x window  (us)\n");
+    std::vector<double> full(K);
+    for (int i = 0; i < K; ++i) {
+        const double a = parts_us<0>(vals[i], col16, rowptr, x, y, nrows), b = parts_us<1>(vals[i], col16, rowptr, x, y, nrows),
+                     c = parts_us<3>(vals[i], col16, rowptr, x, y, nrows), d = parts_us<7>(vals[i], col16, rowptr, x, y, nrows),
+                     e = parts_us<15>(vals[i], col16, rowptr, x, y, nrows), f = parts_us<4>(vals[i], col16, rowptr, x, y, nrows),
+                     g = parts_us<8>(vals[i], col16, rowptr, x, y, nrows);
+        full[i] = e;
+        printf("  %3d  %6.1f  %6.1f  %6.1f  %6.1f  %6.1f  |  %6.1f  %6.1f\n", i, a, b, c, d, e, f, g);
+        fflush(stdout);
+    }
+    int lo = 0, hi = 0;
+    for (int i = 0; i < K; ++i) { if (full[i] < full[lo]) lo = i; if (full[i] > full[hi]) hi = i; }
+    // other allocations of y and of the columns against the slowest and the fastest values array
+    double *ys[6];
+    uint16_t *cs[6];
+    for (int j = 0; j < 6; ++j) {
+        void *pad;
+        CK(hipMalloc(&pad, (size_t)(j + 1) * 12'345'678));
+        CK(hipMalloc(&ys[j], (size_t)nrows * 8));
+        CK(hipMalloc(&cs[j], nnz * 2)); CK(hipMemset(cs[j], 1, nnz * 2));
+    }
+    for (int which : {lo, hi}) {
+        printf("values array %d (%.1f us): y in 6 other allocations:", which, full[which]);
+        for (int j = 0; j < 6; ++j) printf(" %6.1f", parts_us<15>(vals[which], col16, rowptr, x, ys[j], nrows));
+        printf("   columns in 6 other allocations:");
+        for (int j = 0; j < 6; ++j) printf(" %6.1f", parts_us<15>(vals[which], cs[j], rowptr, x, y, nrows));
+        printf("\n");
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && std::string(argv[1]) == "--map-parts") return map_parts_main(argc > 2 ? atof(argv[2]) : 0.0, argc > 3 ? atoi(argv[3]) : 0);
+    if (argc > 1 && std::string(argv[1]) == "--map-chunk") return map_chunk_main(argc > 2 ? atof(argv[2]) : 0.0);
+    if (argc > 4 && std::string(argv[1]) == "--map-vmm") return map_vmm_main(atoll(argv[2]), atoll(argv[3]), atoll(argv[4]), argc > 5 ? atof(argv[5]) : 0.0);
+    if (argc > 1 && std::string(argv[1]) == "--map") return map_main(argc > 2 ? atof(argv[2]) : 0.0);
     if (argc > 1 && std::string(argv[1]) == "--walk") return walk_main();
     if (argc > 3 && std::string(argv[1]) == "--quick") return quick_main((uint32_t)atoll(argv[2]), (uint32_t)atoll(argv[3]));
     if (argc > 1 && std::string(argv[1]) == "--place") return place_main();

@@ -21,7 +21,7 @@ run fetch5 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/fetch5 -o b -- p
 run write5 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/write5 -o b -- python3 bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline
 # LDS bank conflicts: the one-super-tile kernel as shipped vs the conflict-free (wrong-result) ablation build
 export SPAL_HIP_LIB=$PWD/spalinalg_amd/lib_var/diag/libspal_hip.so
-run sq3_plain rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $P/sq3_plain -o b -- python3 tools/lab_ab1.py "diag=0,slide_on=0" @rounds=1
-run sq3_noconf rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $P/sq3_noconf -o b -- python3 tools/lab_ab1.py "diag=256,slide_on=0" @rounds=1
+run sq3_plain rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $P/sq3_plain -o b -- python3 tools/lab.py ab1 "diag=0,slide_on=0" @rounds=1
+run sq3_noconf rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $P/sq3_noconf -o b -- python3 tools/lab.py ab1 "diag=256,slide_on=0" @rounds=1
 unset SPAL_HIP_LIB
 find $P -name "*.csv" | head -40
