@@ -6,12 +6,11 @@
 // second time in TILES: rows in blocks of RB = 256 * RPT, columns in blocks of CB (x slice of CB columns = 2 MB: it
 // stays in every XCD's 4 MB L2 while the workgroups of that XCD work on it), entries ordered (row block, column
 // block, row, column).  One workgroup per row block walks its column blocks in ascending order; per tile
-//   * the tile's entries are read entry-parallel (coalesced 8 + 4 bytes per lane), x gathered (L2 hits), the
-//     PRODUCT, rounded, goes to an LDS strip in entry order;
-//   * thread t owns the RPT consecutive rows t * RPT ... of the row block; the rows' entry counts in this tile
-//     (one byte per row and column block, one vector load per thread) give, by a block scan, where the thread's
-//     products start in the strip; it adds them to its rows' running sums ONE AFTER THE OTHER.
-// The running sum of a row lives in a register from the first column block to the last, so a row's products are
+//   * the tile's entries are read entry-parallel (coalesced 8 + 4 + 2 bytes per lane: value, column, row inside the
+//     row block), x gathered (L2 hits), the PRODUCT, rounded, goes to an LDS strip in entry order;
+//   * the entry that heads its row's run in the tile adds the run's products to the row's running sum ONE AFTER THE
+//     OTHER.
+// The running sum of a row lives in LDS from the first column block to the last, so a row's products are
 // added in ascending column order, the product rounded before the add, the first product taken as it is: exactly
 // the reference's order (src/csr/ops/mul.rs:31-38) -- rows are bit-identical to the sequential CPU result.
 // (The running sums start at -0.0: -0.0 + p == p bit for bit for every p, which makes "add" the reference's
@@ -22,28 +21,9 @@
 namespace spal {
 
 constexpr int kCbThreads = 256;
-constexpr uint32_t kCbStrip = 4096;      // products of one tile (entries): 32 KiB of f64
+constexpr uint32_t kCbStrip = 4096;      // most products of one tile (entries): 32 KiB of f64
+constexpr uint32_t kCbMaxRows = 4096;    // most rows of a row block (their running sums: 32 KiB of f64)
 constexpr uint32_t kCbMaxBlocks = 64;    // column blocks per matrix
-
-template <int RPT> struct CbCounts;      // RPT bytes as one vector
-template <> struct CbCounts<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
-template <> struct CbCounts<8> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
-template <> struct CbCounts<4> { typedef uint32_t type; };
-template <> struct CbCounts<2> { typedef uint16_t type; };
-
-template <int RPT>
-__device__ __forceinline__ void cb_unpack(const typename CbCounts<RPT>::type &v, uint32_t (&c)[RPT]) {
-    if constexpr (RPT == 16) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = (v[r >> 2] >> (8 * (r & 3))) & 0xffu;
-    } else if constexpr (RPT == 8) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) c[r] = (v[r >> 2] >> (8 * (r & 3))) & 0xffu;
-    } else {
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) c[r] = ((uint32_t)v >> (8 * r)) & 0xffu;
-    }
-}
 
 __device__ __forceinline__ uint32_t cb_wave_inclusive_scan(uint32_t v, uint32_t lane) {
 #pragma unroll
@@ -54,31 +34,37 @@ __device__ __forceinline__ uint32_t cb_wave_inclusive_scan(uint32_t v, uint32_t 
     return v;
 }
 
-// tile_ptr[rb * nbc + cb] = first entry of tile (rb, cb); cnt8[(rb * nbc + cb) * RB + r] = entries of row r of the
-// row block in column block cb (<= 255, checked by the plan); every tile holds at most kCbStrip entries (plan).
-template <typename T, int RPT, int U>
+// tile_ptr[rb * nbc + cb] = first entry of tile (rb, cb); rows16[e] = row of entry e inside its row block; a tile holds
+// at most S entries (plan).  Entry-parallel: the running sums of the row block live in LDS (acc), every entry's product
+// goes to the strip; an entry whose predecessor in the tile belongs to another row HEADS its row's run and adds the run
+// to acc[row] one product after the other -- acc[row], then + first product, then + second ...: the reference's order.
+// A row has one head per tile, so no two threads touch one acc[row] between two barriers.
+// RB (rows of a row block, <= kCbMaxRows) and S (strip entries) are the plan's: the row blocks are sized so that the
+// launch is a whole number of rounds of the workgroups the device holds (a launch of 1.2 rounds costs two).
+// LDS (dynamic): strip T[S] | acc T[RB rounded up to 2] | srow u16[S + 2].
+template <typename T, int U>
 __global__ __launch_bounds__(kCbThreads) void csr_spmv_cblock(const T *__restrict__ vals, const uint32_t *__restrict__ cols,
+                                                              const uint16_t *__restrict__ rows16,
                                                               const uint32_t *__restrict__ tile_ptr,
-                                                              const uint8_t *__restrict__ cnt8, const T *__restrict__ x,
-                                                              T *__restrict__ y, uint32_t nrows, uint32_t nbc) {
-    constexpr uint32_t RB = kCbThreads * RPT;
-    __shared__ __attribute__((aligned(16))) T strip[kCbStrip > RB ? kCbStrip : RB];
+                                                              const uint32_t *__restrict__ rowptr, const T *__restrict__ x,
+                                                              T *__restrict__ y, uint32_t nrows, uint32_t nbc, uint32_t RB,
+                                                              uint32_t S) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
+    T *strip = reinterpret_cast<T *>(spal_smem);
+    T *acc = strip + S;
+    uint16_t *srow = reinterpret_cast<uint16_t *>(acc + ((RB + 1u) & ~1u));   // srow[1 + i] = row of entry i; sentinels either side
     __shared__ uint32_t s_tp[kCbMaxBlocks + 1];
-    __shared__ uint32_t s_wsum[kCbThreads / 64];
-    using cnt_t = typename CbCounts<RPT>::type;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint32_t tid = threadIdx.x;
     const uint32_t rb = blockIdx.x;
     for (uint32_t i = tid; i <= nbc; i += kCbThreads) s_tp[i] = tile_ptr[(size_t)rb * nbc + i];
+    for (uint32_t i = tid; i < RB; i += kCbThreads) acc[i] = -T(0);
+    if (tid == 0) srow[0] = 0xffffu;
     __syncthreads();
-    T acc[RPT];
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) acc[r] = -T(0);
-    uint32_t seen = 0;                                    // bit r: row r of this thread holds an entry
-    const cnt_t *cnt_base = reinterpret_cast<const cnt_t *>(cnt8 + ((size_t)rb * nbc) * RB) + tid;
 
     // the first non-empty tile's entries are requested here, every later tile's while the one before it is summed
     T v[U];
     uint32_t c[U];
+    uint16_t rw[U];
     uint32_t cb = 0;
     while (cb < nbc && s_tp[cb + 1] == s_tp[cb]) ++cb;    // uniform
     auto request = [&](uint32_t e0, uint32_t n) {         // one batch: entries e0 + tid + 256 * u (clamped: unconditional loads)
@@ -87,68 +73,49 @@ __global__ __launch_bounds__(kCbThreads) void csr_spmv_cblock(const T *__restric
             const uint32_t i = e0 + min(tid + (uint32_t)u * kCbThreads, n - 1u);
             v[u] = load_stream(vals + i);
             c[u] = load_stream(cols + i);
+            rw[u] = load_stream(rows16 + i);
+        }
+    };
+    auto products = [&](uint32_t b0, uint32_t n) {        // the batch in hand -> strip and srow
+        T xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t i = b0 + tid + (uint32_t)u * kCbThreads;
+            if (i < n) { strip[i] = v[u] * xv[u]; srow[1 + i] = rw[u]; }
         }
     };
     if (cb < nbc) request(s_tp[cb], s_tp[cb + 1] - s_tp[cb]);
     while (cb < nbc) {
-        const uint32_t e0 = s_tp[cb], n = s_tp[cb + 1] - e0;   // 1 <= n <= kCbStrip
-        const cnt_t packed = cnt_base[(size_t)cb * (RB / RPT)];
-        // products of the batch in hand -> strip; further batches of a tile above 256 * U entries right after
-        {
-            T xv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) xv[u] = x[c[u]];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t i = tid + (uint32_t)u * kCbThreads;
-                if (i < n) strip[i] = v[u] * xv[u];
-            }
-        }
-        for (uint32_t b0 = kCbThreads * U; b0 < n; b0 += kCbThreads * U) {   // uniform
+        const uint32_t e0 = s_tp[cb], n = s_tp[cb + 1] - e0;   // 1 <= n <= S
+        products(0u, n);
+        for (uint32_t b0 = kCbThreads * U; b0 < n; b0 += kCbThreads * U) {   // uniform: tiles above 256 * U entries
             request(e0 + b0, n - b0);
-            T xv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) xv[u] = x[c[u]];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t i = b0 + tid + (uint32_t)u * kCbThreads;
-                if (i < n) strip[i] = v[u] * xv[u];
-            }
+            products(b0, n);
         }
+        if (tid == 0) srow[1 + n] = 0xffffu;               // no run continues past the tile
         // the next non-empty tile's first batch travels while this one is summed
         uint32_t nb = cb + 1;
         while (nb < nbc && s_tp[nb + 1] == s_tp[nb]) ++nb;
         if (nb < nbc) request(s_tp[nb], s_tp[nb + 1] - s_tp[nb]);
-        // where this thread's rows start in the strip: exclusive scan of the threads' entry counts
-        uint32_t cnt[RPT];
-        cb_unpack<RPT>(packed, cnt);
-        uint32_t mine = 0;
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) mine += cnt[r];
-        const uint32_t inc = cb_wave_inclusive_scan(mine, lane);
-        if (lane == 63) s_wsum[w] = inc;
-        __syncthreads();                                   // (also: every product is in the strip)
-        uint32_t pos = inc - mine;
-#pragma unroll
-        for (uint32_t i = 0; i < kCbThreads / 64; ++i)
-            if (i < w) pos += s_wsum[i];
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            for (uint32_t k = 0; k < cnt[r]; ++k) acc[r] = acc[r] + strip[pos++];
-            seen |= (cnt[r] ? 1u : 0u) << r;
+        __syncthreads();                                   // every product and row of the tile is in LDS
+        for (uint32_t i = tid; i < n; i += kCbThreads) {
+            const uint32_t r = srow[1 + i];
+            if (srow[i] != r) {                            // the row's first entry in this tile: its run, in order
+                T a = acc[r] + strip[i];
+                for (uint32_t k = i + 1; srow[1 + k] == r; ++k) a = a + strip[k];
+                acc[r] = a;
+            }
         }
-        __syncthreads();                                   // the strip is written again
+        __syncthreads();                                   // strip and srow are written again
         cb = nb;
     }
-    // y: through the strip, so that a wave stores 64 consecutive rows
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) strip[tid * RPT + r] = ((seen >> r) & 1u) ? acc[r] : T(0);
-    __syncthreads();
+    // y: rows without entries are +0.0 (the running sums started at -0.0: -0.0 + p == p for the first product)
     const uint32_t r0 = rb * RB;
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        const uint32_t i = tid + (uint32_t)r * kCbThreads;
-        if (r0 + i < nrows) y[r0 + i] = strip[i];
+    for (uint32_t i = tid; i < RB; i += kCbThreads) {
+        const uint32_t r = r0 + i;
+        if (r < nrows) y[r] = rowptr[r + 1] != rowptr[r] ? acc[i] : T(0);
     }
 }
 
@@ -187,27 +154,34 @@ __global__ __launch_bounds__(256) void cb_tile_totals(const uint8_t *__restrict_
     if (threadIdx.x == 0) tile_n[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-// the tiled copy: one workgroup per row block; thread t owns RPT consecutive rows, as in the product kernel, and
-// moves their entries tile by tile (plan time: bandwidth is not the point)
-template <typename T, int RPT>
+// the tiled copy: one workgroup per row block; thread t owns the rpt = ceil(RB / 256) consecutive rows t * rpt ... of it
+// and moves their entries tile by tile (plan time: bandwidth is not the point)
+template <typename T>
 __global__ __launch_bounds__(kCbThreads) void cb_fill(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
                                                       const T *__restrict__ values, const uint32_t *__restrict__ tile_ptr,
-                                                      const uint8_t *__restrict__ cnt8, uint32_t nrows, uint32_t nbc,
-                                                      uint32_t *__restrict__ out_col, T *__restrict__ out_val) {
-    constexpr uint32_t RB = kCbThreads * RPT;
+                                                      const uint8_t *__restrict__ cnt8, uint32_t nrows, uint32_t nbc, uint32_t RB,
+                                                      uint32_t *__restrict__ out_col, T *__restrict__ out_val,
+                                                      uint16_t *__restrict__ out_row) {
+    constexpr int kMaxRpt = (int)(kCbMaxRows / kCbThreads);
     __shared__ uint32_t s_wsum[kCbThreads / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, rb = blockIdx.x;
-    uint32_t src[RPT];
+    const uint32_t rpt = (RB + kCbThreads - 1) / kCbThreads;
+    uint32_t src[kMaxRpt];
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        const uint64_t row = (uint64_t)rb * RB + tid * RPT + r;
-        src[r] = row < nrows ? rowptr[row] : 0u;
+    for (int r = 0; r < kMaxRpt; ++r) {
+        const uint32_t rl = tid * rpt + (uint32_t)r;
+        const uint64_t row = (uint64_t)rb * RB + rl;
+        src[r] = ((uint32_t)r < rpt && rl < RB && row < nrows) ? rowptr[row] : 0u;
     }
     for (uint32_t cb = 0; cb < nbc; ++cb) {
-        const uint8_t *c8 = cnt8 + ((size_t)rb * nbc + cb) * RB + tid * RPT;
-        uint32_t cnt[RPT], mine = 0;
+        const uint8_t *c8 = cnt8 + ((size_t)rb * nbc + cb) * RB;
+        uint32_t cnt[kMaxRpt], mine = 0;
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) { cnt[r] = c8[r]; mine += cnt[r]; }
+        for (int r = 0; r < kMaxRpt; ++r) {
+            const uint32_t rl = tid * rpt + (uint32_t)r;
+            cnt[r] = ((uint32_t)r < rpt && rl < RB) ? c8[rl] : 0u;
+            mine += cnt[r];
+        }
         const uint32_t inc = cb_wave_inclusive_scan(mine, lane);
         if (lane == 63) s_wsum[w] = inc;
         __syncthreads();
@@ -217,10 +191,11 @@ __global__ __launch_bounds__(kCbThreads) void cb_fill(const uint32_t *__restrict
             if (i < w) pos += s_wsum[i];
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < RPT; ++r)
+        for (int r = 0; r < kMaxRpt; ++r)
             for (uint32_t k = 0; k < cnt[r]; ++k) {
                 out_col[pos] = colind[src[r]];
                 out_val[pos] = values[src[r]];
+                out_row[pos] = (uint16_t)(tid * rpt + (uint32_t)r);
                 ++pos;
                 ++src[r];
             }

@@ -35,6 +35,20 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t 
     return (bid & 7u) * per_xcd + (bid >> 3);
 }
 
+// ... or, with the top bit of `per_xcd` set, interleaved in CHUNKS of C = per_xcd & 0x7fffffff consecutive row blocks
+// (XCD x takes chunks x, x + 8, ...): neighbouring blocks still share an L2 inside a chunk, and all 8 XCDs work inside
+// one moving window of 8 * C blocks instead of at 8 places an eighth of the arrays apart -- worth 5 % in every
+// placement class in the footprint micro-benchmark (260 -> 245 us, 248 -> 235 us; profiles/r03/placement_pairs.txt).
+// The grid covers ceil(nblocks / 8C) * 8C blocks; blocks past the last return.
+constexpr uint32_t kXcdChunked = 0x80000000u;
+__device__ __forceinline__ uint32_t xcd_block(uint32_t bid, uint32_t per_xcd) {
+    if (per_xcd & kXcdChunked) {
+        const uint32_t C = per_xcd & ~kXcdChunked, xcd = bid & 7u, slot = bid >> 3;
+        return ((slot / C) * 8u + xcd) * C + slot % C;
+    }
+    return xcd_contiguous_block(bid, per_xcd);
+}
+
 template <typename T>
 __device__ __forceinline__ T load_stream(const T *p) {
     return __builtin_nontemporal_load(p);
@@ -505,7 +519,10 @@ __device__ __forceinline__ T strip_row_sum(const T *prod, uint32_t off, uint32_t
 // ... and the stores of a tile's results: RPT <= 64 a row per lane, RPT = 128 / 256 the lane's two / four adjacent rows
 template <typename T, int RPT, bool SKEW, typename Tile>
 __device__ __forceinline__ void strip_sums_to_y(const Tile &t, const T *prod, T *__restrict__ y, uint32_t row0,
-                                                uint32_t row1, uint32_t lane, bool nt_store) {
+                                                uint32_t row1, uint32_t lane, uint32_t nt_store) {
+    // nt_store: y stored non-temporally (the autotune's choice).  A third form -- written through at agent scope, an
+    // atomic store -- gained 2-6 us in a micro-benchmark, but its mere PRESENCE as a third branch in these kernels cost
+    // the sliding kernel 12 % (252.7 -> 283-290 us on one handle, never executed: profiles/r03/README.md): not built in.
     const uint32_t rlast = min(row0 + (uint32_t)RPT, row1);
     if constexpr (RPT > 64) {
         constexpr uint32_t RPL = RPT / 64;
@@ -599,7 +616,7 @@ __device__ __forceinline__ void stream_load(StreamTile<T> &t, const uint32_t *__
 template <typename T, int RPT, bool SKEW>
 __device__ __forceinline__ void stream_compute(const StreamTile<T> &t, const T *xw, uint32_t wmax,
                                                T *prod, T *__restrict__ y, uint32_t row0,
-                                               uint32_t row1, uint32_t lane, bool nt_store = false,
+                                               uint32_t row1, uint32_t lane, uint32_t nt_store = 0u,
                                                uint32_t flags = 0u) {
     using pair_t = typename Pair<T>::type;
 #pragma unroll
@@ -679,7 +696,7 @@ template <typename T, int RPT, bool SKEW>
 __device__ __forceinline__ void stream_compute_g(const StreamTileG<T> &t, const T *__restrict__ x,
                                                  uint32_t cmax, T *prod, T *__restrict__ y,
                                                  uint32_t row0, uint32_t row1, uint32_t lane,
-                                                 bool nt_store) {
+                                                 uint32_t nt_store) {
     using pair_t = typename Pair<T>::type;
     T xa[kStreamSteps], xb[kStreamSteps];
 #pragma unroll
@@ -764,7 +781,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_stream(
     T *prod_all = reinterpret_cast<T *>(spal_smem);
     T *xw = prod_all + kStreamWaves * stream_strip<SKEW>();
 
-    const uint32_t b = xcd_contiguous_block(blockIdx.x, per_xcd);
+    const uint32_t b = xcd_block(blockIdx.x, per_xcd);
     if (b >= nblocks) return;
     constexpr uint32_t kRows = stream_rows(TPW, RPT);
     const uint32_t row0 = b * kRows;

@@ -70,6 +70,14 @@ __global__ __launch_bounds__(256) void csc_block_windows(const uint32_t *__restr
     if (threadIdx.x == 0) out[blockIdx.x] = make_uint2(s_min, s_max);
 }
 
+// *differs |= 1 when some column does not hold exactly `len` entries
+__global__ __launch_bounds__(256) void csc_uniform_check(const uint32_t *__restrict__ colptr, uint32_t ncols, uint32_t len,
+                                                         uint32_t *__restrict__ differs) {
+    const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool bad = k < ncols && colptr[k + 1] - colptr[k] != len;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(differs, 1u);
+}
+
 // meta[p] = (row - rbase) | (col - k0) << 16 for LDS-mode super-tiles
 __global__ __launch_bounds__(256) void csc_encode_meta(const uint32_t *__restrict__ colptr,
                                                        const uint32_t *__restrict__ rowind,
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(kCscBlock, kCscBlock >= 1024 ? 1 : 2) void csc_spmv
     T *__restrict__ y, const uint4 *__restrict__ desc, uint32_t ncols, uint32_t nblocks,
     uint32_t per_xcd, uint32_t last_pair, T *__restrict__ windows, const uint32_t *__restrict__ prev_hi,
     uint32_t *__restrict__ flags, uint32_t epoch, uint32_t nrows, uint32_t ticket_base, uint32_t use_ticket,
-    uint32_t spin_bound, uint32_t *__restrict__ gave_up) {
+    uint32_t spin_bound, uint32_t *__restrict__ gave_up, uint32_t ulen) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_smem[];
     using pair_t = typename Pair<T>::type;
     using u2_t = __attribute__((ext_vector_type(2))) uint32_t;
@@ -130,7 +138,10 @@ __global__ __launch_bounds__(kCscBlock, kCscBlock >= 1024 ? 1 : 2) void csc_spmv
     const uint32_t k0 = b * kCscCols, k1 = min(k0 + (uint32_t)kCscCols, ncols);
     // desc and the two column pointers are independent loads: one round trip for the three
     const uint4 d = desc[b];  // block-uniform
-    const uint32_t p0 = colptr[k0], p1 = colptr[k1];  // uniform
+    // (every column of the matrix holds ulen - 1 entries: the column pointers are arithmetic, and the first batch of
+    //  entries can be requested without waiting for them -- one memory round trip less at the start of a workgroup
+    //  that lives for a dozen)
+    const uint32_t p0 = ulen ? k0 * (ulen - 1u) : colptr[k0], p1 = ulen ? k1 * (ulen - 1u) : colptr[k1];  // uniform
 
     if (d.z == kCscModeLds) {
         // entries in pairs from an even start; a batch = U pairs per thread.  The FIRST batch and this
@@ -356,7 +367,8 @@ static hipError_t csc_launch_c(const spal_csc *a, const void *x, void *y, hipStr
                        (uint32_t)(((a->nnz + kStreamPad) & ~(uint64_t)1) - 2),
                        (a->flush == 1 && a->d_windows) ? (T *)a->d_windows : (T *)nullptr,
                        epoch ? a->d_prev_hi : (const uint32_t *)nullptr, a->d_flags, epoch, (uint32_t)a->nrows,
-                       ticket_base, (uint32_t)(a->use_ticket < 0 ? a->ticket_auto : a->use_ticket), a->spin_bound, a->d_gave_up);
+                       ticket_base, (uint32_t)(a->use_ticket < 0 ? a->ticket_auto : a->use_ticket), a->spin_bound, a->d_gave_up,
+                       a->uniform_cols);
     return hipGetLastError();
 }
 
@@ -387,13 +399,25 @@ static hipError_t csc_launch_t(spal_csc *a, const void *x, void *y, hipStream_t 
             a->handoff_timeouts++;
             return hipErrorLaunchTimeOut;
         }
-        if (!a->ev_last) {
-            e = hipEventCreateWithFlags(&a->ev_last, hipEventDisableTiming);
-            if (e != hipSuccess) return e;
-        } else {
-            e = hipStreamWaitEvent(st, a->ev_last, 0);
+        // launches of one handle share its flags: each must run after the one before.  On ONE stream that is the
+        // stream's order and costs nothing; only a launch on another stream than the last waits for an event, recorded
+        // now on that last stream (it covers everything submitted there so far).  (An event wait + record around
+        // every launch cost ~3 us of a 38 us product in a loop.)
+        if (a->last_stream_valid && a->last_stream != st) {
+            if (!a->ev_last) {
+                e = hipEventCreateWithFlags(&a->ev_last, hipEventDisableTiming);
+                if (e != hipSuccess) return e;
+            }
+            e = hipEventRecord(a->ev_last, a->last_stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, a->ev_last, 0);
+            if (e != hipSuccess) {   // (the caller may have destroyed that stream meanwhile: everything it held has then run or is flushed here)
+                (void)hipGetLastError();
+                e = hipDeviceSynchronize();
+            }
             if (e != hipSuccess) return e;
         }
+        a->last_stream = st;
+        a->last_stream_valid = 1;
         if (++a->epoch == 0) {   // (wrapped after 2^32 launches: the flags and the ticket counter start over)
             e = hipMemsetAsync(a->d_flags, 0, ((size_t)a->nblocks + 2) * 4, st);
             if (e != hipSuccess) return e;
@@ -417,10 +441,7 @@ static hipError_t csc_launch_t(spal_csc *a, const void *x, void *y, hipStream_t 
         case 4096: e = csc_launch_c<T, 4096>(a, x, y, st, epoch, ticket_base); break;
         default: return hipErrorInvalidValue;
     }
-    if (ordered) {
-        if (e == hipSuccess) e = hipEventRecord(a->ev_last, st);
-        return e;
-    }
+    if (ordered) return e;
     if (e != hipSuccess || !two_phase) return e;
     if (assign)
         hipLaunchKernelGGL((csc_window_reduce<T, true>), dim3(a->nchunks), dim3(256), 0, st,
@@ -471,6 +492,22 @@ static int csc_plan_build(spal_csc *a) {
     a->lds_col_fraction = 0.0;
     a->cols_per_block = a->user_cols ? a->user_cols : 1024;
     a->nblocks = (uint32_t)((a->ncols + a->cols_per_block - 1) / a->cols_per_block);
+    a->uniform_cols = 0;
+    if (a->nnz && a->nnz % a->ncols == 0) {   // every column the same length?  (then the kernel computes the column pointers)
+        const uint32_t len = (uint32_t)(a->nnz / a->ncols);
+        uint32_t *d_f = nullptr, f = 1;
+        SPAL_HIP_TRY(dev_alloc((void **)&d_f, 4));
+        hipError_t e = hipMemsetAsync(d_f, 0, 4, a->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(csc_uniform_check, dim3((uint32_t)((a->ncols + 255) / 256)), dim3(256), 0, a->stream,
+                               a->d_colptr, (uint32_t)a->ncols, len, d_f);
+            e = hipMemcpyAsync(&f, d_f, 4, hipMemcpyDeviceToHost, a->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
+        (void)dev_free(d_f);
+        SPAL_HIP_TRY(e);
+        if (!f) a->uniform_cols = len + 1;
+    }
     std::vector<uint4> desc(a->nblocks, make_uint4(0, 0, kCscModeGlobal, 0));
     if (a->nnz && a->use_lds) {
         // row windows per 1024 columns (one device pass); wider super-tiles are unions of those
@@ -969,7 +1006,7 @@ int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len) {
              "{\"format\": \"csc\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"nnz\": %llu, "
              "\"kernel\": \"%s\", \"cols_per_block\": %d, \"blocks\": %u, \"lanes_per_col\": %d, "
              "\"lds_window_bytes\": %llu, \"lds_col_fraction\": %.4f, \"flush\": \"%s\", "
-             "\"window_store_bytes\": %llu, \"ticket\": %d, \"handoff_timeouts\": %d}",
+             "\"window_store_bytes\": %llu, \"ticket\": %d, \"handoff_timeouts\": %d, \"uniform_columns\": %d}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz,
              a->kernel == 2 ? "transposed_csr" : a->lds_entries ? "lds_privatised_scatter" : "atomic_scatter",
@@ -978,7 +1015,8 @@ int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len) {
              a->lds_col_fraction, (a->flush == 1 && a->d_windows) ? "windows_then_reduce"
                                   : (a->flush == 0 && a->ordered) ? "neighbour_handoff" : "global_atomics",
              (unsigned long long)a->windows_entries * (unsigned long long)a->elem_size, a->use_ticket < 0 ? a->ticket_auto : a->use_ticket,
-             a->handoff_timeouts + ((a->h_gave_up && __atomic_load_n(a->h_gave_up, __ATOMIC_RELAXED)) ? 1 : 0));
+             a->handoff_timeouts + ((a->h_gave_up && __atomic_load_n(a->h_gave_up, __ATOMIC_RELAXED)) ? 1 : 0),
+             a->uniform_cols ? 1 : 0);
     return SPAL_OK;
 }
 

@@ -710,16 +710,19 @@ static hipError_t launch_stream_tpw(const spal_csr *a, const void *x, void *y, h
     // rows: a wave per row, four (colind, value) pairs per lane in flight (any geometry is correct)
     constexpr int L = 64;
     const CsrPlan &p = a->plan;
-    const uint32_t per_xcd = (p.nblocks + 7) / 8;
+    // the 8 XCDs: one contiguous run of super-tiles each, or (option "xcd_chunk", default 32) interleaved in chunks
+    const uint32_t C = (uint32_t)p.xcd_chunk;
+    const uint32_t per_xcd = C ? (kXcdChunked | C) : (p.nblocks + 7) / 8;
+    const uint32_t grid = C ? ((p.nblocks + 8 * C - 1) / (8 * C)) * 8 * C : ((p.nblocks + 7) / 8) * 8;
     const size_t lds = ((size_t)kStreamWaves * stream_strip<SKEW>() + p.lds_entries) * sizeof(T);
     auto kern = csr_spmv_stream<T, L, 1, true, TPW, RPT, SKEW, PF>;
     static std::atomic<uint64_t> configured{0};
     hipError_t e = raise_lds_cap(kern, a->device, lds, configured);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
                        a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc, a->d_pages,
                        (uint32_t)a->nrows, (uint32_t)a->ncols, (uint32_t)a->nnz, p.nblocks, per_xcd,
-                       (uint32_t)(p.nt_store ? 1 : 0) | ((a->n_ptiles && panel_runs(a, x)) ? 2u : 0u) | (uint32_t)p.diag,
+                       (uint32_t)(p.nt_store == 1 ? 1 : 0) | ((a->n_ptiles && panel_runs(a, x)) ? 2u : 0u) | (uint32_t)p.diag,
                        (uint32_t)p.ring_pages);
     return hipGetLastError();
 }
@@ -748,7 +751,7 @@ static hipError_t launch_stream_persistent(const spal_csr *a, const void *x, voi
     hipLaunchKernelGGL(kern, dim3(used * 8), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_colind,
                        a->d_col16, (const T *)a->d_values, (const T *)x, (T *)y, a->d_desc, a->d_pages,
                        (uint32_t)a->nrows, (uint32_t)a->ncols, (uint32_t)a->nnz, p.nblocks, per_xcd, chunk,
-                       (uint32_t)(p.nt_store ? 1 : 0) | ((a->n_ptiles && panel_runs(a, x)) ? 2u : 0u), (uint32_t)p.ring_pages);
+                       (uint32_t)(p.nt_store == 1 ? 1 : 0) | ((a->n_ptiles && panel_runs(a, x)) ? 2u : 0u), (uint32_t)p.ring_pages);
     return hipGetLastError();
 }
 
@@ -841,6 +844,14 @@ int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream) 
                                (float *)y_dev, n);
         SPAL_HIP_TRY(hipGetLastError());
         return SPAL_OK;
+    }
+    if (a->plan.cblock_pending) {   // a handle assembled on the device whose columns are anywhere: the tiled copy, once
+        std::lock_guard<std::mutex> lock(a->mu_cb);
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (a->plan.cblock_pending && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+            a->plan.cblock_pending = 0;
+            SPAL_TRY(cblock_plan(a, false));
+        }
     }
     hipError_t e = a->elem_size == 8 ? launch_lanes<double>(a, x_dev, y_dev, stream)
                                      : launch_lanes<float>(a, x_dev, y_dev, stream);
@@ -1214,10 +1225,15 @@ int csr_plan_build(spal_csr *a) {
                     if (best_desc[b].z == kModeStreamGlobal && !(best_desc[b].w & 2u))
                         far_rows += std::min<uint64_t>(R, a->nrows - (uint64_t)b * R);
                 p.nonlocal_row_fraction = (double)far_rows / (double)a->nrows;
-                if (p.cblock_user == 1 || (p.cblock_user < 0 && p.nonlocal_row_fraction >= 0.5))
-                    SPAL_TRY(cblock_plan(a, p.cblock_user == 1));
-                else
+                p.cblock_pending = 0;
+                if (getenv("SPAL_CBLOCK_DEBUG"))
+                    fprintf(stderr, "[spal cblock] plan: nonlocal rows %.3f, user %d, lazy %d\n", p.nonlocal_row_fraction, p.cblock_user, a->cblock_lazy);
+                if (p.cblock_user == 1 || (p.cblock_user < 0 && p.nonlocal_row_fraction >= 0.5)) {
+                    if (a->cblock_lazy && p.cblock_user < 0) { cblock_free(a); p.cblock_pending = 1; }   // built by the first product
+                    else SPAL_TRY(cblock_plan(a, p.cblock_user == 1));
+                } else {
                     cblock_free(a);
+                }
             }
             return SPAL_OK;
         }
@@ -1346,7 +1362,7 @@ static void csr_free(spal_csr *a) {
 
 int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, uint64_t nnz,
                      uint64_t cap_entries, uint32_t *d_rowptr, uint32_t *d_colind, void *d_values,
-                     spal_csr **out, const std::vector<uint2> *win256) {
+                     spal_csr **out, const std::vector<uint2> *win256, bool eager_copies) {
     spal_csr *a = new spal_csr;
     if (win256 && win256->size() == (nrows + kWinBase - 1) / kWinBase) a->win_base = *win256;
     a->device = device;
@@ -1354,6 +1370,7 @@ int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, 
     a->nrows = nrows; a->ncols = ncols; a->nnz = nnz;
     a->d_rowptr = d_rowptr; a->d_colind = d_colind; a->d_values = d_values;
     a->cap_entries = cap_entries;
+    a->cblock_lazy = eager_copies ? 0 : 1;   // (a handle created from host arrays pays for its second copy at create time)
     auto bail = [&](int st) {
         // the caller keeps ownership of the arrays it passed in on failure
         if (a->d_rowptr == d_rowptr) a->d_rowptr = nullptr;
@@ -1428,7 +1445,7 @@ static int csr_create_rows(int device, uint64_t r0, uint64_t r1, uint64_t ncols,
                     "spal_csr_create: upload failed: %s", hipGetErrorString(e));
     }
     spal_csr *a = nullptr;
-    int st = csr_adopt_device(device, (int)sizeof(T), nrows, ncols, nnz, cap, d_rp, d_ci, d_v, &a);
+    int st = csr_adopt_device(device, (int)sizeof(T), nrows, ncols, nnz, cap, d_rp, d_ci, d_v, &a, nullptr, true);
     if (st != SPAL_OK) { cleanup(); return st; }
     *out = a;
     return SPAL_OK;
@@ -1596,7 +1613,13 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t e0, e1;
     SPAL_HIP_TRY(hipEventCreate(&e0));
-    SPAL_HIP_TRY(hipEventCreate(&e1));
+    {
+        const hipError_t ee = hipEventCreate(&e1);
+        if (ee != hipSuccess) {
+            (void)hipEventDestroy(e0);
+            return fail(SPAL_ERR_HIP, "spal_csr_autotune: hipEventCreate: %s", hipGetErrorString(ee));
+        }
+    }
     int rc = SPAL_OK;
     auto timed = [&](int n, float *ms_per_launch) {   // n launches of the current configuration
         for (int i = 0; i < 3 && rc == SPAL_OK; ++i) rc = csr_launch(a, x_dev, y_dev, st);
@@ -1612,6 +1635,7 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
     };
     // ---- 0. columns anywhere: the column-blocked kernel against the stream kernels (results are bit-identical)
     a->cblock_us[0] = a->cblock_us[1] = 0.f;
+    if (p.cblock_pending) { p.cblock_pending = 0; rc = cblock_plan(a, false); }
     if (p.cblock) {
         float ms[2] = {0.f, 0.f};
         for (int round = 0; round < 2 && rc == SPAL_OK; ++round)
@@ -1882,15 +1906,19 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
 #else
         return fail(SPAL_ERR_INVALID_ARGUMENT, "diag: this library is not an ablation build (-DSPAL_DIAG)");
 #endif
+    } else if (!strcmp(key, "xcd_chunk")) {
+        // one-super-tile stream kernel: super-tiles dealt to the 8 XCDs in chunks of this many (0 = one contiguous run per XCD)
+        if (value < 0 || value > 4096) return fail(SPAL_ERR_INVALID_ARGUMENT, "xcd_chunk must be in [0, 4096]");
+        p.xcd_chunk = (int)value;
     } else if (!strcmp(key, "cblock")) {
         // the column-blocked kernel (csr_cblock.hpp): -1 = when most rows gather x from beyond L2, 0 = never, 1 = always
         if (value < -1 || value > 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "cblock must be -1 (auto), 0 or 1");
         p.cblock_user = (int)value;
         p.cblock_on = 1;
-    } else if (!strcmp(key, "cblock_rpt")) {
-        if (value != 0 && value != 2 && value != 4 && value != 8 && value != 16)
-            return fail(SPAL_ERR_INVALID_ARGUMENT, "cblock_rpt (rows per thread; a row block holds 256 times as many) must be 0 (auto), 2, 4, 8 or 16");
-        p.cblock_rpt_user = (int)value;
+    } else if (!strcmp(key, "cblock_rows")) {
+        if (value < 0 || value > 4096)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "cblock_rows (rows of a row block of the column-blocked kernel) must be 0 (auto) or in [1, 4096]");
+        p.cblock_rows_user = (int)value;
     } else if (!strcmp(key, "cblock_shift")) {
         if (value != 0 && (value < 8 || value > 24))
             return fail(SPAL_ERR_INVALID_ARGUMENT, "cblock_shift (log2 of the columns of a column block) must be 0 (auto: 2 MB of x) or in [8, 24]");
@@ -1938,7 +1966,7 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f, "
              "\"overflow_tiles\": %u, \"skew\": %d, \"persistent\": %d, \"nt_store\": %d, \"uniform_row_fraction\": %.4f, "
              "\"prefetch\": %d, \"slide\": %d, \"ring_pages\": %d, \"tile_steps\": %d, \"split_tiles\": %u, \"panel_tiles\": %u, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f], \"placement_us\": [%.1f, %.1f], \"placement_tries\": %d, \"addr\": [\"%llx\", \"%llx\", \"%llx\"], "
-             "\"nonlocal_row_fraction\": %.4f, \"cblock\": %d, \"cblock_rows\": %d, \"cblock_cols\": %llu, \"cblock_col_blocks\": %d, \"cblock_row_blocks\": %u, \"cblock_us\": [%.1f, %.1f]}",
+             "\"nonlocal_row_fraction\": %.4f, \"cblock\": %d, \"cblock_pending\": %d, \"cblock_rows\": %d, \"cblock_cols\": %llu, \"cblock_col_blocks\": %d, \"cblock_row_blocks\": %u, \"cblock_us\": [%.1f, %.1f]}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, (p.kernel == 2 || p.vec_col16) ? 16 : 32,
              (p.cblock && p.cblock_on) ? "cblock" : p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
@@ -1948,7 +1976,7 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              p.kernel == 2 ? ((p.slide && p.slide_on) ? a->n_ovtiles_slide : a->n_ovtiles) : 0u,   // (tiles the overflow kernel runs)
              (p.kernel == 2 && p.skew) ? 1 : 0,
              (p.kernel == 2 && p.persistent && p.tiles_per_wave == 4) ? 1 : 0,
-             (p.kernel == 2 && p.nt_store) ? 1 : 0, p.kernel == 2 ? p.uniform_row_fraction : 0.0,
+             p.kernel == 2 ? p.nt_store : 0, p.kernel == 2 ? p.uniform_row_fraction : 0.0,
              p.kernel == 2 ? p.prefetch : 0, (p.kernel == 2 && p.slide && p.slide_on) ? 1 : 0,
              p.kernel == 2 ? p.ring_pages : 0, (p.kernel == 2 && p.slide) ? p.slide_S : 0,
              (p.kernel == 2 && p.slide && p.slide_on) ? a->n_split_tiles : 0u,
@@ -1957,7 +1985,7 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              (double)a->tuned_us[2], (double)a->tuned_us[3], (double)a->place_us[0], (double)a->place_us[1],
              a->place_tried, (unsigned long long)(uintptr_t)a->d_values,
              (unsigned long long)(uintptr_t)a->d_col16, (unsigned long long)(uintptr_t)a->d_rowptr,
-             p.kernel == 2 ? p.nonlocal_row_fraction : 0.0, (p.cblock && p.cblock_on) ? 1 : 0, p.cblock ? 256 * p.cblock_rpt : 0,
+             p.kernel == 2 ? p.nonlocal_row_fraction : 0.0, (p.cblock && p.cblock_on) ? 1 : 0, p.cblock_pending, p.cblock ? p.cblock_rows : 0,
              p.cblock ? (1ull << p.cblock_shift) : 0ull, p.cblock ? p.cblock_nbc : 0, p.cblock ? p.cblock_nrb : 0u,
              (double)a->cblock_us[0], (double)a->cblock_us[1]);
     return SPAL_OK;

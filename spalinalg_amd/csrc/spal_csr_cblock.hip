@@ -9,26 +9,36 @@ void cblock_free(spal_csr *a) {
     (void)dev_free(a->d_cb_col); a->d_cb_col = nullptr;
     (void)dev_free(a->d_cb_tile); a->d_cb_tile = nullptr;
     (void)dev_free(a->d_cb_cnt); a->d_cb_cnt = nullptr;
+    (void)dev_free(a->d_cb_row); a->d_cb_row = nullptr;
     a->plan.cblock = 0;
 }
 
-template <typename T, int RPT>
-static void fill_t(spal_csr *a, uint32_t nrb, uint32_t nbc) {
-    hipLaunchKernelGGL((cb_fill<T, RPT>), dim3(nrb), dim3(kCbThreads), 0, a->stream, a->d_rowptr, a->d_colind,
-                       (const T *)a->d_values, a->d_cb_tile, a->d_cb_cnt, (uint32_t)a->nrows, nbc, a->d_cb_col,
-                       (T *)a->d_cb_val);
+static size_t cb_lds_bytes(uint32_t RB, uint32_t S, size_t esz) {
+    return (size_t)S * esz + (size_t)((RB + 1u) & ~1u) * esz + ((size_t)S + 2) * 2;
+}
+static uint32_t cb_per_cu(size_t lds) {   // workgroups of 256 threads a CU holds: LDS decides (160 KiB), at most 8
+    return (uint32_t)std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / (lds + 512)));
 }
 
 // Builds the tiled copy when the matrix qualifies: x larger than an XCD's L2 keeps warm by itself, at most
-// kCbMaxBlocks column blocks of 2 MB of x, at most 255 entries of a row per column block, and a row-block height
-// (4096 ... 512 rows) whose fullest tile fits the product strip.  `force`: option "cblock" = 1 (tests: small matrices).
-// Returns SPAL_OK with a->plan.cblock = 0 when the matrix does not qualify.
+// kCbMaxBlocks column blocks of 2 MB of x, at most 255 entries of a row per column block (the builder's counts are
+// bytes), and a row-block height whose fullest tile fits the product strip.  The height is chosen so that the launch is
+// (nearly) a WHOLE number of rounds of the workgroups the device holds: the workgroups of a round run side by side
+// through the column blocks (that is what keeps one x slice in L2), so a launch of 1.2 rounds takes as long as one of
+// two -- 5M x 5M at 4096 rows per block: 1221 workgroups for 1024 places.  `force`: option "cblock" = 1 (tests: small
+// matrices).  Returns SPAL_OK with a->plan.cblock = 0 when the matrix does not qualify.
 int cblock_plan(spal_csr *a, bool force) {
     CsrPlan &p = a->plan;
     cblock_free(a);
     if (a->nnz == 0 || !a->parts.empty()) return SPAL_OK;
     const size_t esz = (size_t)a->elem_size;
-    uint32_t shift = esz == 8 ? 18 : 19;                       // 2 MB of x per column block
+    uint32_t shift = esz == 8 ? 18 : 19;                       // 2 MB of x per column block ...
+    // ... narrower where rows are long: the kernel is entry-parallel, the thread that heads a row's run inside a tile
+    // adds the whole run, so runs should hold about one entry (14 per row over 4 column blocks: 3.5 per run, a quarter
+    // of the threads busy in that phase)
+    const double mean_row = (double)a->nnz / (double)a->nrows;
+    while (shift > 15 && mean_row / (double)((a->ncols + (1ull << shift) - 1) >> shift) > 1.25 &&
+           ((a->ncols + (1ull << (shift - 1)) - 1) >> (shift - 1)) <= kCbMaxBlocks) --shift;
     if (p.cblock_shift_user > 0) shift = (uint32_t)p.cblock_shift_user;
     const uint64_t nbc64 = (a->ncols + (1ull << shift) - 1) >> shift;
     if (nbc64 > kCbMaxBlocks) return SPAL_OK;
@@ -36,18 +46,40 @@ int cblock_plan(spal_csr *a, bool force) {
     const uint32_t nbc = (uint32_t)nbc64;
     const double mean = (double)a->nnz / (double)a->nrows;
     if (!force && mean > 64.0) return SPAL_OK;                 // long rows: the vector kernels' business
-    // row-block heights, tallest first (fewest bytes of counts per entry); the fullest tile decides
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, a->device);
+    // candidate heights, tallest first: the tallest whose launch fills at least 92 % of its last round (or is long enough
+    // -- 6 rounds and more -- for the last round not to matter), else the best filled
+    auto strip_for = [&](uint32_t RB) {   // entries: the average tile + 30 %, a power of two, at least 1024
+        uint32_t S = 1024;
+        while (S < kCbStrip && (double)S < 1.3 * (double)RB * mean / (double)nbc + 64.0) S <<= 1;
+        return S;
+    };
+    std::vector<uint32_t> cands;
+    if (p.cblock_rows_user > 0) cands.push_back((uint32_t)p.cblock_rows_user);
+    else {
+        uint32_t best = 0;
+        double best_eff = 0.0;
+        for (uint32_t RB = kCbMaxRows; RB >= 256; RB -= 128) {
+            if (1.3 * (double)RB * mean / (double)nbc + 64.0 > (double)kCbStrip) continue;   // the average tile would not fit
+            if ((size_t)((a->nrows + RB - 1) / RB) * nbc * RB > (size_t)a->nnz * 12 && !force) continue;   // counts heavier than the entries
+            const uint32_t slots = (uint32_t)cus * cb_per_cu(cb_lds_bytes(RB, strip_for(RB), esz));
+            const double rounds = (double)((a->nrows + RB - 1) / RB) / (double)slots;
+            const double eff = rounds / std::ceil(rounds);
+            if (eff >= 0.92 || rounds >= 6.0) { cands.push_back(RB); break; }
+            if (eff > best_eff) { best_eff = eff; best = RB; }
+        }
+        if (cands.empty() && best) cands.push_back(best);
+        for (uint32_t RB : {2048u, 1024u, 512u}) cands.push_back(RB);   // (when the fullest tile of the first choice does not fit)
+    }
     uint32_t *d_flag = nullptr, *d_tile_n = nullptr;
-    int chosen = 0;
+    uint32_t chosen = 0, S = 0;
     std::vector<uint32_t> tile_n;
     SPAL_HIP_TRY(dev_alloc((void **)&d_flag, 4));
-    for (int rpt : {16, 8, 4, 2}) {
-        if (p.cblock_rpt_user > 0 && rpt != p.cblock_rpt_user) continue;
-        const uint32_t RB = (uint32_t)kCbThreads * (uint32_t)rpt;
-        if ((double)RB * mean / (double)nbc > 0.9 * (double)kCbStrip && rpt > 2 && p.cblock_rpt_user <= 0) continue;   // average tile too full: do not even count
+    for (uint32_t RB : cands) {
+        if (RB < 1 || RB > kCbMaxRows) continue;
         const uint32_t nrb = (uint32_t)((a->nrows + RB - 1) / RB);
         const size_t cnt_bytes = (size_t)nrb * nbc * RB;
-        if (cnt_bytes > ((size_t)a->nnz * 12) && !force) break;                  // counts heavier than the entries: not this kernel's matrix
         (void)dev_free(a->d_cb_cnt); a->d_cb_cnt = nullptr;
         (void)dev_free(d_tile_n); d_tile_n = nullptr;
         SPAL_HIP_TRY(dev_alloc((void **)&a->d_cb_cnt, cnt_bytes));
@@ -66,12 +98,20 @@ int cblock_plan(spal_csr *a, bool force) {
         if (flag) break;                                       // a row with more than 255 entries in one column block
         uint32_t fullest = 0;
         for (uint32_t n : tile_n) fullest = std::max(fullest, n);
-        if (fullest <= kCbStrip) { chosen = rpt; break; }
+        if (fullest <= kCbStrip) {
+            chosen = RB;
+            S = strip_for(RB);
+            while (S < fullest) S <<= 1;
+            break;
+        }
     }
     (void)dev_free(d_flag);
     (void)dev_free(d_tile_n);
+    if (getenv("SPAL_CBLOCK_DEBUG"))
+        fprintf(stderr, "[spal cblock] %llu x %llu, %.2f per row, %u column blocks of 2^%u: %u rows per block, strip %u%s\n", (unsigned long long)a->nrows,
+                (unsigned long long)a->ncols, mean, nbc, shift, chosen, S, chosen ? "" : " (does not qualify)");
     if (!chosen) { cblock_free(a); return SPAL_OK; }
-    const uint32_t RB = (uint32_t)kCbThreads * (uint32_t)chosen;
+    const uint32_t RB = chosen;
     const uint32_t nrb = (uint32_t)((a->nrows + RB - 1) / RB);
     std::vector<uint32_t> tp((size_t)nrb * nbc + 1);
     uint64_t run = 0;
@@ -81,37 +121,46 @@ int cblock_plan(spal_csr *a, bool force) {
     SPAL_HIP_TRY(dev_alloc((void **)&a->d_cb_tile, tp.size() * 4));
     SPAL_HIP_TRY(dev_alloc((void **)&a->d_cb_col, ((size_t)a->nnz + 256) * 4));
     SPAL_HIP_TRY(dev_alloc((void **)&a->d_cb_val, ((size_t)a->nnz + 256) * esz));
+    SPAL_HIP_TRY(dev_alloc((void **)&a->d_cb_row, ((size_t)a->nnz + 256) * 2));
     SPAL_HIP_TRY(hipMemcpyAsync(a->d_cb_tile, tp.data(), tp.size() * 4, hipMemcpyHostToDevice, a->stream));
-#define SPAL_CB_FILL(RPT) \
-    case RPT: if (esz == 8) fill_t<double, RPT>(a, nrb, nbc); else fill_t<float, RPT>(a, nrb, nbc); break;
-    switch (chosen) { SPAL_CB_FILL(16) SPAL_CB_FILL(8) SPAL_CB_FILL(4) SPAL_CB_FILL(2) }
-#undef SPAL_CB_FILL
+    if (esz == 8)
+        hipLaunchKernelGGL(cb_fill<double>, dim3(nrb), dim3(kCbThreads), 0, a->stream, a->d_rowptr, a->d_colind, (const double *)a->d_values,
+                           a->d_cb_tile, a->d_cb_cnt, (uint32_t)a->nrows, nbc, RB, a->d_cb_col, (double *)a->d_cb_val, a->d_cb_row);
+    else
+        hipLaunchKernelGGL(cb_fill<float>, dim3(nrb), dim3(kCbThreads), 0, a->stream, a->d_rowptr, a->d_colind, (const float *)a->d_values,
+                           a->d_cb_tile, a->d_cb_cnt, (uint32_t)a->nrows, nbc, RB, a->d_cb_col, (float *)a->d_cb_val, a->d_cb_row);
     SPAL_HIP_TRY(hipGetLastError());
     SPAL_HIP_TRY(hipStreamSynchronize(a->stream));             // `tp` goes out of scope
+    (void)dev_free(a->d_cb_cnt); a->d_cb_cnt = nullptr;       // the counts were the builder's; the kernel reads the entries' rows
     p.cblock = 1;
-    p.cblock_rpt = chosen;
+    p.cblock_rows = (int)RB;
+    p.cblock_strip = (int)S;
     p.cblock_shift = (int)shift;
     p.cblock_nbc = (int)nbc;
     p.cblock_nrb = nrb;
     return SPAL_OK;
 }
 
-template <typename T, int RPT>
+template <typename T>
 static hipError_t launch_cb(const spal_csr *a, const void *x, void *y, hipStream_t st) {
-    hipLaunchKernelGGL((csr_spmv_cblock<T, RPT, 8>), dim3(a->plan.cblock_nrb), dim3(kCbThreads), 0, st,
-                       (const T *)a->d_cb_val, a->d_cb_col, a->d_cb_tile, a->d_cb_cnt, (const T *)x, (T *)y,
-                       (uint32_t)a->nrows, (uint32_t)a->plan.cblock_nbc);
+    const CsrPlan &p = a->plan;
+    const size_t lds = cb_lds_bytes((uint32_t)p.cblock_rows, (uint32_t)p.cblock_strip, sizeof(T));
+    auto kern = csr_spmv_cblock<T, 8>;
+    static std::atomic<uint64_t> configured{0};
+    const uint64_t bit = 1ull << (a->device & 63);
+    if (lds > 48 * 1024 && !(configured.load(std::memory_order_relaxed) & bit)) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        if (e != hipSuccess) return e;
+        configured.fetch_or(bit, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(kern, dim3(p.cblock_nrb), dim3(kCbThreads), lds, st, (const T *)a->d_cb_val, a->d_cb_col, a->d_cb_row,
+                       a->d_cb_tile, a->d_rowptr, (const T *)x, (T *)y, (uint32_t)a->nrows, (uint32_t)p.cblock_nbc,
+                       (uint32_t)p.cblock_rows, (uint32_t)p.cblock_strip);
     return hipGetLastError();
 }
 
 hipError_t launch_cblock(const spal_csr *a, const void *x, void *y, hipStream_t st) {
-#define SPAL_CB_CASE(RPT) \
-    case RPT: return a->elem_size == 8 ? launch_cb<double, RPT>(a, x, y, st) : launch_cb<float, RPT>(a, x, y, st);
-    switch (a->plan.cblock_rpt) {
-        SPAL_CB_CASE(16) SPAL_CB_CASE(8) SPAL_CB_CASE(4) SPAL_CB_CASE(2)
-        default: return hipErrorInvalidValue;
-    }
-#undef SPAL_CB_CASE
+    return a->elem_size == 8 ? launch_cb<double>(a, x, y, st) : launch_cb<float>(a, x, y, st);
 }
 
 }  // namespace spal

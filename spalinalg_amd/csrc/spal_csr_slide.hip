@@ -88,7 +88,7 @@ static hipError_t launch_panel_inst(const spal_csr *a, const void *x, void *y, h
     hipLaunchKernelGGL(kern, dim3(a->n_ptiles), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_col16,
                        (const T *)a->d_values, (const T *)x, (T *)y, a->d_ptiles, a->d_pwin, a->d_desc, a->n_ptiles,
                        (uint32_t)a->nrows, (uint32_t)a->ncols, (uint32_t)p.panel_window_pages,
-                       (uint32_t)(p.nt_store ? 1 : 0));
+                       (uint32_t)(p.nt_store == 1 ? 1 : 0));
     return hipGetLastError();
 }
 

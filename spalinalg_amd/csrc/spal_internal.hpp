@@ -127,12 +127,16 @@ struct CsrPlan {
     int panel_window_pages = 0;  // pages of one panel (LDS)
     int panel_window_user = 0;   // option "panel_window" (0 = 80 KB)
     int slide_run = 0;       // steps per run (0 = one run per workgroup: fully persistent)
+    int xcd_chunk = 32;      // one-super-tile stream kernel: chunks of super-tiles per XCD (0 = one run per XCD)
     // the column-blocked kernel (csr_cblock.hpp): matrices whose columns are not local
     int cblock_user = -1;    // option "cblock": -1 = when the plan finds most rows gathering x from beyond L2, 0 never, 1 always (tests)
     int cblock = 0;          // the tiled copy is built
+    int cblock_pending = 0;  // the matrix qualifies; the copy is built by the first product (handles assembled on the device:
+                             // the assembly call does not pay for a second copy nobody may use)
     int cblock_on = 1;       // launch it (autotune: 0 when the stream kernels measured faster)
-    int cblock_rpt = 0;      // rows per thread: a row block holds 256 * cblock_rpt rows
-    int cblock_rpt_user = 0, cblock_shift_user = 0;   // options "cblock_rpt", "cblock_shift"
+    int cblock_rows = 0;     // rows of a row block (one workgroup each)
+    int cblock_strip = 0;    // entries of the product strip (the fullest tile fits)
+    int cblock_rows_user = 0, cblock_shift_user = 0;   // options "cblock_rows", "cblock_shift"
     int cblock_shift = 0;    // a column block holds 2^shift columns
     int cblock_nbc = 0;      // column blocks
     uint32_t cblock_nrb = 0; // row blocks = workgroups
@@ -190,8 +194,11 @@ struct spal_csr {
     // column-blocked copy (csr_cblock.hpp): entries ordered (row block, column block, row, column)
     void *d_cb_val = nullptr;
     uint32_t *d_cb_col = nullptr, *d_cb_tile = nullptr;   // columns; first entry of every tile (+ the end)
-    uint8_t *d_cb_cnt = nullptr;   // entries per (tile, row)
+    uint8_t *d_cb_cnt = nullptr;   // entries per (tile, row): the builder's scratch
+    uint16_t *d_cb_row = nullptr;  // row of every entry inside its row block
     float cblock_us[2] = {0.f, 0.f};   // autotune: per launch {stream kernels, column-blocked kernel}
+    int cblock_lazy = 0;           // build the tiled copy with the first product, not with the plan (csr_adopt_device)
+    std::mutex mu_cb;
     // autotune: microseconds per launch of {plain, persistent} x {plain, non-temporal y stores}
     float tuned_us[4] = {0.f, 0.f, 0.f, 0.f};
     float place_us[2] = {0.f, 0.f};   // autotune: per launch before / after re-placing the values array
@@ -235,10 +242,13 @@ struct spal_csc {
     uint32_t ticket_next = 0;      // value of the ticket counter when the next launch begins (guarded by mu_launch)
     uint32_t spin_bound = 1u << 22;
     int use_ticket = -1;           // option "ticket": -1 = ticket_auto
+    uint32_t uniform_cols = 0;     // 1 + the length of every column when all columns have one length (the kernel computes colptr), else 0
     int ticket_auto = 0;           // plan: the launch has more workgroups than the device holds at once
     int handoff_timeouts = 0;      // products of this handle that hit the spin bound (their y was invalid)
     uint32_t epoch = 0;            // launch number (guarded by mu, with ev_last)
-    hipEvent_t ev_last = nullptr;  // launches of one handle run one after the other (they share d_flags)
+    hipEvent_t ev_last = nullptr;  // launches of one handle run one after the other (they share d_flags): stream order, or this event across streams
+    hipStream_t last_stream = nullptr;
+    int last_stream_valid = 0;
     std::mutex mu_launch;          // ... chained under this lock
     int all_lds = 0;               // every super-tile with entries is in LDS mode: y needs no memset
     int cols_per_block = 1024;     // columns of a super-tile: 4096 / 2048 / 1024 (the widest whose row windows fit LDS)
@@ -293,5 +303,5 @@ hipError_t launch_cblock(const spal_csr *a, const void *x, void *y, hipStream_t 
 int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols,
                      uint64_t nnz, uint64_t cap_entries, uint32_t *d_rowptr,
                      uint32_t *d_colind, void *d_values, spal_csr **out,
-                     const std::vector<uint2> *win256 = nullptr);
+                     const std::vector<uint2> *win256 = nullptr, bool eager_copies = false);
 }  // namespace spal

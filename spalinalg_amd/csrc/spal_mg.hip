@@ -431,8 +431,10 @@ static int mg_multiply_allgather(spal_mg_csr *a) {
         if (!a->d_yall[g]) {
             DeviceGuard guard(c->devices[g]);
             if (guard.status != SPAL_OK) return guard.status;
-            SPAL_HIP_TRY(dev_alloc(&a->d_ypad[g], a->max_rows * es));
-            SPAL_HIP_TRY(hipMemsetAsync(a->d_ypad[g], 0, a->max_rows * es, c->streams[g]));
+            if (!a->d_ypad[g]) {   // (guarded on its own pointer: a failed d_yall below must not allocate it again next time)
+                SPAL_HIP_TRY(dev_alloc(&a->d_ypad[g], a->max_rows * es));
+                SPAL_HIP_TRY(hipMemsetAsync(a->d_ypad[g], 0, a->max_rows * es, c->streams[g]));
+            }
             SPAL_HIP_TRY(dev_alloc(&a->d_yall[g], (size_t)c->ngpus * a->max_rows * es));
         }
     SPAL_TRY(mg_launch_shards(a, a->d_x, a->d_ypad, false));

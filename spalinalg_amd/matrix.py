@@ -257,6 +257,7 @@ class MultiGpuCsr:
         check(_ffi.lib().spal_mg_transport(self._ctx, C.byref(t)))
         self.transport = "rccl" if t.value == 0 else "copy"
         self.root_device = devices[0] if devices is not None else 0
+        self.devices = list(devices) if devices is not None else list(range(ngpus))
 
     def partition(self) -> np.ndarray:
         b = np.empty(self.ngpus + 1, dtype=np.uint64)

@@ -108,7 +108,13 @@ def main():
             assert same(yh, torch.from_numpy(vh).to(device)), f"rank {rank}: halo steps differ"
             torch.cuda.synchronize()
     dist.barrier()
+    # what this rank saw: the communicator's size (RCCL's, not an environment variable) and its device
+    seen = torch.zeros(world, dtype=torch.int64, device=device)
+    seen[rank] = torch.cuda.current_device() + 1
+    dist.all_reduce(seen)
     if rank == 0:
+        print(f"[dist worker] backend {dist.get_backend()}, world {dist.get_world_size()}, devices of the ranks "
+              f"{[int(v) - 1 for v in seen.tolist()]}", flush=True)
         print("dist worker ok", flush=True)
     dist.destroy_process_group()
 

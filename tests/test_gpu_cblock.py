@@ -30,11 +30,11 @@ def random_rows(rng, nrows, ncols, lens, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("rpt", [2, 4, 8, 16])
-def test_forced_geometries_bit_identical(oracle, dtype, rpt):
-    """Every row-block height (512 ... 4096 rows), small column blocks (many tiles, empty tiles, tiles of one entry),
+@pytest.mark.parametrize("rows", [300, 512, 1000, 2048, 3333, 4096])
+def test_forced_geometries_bit_identical(oracle, dtype, rows):
+    """Row-block heights from 300 to 4096 rows (multiples of the workgroup size or not), small column blocks (many tiles, empty tiles, tiles of one entry),
     rows of 0 ... 40 entries, a row count that is no multiple of anything."""
-    rng = np.random.default_rng(100 + rpt)
+    rng = np.random.default_rng(100 + rows)
     nrows, ncols = 70_001, 50_000
     lens = rng.integers(0, 41, nrows)
     lens[rng.random(nrows) < 0.2] = 0                  # empty rows
@@ -46,13 +46,13 @@ def test_forced_geometries_bit_identical(oracle, dtype, rpt):
     ran = 0
     for shift in (10, 13, 16):                         # 49, 7 and 1 column blocks
         dev.set_option("cblock_shift", shift)
-        dev.set_option("cblock_rpt", rpt)
+        dev.set_option("cblock_rows", rows)
         dev.set_option("cblock", 1)
         d = dev.describe()
         if d["kernel"] != "cblock":                   # (a tile above the strip's 4096 entries: this height does not qualify)
             continue
         ran += 1
-        assert d["cblock_rows"] == 256 * rpt and d["cblock_cols"] == 1 << shift, d
+        assert d["cblock_rows"] == rows and d["cblock_cols"] == 1 << shift, d
         y = dev.spmv(x)
         assert np.array_equal(bits(y), bits(y_ref)), (shift, d)
     assert ran >= 1
@@ -83,7 +83,7 @@ def test_uniform_columns_take_the_column_blocked_kernel(oracle, dtype):
     from beyond L2 and builds the tiled copy by itself; the product equals the oracle's bit for bit and agrees with
     the stream kernels' (same order of additions)."""
     import torch
-    n = 1_000_000
+    n = 1_000_000 if dtype == np.float64 else 2_000_000      # x of 8 MB either way (4 MB would sit in an XCD's L2)
     rp, ci, va = synth.banded_csr(n, n, 14, n, synth.matrix_seed(2), dtype=dtype)
     x = synth.vector(n, dtype=dtype)
     y_ref = oracle.csr_spmv(rp, ci, va, x)

@@ -412,8 +412,12 @@ def test_config2_banded_and_uniform(oracle, dtype, window):
     dev = check(oracle, rp, ci, va, x, n)
     d = dev.describe()
     assert d["lds_x"] == (1 if window else 0)
-    assert d["kernel"] == "stream"          # uniform columns: stream tiles, x through L2
+    # banded: stream tiles out of the LDS window; uniform columns: the column-blocked kernel when x is beyond what an
+    # XCD's L2 keeps (f64: 8 MB), else stream tiles with x through L2 (f32: 4 MB)
+    assert d["kernel"] == ("cblock" if (window is None and dtype == np.float64) else "stream"), d
     check(oracle, rp, ci, va, x, n, kernel=1)
+    dev = check(oracle, rp, ci, va, x, n, cblock=0)
+    assert dev.describe()["kernel"] == "stream"          # ... and the stream kernels on request
 
 
 def test_dimension_mismatch_panics():

@@ -162,6 +162,9 @@ def test_dist_worker_rehearsal_two_ranks_on_one_gpu():
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
     assert "dist worker ok" in out.stdout
+    seen = [ln for ln in out.stdout.splitlines() if ln.startswith("[dist worker]")]
+    print("\n".join(seen))                          # the world size and devices the ranks saw
+    assert any("backend gloo, world 2" in ln for ln in seen), out.stdout[-2000:]
 
 
 def test_dist_worker_over_nccl_with_one_rank():
@@ -172,6 +175,9 @@ def test_dist_worker_over_nccl_with_one_rank():
                           os.path.join(ROOT, "tests", "dist_nccl_worker.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
     assert "dist worker ok" in out.stdout
+    seen = [ln for ln in out.stdout.splitlines() if ln.startswith("[dist worker]")]
+    print("\n".join(seen))                          # the RCCL world size and devices the ranks saw
+    assert any(f"world {ngpus}" in ln for ln in seen), out.stdout[-2000:]
 
 
 @pytest.mark.parametrize("transport", ["rccl", "copy"])
@@ -183,6 +189,10 @@ def test_real_gpus(oracle, ngpus, transport):
         a, x = banded(400_000 + 1000 * ngpus, dtype)
         mg = sp.MultiGpuCsr(a, ngpus, transport=transport)
         assert mg.transport == transport
+        # (the first box with several GPUs runs this before any benchmark: say what it saw)
+        print(f"[test_real_gpus] {transport}: {mg.ngpus} GPUs in the communicator, devices {mg.devices}, "
+              f"{np.dtype(dtype).name}, partition {list(mg.partition())}")
+        assert mg.ngpus == ngpus and len(set(mg.devices)) == ngpus
         check_all_paths(mg, a, x, oracle)
         mg.close()
 
@@ -199,3 +209,6 @@ def test_row_partitioned_spmv_over_nccl(ngpus):
                           os.path.join(ROOT, "tests", "dist_nccl_worker.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-4000:] + out.stderr[-4000:]
     assert "dist worker ok" in out.stdout
+    seen = [ln for ln in out.stdout.splitlines() if ln.startswith("[dist worker]")]
+    print("\n".join(seen))                          # the RCCL world size and devices the ranks saw
+    assert any(f"world {ngpus}" in ln for ln in seen), out.stdout[-2000:]

@@ -124,7 +124,7 @@ def ab1():
         times = [[] for _ in variants]
         equal, plans = [None] * len(variants), [None] * len(variants)
         defaults = {"slide": -1, "slide_on": 1, "uniform_rows": 1, "prefetch": 1, "persistent": 0, "nt_store": 0, "diag": 0,
-                    "tiles_per_wave": 4, "rows_per_tile": 0, "persistent_blocks": 0, "slide_run": 0, "panel_on": 1, "panel_pages": 192, "panel_window": 0, "kernel": 0, "skew": -1, "window_pages": 0, "stream_global": 1}
+                    "tiles_per_wave": 4, "rows_per_tile": 0, "persistent_blocks": 0, "slide_run": 0, "panel_on": 1, "panel_pages": 192, "panel_window": 0, "kernel": 0, "skew": -1, "window_pages": 0, "stream_global": 1, "cblock": -1}
         named = {kv.split("=")[0] for v in variants for kv in v.split(",")}
         for r in range(rounds):
             for i, v in enumerate(variants):
@@ -1442,6 +1442,55 @@ def zoo():
 
     if True:  # (was the script's __main__ block)
         main()
+
+
+@lab
+def cblock():
+    """Column-blocked kernel (csr_cblock.hpp): sweep of the row-block height and the column-block width on matrices
+    with uniform-random columns -- `lab.py cblock [nrows] [per_row]` (default 5M x 5M, 10 per row: the shape of the
+    assembled config-5 matrix; 1000000 14 = config 2 with uniform columns).  us per product, stream kernels beside."""
+    import numpy as np
+    import torch
+    import spalinalg_amd as sp
+    import spal_synth as synth
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
+    per_row = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    rp, ci, va = synth.banded_csr(n, n, per_row, n, synth.matrix_seed(2))
+    d = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
+    x = torch.from_numpy(synth.vector(n)).cuda()
+    y = torch.empty_like(x)
+
+    def us(reps=30):
+        for _ in range(5):
+            d.spmv_torch(x, out=y)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            d.spmv_torch(x, out=y)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+    d.set_option("cblock", 0)
+    print(f"{n} x {n}, {per_row} per row, uniform columns: stream kernels {us():7.1f} us", flush=True)
+    ref = y.clone()
+    d.set_option("cblock", -1)
+    d.set_option("cblock_rows", 0)
+    p = d.describe()
+    t = us()
+    print(f"  automatic plan: columns per block {p['cblock_cols']} ({p['cblock_col_blocks']} blocks), rows per block {p['cblock_rows']} "
+          f"({p['cblock_row_blocks']} workgroups): {t:7.1f} us   same bits as the stream kernels: {bool(torch.equal(y, ref))}", flush=True)
+    for shift in (15, 16, 17, 18, 19):
+        for rows in (1024, 2048, 3072, 4096):
+            d.set_option("cblock_shift", shift)
+            d.set_option("cblock_rows", rows)
+            p = d.describe()
+            if p["kernel"] != "cblock":
+                print(f"  columns per block 2^{shift}, rows per block {rows}: does not qualify")
+                continue
+            t = us()
+            print(f"  columns per block 2^{shift} ({p['cblock_col_blocks']} blocks), rows per block {rows} ({p['cblock_row_blocks']} workgroups): "
+                  f"{t:7.1f} us   same bits as the stream kernels: {bool(torch.equal(y, ref))}", flush=True)
 
 
 def main():

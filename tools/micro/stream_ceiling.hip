@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void footprint_chunk(const double *__restri
 // Which second stream does the values array's "class" need?  The chunk-interleaved footprint (C = 64) with parts
 // switched off: MASK bit 0 = the 16-bit columns are read, bit 1 = the row pointers, bit 2 = y is written, bit 3 = the
 // x window is staged.
-template <int MASK>
+template <int MASK, int YMODE = 1>   // YMODE: how y is stored -- 1 plain, 2 non-temporal, 3 agent-scope atomic store (written through), 4 the super-tile's 1024 rows in one burst out of LDS
 __global__ __launch_bounds__(256, 2) void footprint_parts(const double *__restrict__ vals, const uint16_t *__restrict__ col16,
                                                           const uint32_t *__restrict__ rowptr, const double *__restrict__ x,
                                                           double *__restrict__ y, uint32_t nrows, uint32_t nblocks, uint32_t C) {
@@ -168,6 +168,74 @@ __global__ __launch_bounds__(256, 2) void footprint_parts(const double *__restri
         for (int j = 0; j < 7; ++j) {
             v[s][j] = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(vals + e0 + j * 128));
             c[s][j] = (MASK & 1) ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(col16 + e0 + j * 128)) : 0u;
+        }
+        r0v[s] = (MASK & 2) ? rowptr[row + lane] : 0u;
+        r1v[s] = (MASK & 2) ? rowptr[row + lane + 1] : 1u;
+    };
+    load(0, wrow);
+    if (MASK & 8) {
+        u32x4 *d4 = reinterpret_cast<u32x4 *>(smem);
+        const uint32_t c0 = b * 1024 > 2048 ? b * 1024 - 2048 : 0;
+        const u32x4 *s4 = reinterpret_cast<const u32x4 *>(x + min(c0, nrows - 5120));
+        u32x4 r[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) r[k] = s4[threadIdx.x + k * 256];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) d4[threadIdx.x + k * 256] = r[k];
+        __syncthreads();
+    }
+    double keep = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t r0 = wrow + k * 64;
+        if (r0 >= nrows) break;
+        if (k + 1 < 4 && r0 + 64 < nrows) load((k + 1) & 1, r0 + 64);
+        double s = 0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) s += v[k & 1][j].x + v[k & 1][j].y + (double)c[k & 1][j];
+        s += (double)(r1v[k & 1] - r0v[k & 1]);
+        if (MASK & 8) s += reinterpret_cast<const double *>(smem)[(lane * 37 + k) & 4095];
+        if (MASK & 4) {
+            if (r0 + lane < nrows) {
+                if (YMODE == 1) y[r0 + lane] = s;
+                else if (YMODE == 2) __builtin_nontemporal_store(s, y + r0 + lane);
+                else if (YMODE == 3) __hip_atomic_store(y + r0 + lane, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else reinterpret_cast<double *>(smem + 40960)[wave * 256 + k * 64 + lane] = s;
+            }
+        } else keep += s;
+    }
+    if ((MASK & 4) && YMODE == 4) {
+        __syncthreads();
+        const f64x2 *src = reinterpret_cast<const f64x2 *>(smem + 40960);
+        f64x2 *dst = reinterpret_cast<f64x2 *>(y + (size_t)b * 1024);
+        for (uint32_t i = threadIdx.x; i < 512 && (size_t)b * 1024 + i * 2 + 1 < nrows; i += 256) dst[i] = src[i];
+    }
+    if (!(MASK & 4) && keep == 1.2345e300) y[0] = keep;
+}
+
+
+// The footprint with values and 16-bit columns MERGED into one array: per step of 128 entries 1024 bytes of values
+// followed by 256 bytes of columns (one stream instead of two).  MASK as footprint_parts (bit 0 is implied).
+template <int MASK>
+__global__ __launch_bounds__(256, 2) void footprint_merged(const unsigned char *__restrict__ vc, const uint32_t *__restrict__ rowptr,
+                                                           const double *__restrict__ x, double *__restrict__ y, uint32_t nrows,
+                                                           uint32_t nblocks, uint32_t C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t b = ((slot / C) * 8u + xcd) * C + slot % C;
+    if (b >= nblocks) return;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t wrow = b * 1024 + wave * 256;
+    f64x2 v[2][7];
+    uint32_t c[2][7], r0v[2], r1v[2];
+    auto load = [&](int s, uint32_t row) {
+        const size_t e0 = (size_t)row * 14 + lane * 2;            // row * 14 is a multiple of 2; 64 rows = 7 steps
+        const unsigned char *p = vc + (e0 >> 7) * 1280 + (e0 & 127) * 8;
+        const unsigned char *q = vc + (e0 >> 7) * 1280 + 1024 + (e0 & 127) * 2;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            v[s][j] = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(p + j * 1280));
+            c[s][j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(q + j * 1280));
         }
         r0v[s] = (MASK & 2) ? rowptr[row + lane] : 0u;
         r1v[s] = (MASK & 2) ? rowptr[row + lane + 1] : 1u;
@@ -618,10 +686,10 @@ static int map_chunk_main(double gb) {
     return 0;
 }
 
-template <int MASK>
+template <int MASK, int YMODE = 1>
 static double parts_us(const double *vals, const uint16_t *col16, const uint32_t *rowptr, const double *x, double *y, uint32_t nrows) {
     const uint32_t nblocks = (nrows + 1023) / 1024, per_xcd = (nblocks + 7) / 8, C = 64;
-    auto k = footprint_parts<MASK>;
+    auto k = footprint_parts<MASK, YMODE>;
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return time_us([&] { hipLaunchKernelGGL(k, dim3(per_xcd * 8 + 8 * C), dim3(256), 72 * 1024, 0, vals, col16, rowptr, x, y, nrows, nblocks, C); }, 12);
 }
@@ -670,6 +738,14 @@ static int map_parts_main(double gb, int method) {   // method 0 hipMalloc, 1 hi
         CK(hipMalloc(&cs[j], nnz * 2)); CK(hipMemset(cs[j], 1, nnz * 2));
     }
     for (int which : {lo, hi}) {
+        printf("values array %d (%.1f us): the whole footprint with y stored plain / non-temporal / written through (sc1) / 8 KB bursts out of LDS:"
+               " %6.1f %6.1f %6.1f %6.1f   values + y only: %6.1f %6.1f %6.1f %6.1f\n", which, full[which],
+               parts_us<15, 1>(vals[which], col16, rowptr, x, y, nrows), parts_us<15, 2>(vals[which], col16, rowptr, x, y, nrows),
+               parts_us<15, 3>(vals[which], col16, rowptr, x, y, nrows), parts_us<15, 4>(vals[which], col16, rowptr, x, y, nrows),
+               parts_us<4, 1>(vals[which], col16, rowptr, x, y, nrows), parts_us<4, 2>(vals[which], col16, rowptr, x, y, nrows),
+               parts_us<4, 3>(vals[which], col16, rowptr, x, y, nrows), parts_us<4, 4>(vals[which], col16, rowptr, x, y, nrows));
+    }
+    for (int which : {lo, hi}) {
         printf("values array %d (%.1f us): y in 6 other allocations:", which, full[which]);
         for (int j = 0; j < 6; ++j) printf(" %6.1f", parts_us<15>(vals[which], col16, rowptr, x, ys[j], nrows));
         printf("   columns in 6 other allocations:");
@@ -679,7 +755,47 @@ static int map_parts_main(double gb, int method) {   // method 0 hipMalloc, 1 hi
     return 0;
 }
 
+template <int MASK>
+static double merged_us(const unsigned char *vc, const uint32_t *rowptr, const double *x, double *y, uint32_t nrows) {
+    const uint32_t nblocks = (nrows + 1023) / 1024, per_xcd = (nblocks + 7) / 8, C = 64;
+    auto k = footprint_merged<MASK>;
+    CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return time_us([&] { hipLaunchKernelGGL(k, dim3(per_xcd * 8 + 8 * C), dim3(256), 72 * 1024, 0, vc, rowptr, x, y, nrows, nblocks, C); }, 12);
+}
+// --map-merged [gb]: per index a values array (1.12 GB) and, right after it, a merged values + columns array (1.4 GB):
+// values + columns as two streams (columns array fixed) against the one merged stream; and the whole footprint each way
+static int map_merged_main(double gb) {
+    const uint32_t nrows = 10'000'000;
+    const size_t nnz = (size_t)nrows * 14 + 4096;
+    const size_t mbytes = ((nnz + 127) / 128) * 1280;
+    double *x, *y;
+    uint16_t *col16;
+    uint32_t *rowptr;
+    CK(hipMalloc(&col16, nnz * 2)); CK(hipMemset(col16, 1, nnz * 2));
+    CK(hipMalloc(&rowptr, ((size_t)nrows + 65) * 4)); CK(hipMemset(rowptr, 0, ((size_t)nrows + 65) * 4));
+    CK(hipMalloc(&x, (size_t)nrows * 8)); CK(hipMalloc(&y, (size_t)nrows * 8));
+    CK(hipMemset(x, 0, (size_t)nrows * 8));
+    if (gb <= 0) gb = 60;
+    const int K = (int)std::min<double>(gb * 1e9 / (nnz * 8.0 + mbytes), 120.0);
+    std::vector<double *> vals(K, nullptr);
+    std::vector<unsigned char *> vc(K, nullptr);
+    for (int i = 0; i < K; ++i) {
+        CK(hipMalloc(&vals[i], nnz * 8)); CK(hipMemsetAsync(vals[i], 1, nnz * 8, 0));
+        CK(hipMalloc(&vc[i], mbytes)); CK(hipMemsetAsync(vc[i], 1, mbytes, 0));
+    }
+    CK(hipDeviceSynchronize());
+    printf("index  two streams: values + columns | whole footprint   ||  merged stream: values + columns | whole footprint  (us)\n");
+    for (int i = 0; i < K; ++i) {
+        printf("  %3d  %6.1f  %6.1f  ||  %6.1f  %6.1f\n", i, parts_us<1>(vals[i], col16, rowptr, x, y, nrows),
+               parts_us<15>(vals[i], col16, rowptr, x, y, nrows), merged_us<1>(vc[i], rowptr, x, y, nrows),
+               merged_us<15>(vc[i], rowptr, x, y, nrows));
+        fflush(stdout);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && std::string(argv[1]) == "--map-merged") return map_merged_main(argc > 2 ? atof(argv[2]) : 0.0);
     if (argc > 1 && std::string(argv[1]) == "--map-parts") return map_parts_main(argc > 2 ? atof(argv[2]) : 0.0, argc > 3 ? atoi(argv[3]) : 0);
     if (argc > 1 && std::string(argv[1]) == "--map-chunk") return map_chunk_main(argc > 2 ? atof(argv[2]) : 0.0);
     if (argc > 4 && std::string(argv[1]) == "--map-vmm") return map_vmm_main(atoll(argv[2]), atoll(argv[3]), atoll(argv[4]), argc > 5 ? atof(argv[5]) : 0.0);
