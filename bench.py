@@ -82,6 +82,8 @@ def parse():
                     help="--host mg: comma-separated device list; repeats (e.g. 0,0,0,0) put several shards on one "
                          "GPU over the copy transport -- a rehearsal of the multi-GPU path on a 1-GPU box")
     ap.add_argument("--transport", default=None, choices=["rccl", "copy"], help="--host mg: exchange transport")
+    ap.add_argument("--torch-vectors", action="store_true",
+                    help="one GPU: x and y from torch's allocator instead of the handle's placed vectors (spal_csr_alloc_vectors)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run (config 3, banded, f64, one GPU): do not append the compact records of configs "
                          "1, 2, 4, 5 and of config 3 in f32 (child processes of this script, ~40 s)")
@@ -475,7 +477,8 @@ def bench_mg(args):
         "efficiency_inputs": {"total_ms": round(total_ms, 4), "K": args.steps,
                               "note": "total = x_distribution + K * compute + y_collection: recompute for any K"},
         "cpu_baseline": cpu,
-        "setup_s": {"generate": round(t_gen, 2), "validate_narrow_upload_plan": round(t_upload, 2)},
+        "setup_s": {"generate": round(t_gen, 2), "validate_narrow_upload_plan": round(t_upload, 2), "autotune": round(t_autotune, 3),
+                    "place_vectors": round(t_vectors, 3)},
     }
     print(json.dumps(out))
     mg.close()
@@ -627,8 +630,16 @@ def main():
         elif args.exchange == "auto":
             exchange = "halo" if int(agree[1]) else "allgather"
 
-    # ---- x: generated on rank 0, broadcast once over RCCL
-    if rank == 0:
+    # ---- x: generated on rank 0, broadcast once over RCCL.  One GPU: x and y are the handle's own vectors
+    # (spal_csr_alloc_vectors: placed so that the stores of y do not collide with the matrix stream)
+    y_placed = None
+    t_vectors = 0.0
+    if world == 1 and not args.torch_vectors:
+        t0 = time.time()
+        x, y_placed = dev.vectors_torch()
+        t_vectors = time.time() - t0
+        x.copy_(torch.from_numpy(synth.vector(ncols, dtype=np_dt)))
+    elif rank == 0:
         x = torch.from_numpy(synth.vector(ncols, dtype=np_dt)).to(device)
     else:
         x = torch.zeros(ncols, dtype=t_dt, device=device)
@@ -639,7 +650,7 @@ def main():
     op.broadcast_x(x)
     torch.cuda.synchronize()
     x_bcast_ms = (time.perf_counter() - tb) * 1e3 if world > 1 else 0.0
-    y = torch.empty(nrows, dtype=t_dt, device=device)
+    y = y_placed if y_placed is not None else torch.empty(nrows, dtype=t_dt, device=device)
     if exchange == "halo":
         # dry run of one halo step; any rank failing sends everyone to the all-gather
         ok = 1
@@ -697,7 +708,9 @@ def main():
         if int(agree[0]):
             x_mode, y_mode = "scatter_windows", "gather_root"
     # setup: let the library pick between its kernel variants on this device (results are identical)
-    plan = dev.autotune(x, op.y_local[: r1 - r0], iters=30)
+    t0 = time.time()
+    plan = dev.autotune(x, y if world == 1 else op.y_local[: r1 - r0], iters=30)   # (on the vectors the timed steps use)
+    t_autotune = time.time() - t0
     # config 2 on one GPU: 188 MB would be served from the 256 MB Infinity Cache, so the
     # launches rotate over independent copies of (A, x, y); config 3 is 1.9 GB
     copies = args.copies if args.copies > 0 else (3 if (args.config == 2 and world == 1) else 1)
@@ -710,7 +723,11 @@ def main():
         for kv in args.opt:
             k, v = kv.split("=")
             d2.set_option(k, int(v))
-        x2, y2 = x.clone(), torch.empty_like(y)
+        if args.torch_vectors:
+            x2, y2 = x.clone(), torch.empty_like(y)
+        else:
+            x2, y2 = d2.vectors_torch()
+            x2.copy_(x)
         d2.autotune(x2, y2, iters=30)
         keep.append((d2, x2, y2))
         single.append(lambda d2=d2, x2=x2, y2=y2: d2.spmv_torch(x2, out=y2))
@@ -998,7 +1015,7 @@ def main():
         "allgather_every_step": None if allgather_ms is None else {
             "ms_per_step": round(allgather_ms, 6),
             "value": round(synth.spmv_flops(nnz) / (allgather_ms * 1e-3) / 1e9, 3), "unit": "GFLOP/s"},
-        "setup_s": {"generate": round(t_gen, 2), "validate_narrow_upload_plan": round(t_upload, 2)},
+        "setup_s": {"generate": round(t_gen, 2), "validate_narrow_upload_plan": round(t_upload, 2), "autotune": round(t_autotune, 3)},
     }
 
     if world == 1:

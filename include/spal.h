@@ -142,15 +142,29 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value);
 /* Setup-time autotune: runs the planned kernel's variants (the stream kernel
  * with one workgroup per super-tile vs. its walking form -- the sliding-window
  * kernel on band-like plans, else the persistent form -- each with plain or
- * non-temporal y stores) `iters` times each on the caller's device vectors and
- * keeps the fastest; then tries up to "place_tries" fresh allocations for the
- * values array, and after it for the 16-bit column array (identical kernels
- * ran 5-14 % apart depending on the allocation the values live in), and keeps
- * the fastest.  All variants produce identical y.  Synchronises `stream`. */
+ * non-temporal y stores; the column-blocked kernel against the stream kernels
+ * where the plan built both) `iters` times each on the caller's device vectors
+ * and keeps the fastest; then copies the 16-bit column array into up to
+ * "place_tries" (default 8) blocks of 1 GiB taken one after the other from the
+ * device's memory and keeps the place where the kernel ran fastest (two streams
+ * out of one class of region disturb each other).  All variants
+ * produce identical y.  Synchronises `stream`.  Cost at config 3 with
+ * iters = 30: about 0.1 s. */
 int spal_csr_autotune_f64(spal_csr_t a, const double *x_dev, double *y_dev,
                           void *stream, int iters);
 int spal_csr_autotune_f32(spal_csr_t a, const float *x_dev, float *y_dev,
                           void *stream, int iters);
+/* Device vectors x (ncols elements) and y (nrows elements) for products with THIS handle, placed so that the stores
+ * of y do not collide with the matrix stream.  Why: on MI355X the time of a product depends on where y lies in the
+ * device's memory RELATIVE to the matrix arrays (streams out of one class of region disturb each other: +-5 % at
+ * config 3) -- a property of the pair that neither side can fix alone, and `hipMalloc` gives no say.
+ * The call walks the device's memory in blocks of 1 GiB (at most "walk_blocks", default 12; ~3 ms each), times the
+ * handle's kernel into a candidate y in every block, keeps the block of the fastest and frees the rest.  The vectors
+ * belong to the handle (freed by spal_csr_destroy; a second call returns the same pointers); any other device memory
+ * works as x / y too, only possibly slower.  Not for handles above 2^32 - 65537 entries (row blocks): plain
+ * allocations there.  Synchronises `stream`.
+ * Replaces nothing in the reference: its `Vec<T>` has no placement.  Rust shim: `DeviceCsr::vectors()`. */
+int spal_csr_alloc_vectors(spal_csr_t a, void **x_dev, void **y_dev, void *stream);
 /* Writes a one-line JSON description of the active plan into buf: "kernel"
  * ("stream" | "vector"), "index_bits" (16: window-relative columns), the
  * geometry ("rows_per_tile", "rows_per_block", "lanes_per_row", ...),
@@ -158,7 +172,8 @@ int spal_csr_autotune_f32(spal_csr_t a, const float *x_dev, float *y_dev,
  * "overflow_tiles" (tiles left to the overflow kernel), "skew", "persistent",
  * "slide", "ring_pages", "uniform_row_fraction", "nt_store", "autotune_us"
  * (one workgroup per super-tile, walking form, each then with non-temporal y
- * stores), "placement_us" (before / after re-placing the values array). */
+ * stores), "placement_us" (before / after placing the 16-bit columns),
+ * "vectors_walk_us" (fastest / slowest block of spal_csr_alloc_vectors). */
 int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len);
 
 /* ---- CSC: y = A * x (atomic scatter) --------------------------------------

@@ -88,6 +88,15 @@ impl<T: HipScalar> DeviceCsr<T> {
         ffi::check(T::csr_autotune(self.h, x_dev, y_dev, stream, iters as c_int));
     }
 
+    /// Device vectors `(x, y)` of `ncols` / `nrows` elements owned by this handle, placed so that the stores of y do
+    /// not collide with the matrix stream (include/spal.h: spal_csr_alloc_vectors; a second call returns the same
+    /// pointers; freed with the handle).  Setup time: a walk over the device's memory.
+    pub fn vectors(&self, stream: *mut c_void) -> (*mut T, *mut T) {
+        let (mut x, mut y): (*mut c_void, *mut c_void) = (std::ptr::null_mut(), std::ptr::null_mut());
+        unsafe { ffi::check(ffi::spal_csr_alloc_vectors(self.h, &mut x, &mut y, stream)); }
+        (x as *mut T, y as *mut T)
+    }
+
     /// Kernel plan knob (include/spal.h: spal_csr_set_option).
     pub fn set_option(&self, key: &str, value: i64) {
         let k = std::ffi::CString::new(key).expect("option key");

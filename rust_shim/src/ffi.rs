@@ -42,6 +42,7 @@ extern "C" {
     pub fn spal_csr_set_option(a: *mut spal_csr, key: *const c_char, value: i64) -> c_int;
     pub fn spal_csr_autotune_f64(a: *mut spal_csr, x_dev: *const f64, y_dev: *mut f64, stream: *mut c_void, iters: c_int) -> c_int;
     pub fn spal_csr_autotune_f32(a: *mut spal_csr, x_dev: *const f32, y_dev: *mut f32, stream: *mut c_void, iters: c_int) -> c_int;
+    pub fn spal_csr_alloc_vectors(a: *mut spal_csr, x_dev: *mut *mut c_void, y_dev: *mut *mut c_void, stream: *mut c_void) -> c_int;
     pub fn spal_csr_describe(a: *mut spal_csr, buf: *mut c_char, buf_len: usize) -> c_int;
     pub fn spal_csc_create_f64(device: c_int, nrows: u64, ncols: u64, colptr: *const u64, colptr_len: u64, rowind: *const u64, rowind_len: u64, values: *const f64, values_len: u64, out: *mut *mut spal_csc) -> c_int;
     pub fn spal_csc_create_f32(device: c_int, nrows: u64, ncols: u64, colptr: *const u64, colptr_len: u64, rowind: *const u64, rowind_len: u64, values: *const f32, values_len: u64, out: *mut *mut spal_csc) -> c_int;

@@ -1353,6 +1353,7 @@ static void csr_free(spal_csr *a) {
     (void)dev_free(a->d_ovtiles_slide);
     (void)dev_free(a->d_ptiles);
     (void)dev_free(a->d_pwin);
+    if (a->d_vec_block) (void)hipFree(a->d_vec_block);
     cblock_free(a);
     (void)dev_free(a->d_x);
     (void)dev_free(a->d_y);
@@ -1671,41 +1672,45 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
     else p.persistent = best & 1;
     p.user_persistent = true;   // measured: a later re-plan keeps it
     p.nt_store = (best >> 1) & 1;
-    // ---- 2. the placement of the values array (72 % of the bytes), then of the 16-bit columns (18 %)
+    // ---- 2. where the 16-bit columns lie relative to the values (two streams out of one class of region
+    // disturb each other, +12 us at config 3; out of two classes they do not): the columns are copied into blocks of
+    // 1 GiB taken one after the other from the device's memory, the kernel is timed on each, the fastest place is kept
+    // (round 2 re-allocated the 1.1 GB values array up to 12 times and, the candidates lying side by side in one
+    // region, often found nothing).  At most `place_tries` blocks (default 8: ~25 ms).
     int tries = p.place_tries;
     if (const char *e = getenv("SPAL_PLACE_TRIES")) tries = atoi(e);
-    struct Placed { void **ptr; size_t bytes; };
-    const Placed arrays[2] = {{&a->d_values, (size_t)a->cap_entries * (size_t)a->elem_size},
-                              {(void **)&a->d_col16, a->d_col16 ? (size_t)a->cap_entries * sizeof(uint16_t) : 0}};
-    std::vector<void *> rejects;
-    for (int which = 0; which < 2 && rc == SPAL_OK && tries > 0; ++which) {
-        const size_t vbytes = arrays[which].bytes;
-        if (vbytes < ((size_t)64 << 20)) continue;
+    const size_t cbytes = a->d_col16 ? (size_t)a->cap_entries * sizeof(uint16_t) : 0;
+    if (rc == SPAL_OK && tries > 0 && cbytes >= ((size_t)64 << 20)) {
+        const size_t block = std::max<size_t>((size_t)1 << 30, (cbytes + 4095) & ~(size_t)4095);
+        const int n = std::max(4, iters / 4);
         float cur_ms = 0.f;
-        timed(iters, &cur_ms);
-        const float first_ms = cur_ms;
-        if (which == 0) a->place_us[0] = cur_ms * 1e3f;
+        timed(n, &cur_ms);
+        a->place_us[0] = cur_ms * 1e3f;
+        uint16_t *const original = a->d_col16;
+        std::vector<void *> blocks;
+        std::vector<float> ms_of;
         for (int k = 0; k < tries && rc == SPAL_OK; ++k) {
-            void *cand = nullptr;
-            if (dev_alloc(&cand, vbytes) != hipSuccess) { (void)hipGetLastError(); break; }   // out of memory: keep what we have
-            hipError_t e = hipMemcpyAsync(cand, *arrays[which].ptr, vbytes, hipMemcpyDeviceToDevice, st);
-            if (e != hipSuccess) { rejects.push_back(cand); rc = fail(SPAL_ERR_HIP, "spal_csr_autotune: %s", hipGetErrorString(e)); break; }
-            void *old = *arrays[which].ptr;
-            *arrays[which].ptr = cand;
+            void *b = nullptr;
+            if (hipMalloc(&b, block) != hipSuccess) { (void)hipGetLastError(); break; }   // the device is full: what we have
+            blocks.push_back(b);
+            hipError_t e = hipMemcpyAsync(b, original, cbytes, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) { rc = fail(SPAL_ERR_HIP, "spal_csr_autotune: %s", hipGetErrorString(e)); break; }
+            a->d_col16 = (uint16_t *)b;
             float ms = 0.f;
-            timed(iters, &ms);
+            timed(n, &ms);
+            ms_of.push_back(ms);
             ++a->place_tried;
-            if (rc == SPAL_OK && ms < 0.99f * cur_ms) { cur_ms = ms; rejects.push_back(old); }
-            else { *arrays[which].ptr = old; rejects.push_back(cand); }
-            // (classes 5 ... 14 % apart for the values: once an allocation of the faster one is in hand, stop looking;
-            //  the columns are a quarter of that)
-            if (cur_ms < (which == 0 ? 0.96f : 0.99f) * first_ms) break;
         }
-        a->place_us[1] = cur_ms * 1e3f;
+        int best = -1;
+        for (size_t k = 0; k < ms_of.size(); ++k)
+            if (ms_of[k] < 0.99f * cur_ms && (best < 0 || ms_of[k] < ms_of[(size_t)best])) best = (int)k;
+        (void)hipStreamSynchronize(st);
+        a->d_col16 = best >= 0 ? (uint16_t *)blocks[(size_t)best] : original;
+        for (size_t k = 0; k < blocks.size(); ++k)
+            if ((int)k != best) (void)hipFree(blocks[k]);
+        if (best >= 0) (void)dev_free(original);
+        a->place_us[1] = (best >= 0 ? ms_of[(size_t)best] : cur_ms) * 1e3f;
     }
-    // the rejected blocks are released only now, so that no try was handed one of them again
-    (void)hipStreamSynchronize(st);
-    for (void *r : rejects) (void)dev_free(r);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return rc;
@@ -1906,6 +1911,11 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
 #else
         return fail(SPAL_ERR_INVALID_ARGUMENT, "diag: this library is not an ablation build (-DSPAL_DIAG)");
 #endif
+    } else if (!strcmp(key, "walk_blocks")) {
+        // spal_csr_alloc_vectors: blocks of 1 GiB the placement walk probes at most (1 = the first block, no search)
+        if (value < 1 || value > 128) return fail(SPAL_ERR_INVALID_ARGUMENT, "walk_blocks must be in [1, 128]");
+        a->walk_max = (int)value;
+        return SPAL_OK;
     } else if (!strcmp(key, "xcd_chunk")) {
         // one-super-tile stream kernel: super-tiles dealt to the 8 XCDs in chunks of this many (0 = one contiguous run per XCD)
         if (value < 0 || value > 4096) return fail(SPAL_ERR_INVALID_ARGUMENT, "xcd_chunk must be in [0, 4096]");
@@ -1934,6 +1944,74 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
     int st = csr_plan_build(a);
     if (st != SPAL_OK) { a->plan = saved; (void)csr_plan_build(a); }
     return st;
+}
+
+int spal_csr_alloc_vectors(spal_csr_t a, void **x_dev, void **y_dev, void *stream) {
+    if (!a || !x_dev || !y_dev) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_alloc_vectors: null argument");
+    DeviceGuard guard(a->device);
+    if (guard.status != SPAL_OK) return guard.status;
+    std::lock_guard<std::mutex> lock(a->mu);
+    const size_t es = (size_t)a->elem_size;
+    auto up = [](size_t v) { return (v + 4095) & ~(size_t)4095; };
+    const size_t xb = up(std::max<uint64_t>(a->ncols, 1) * es), yb = up(std::max<uint64_t>(a->nrows, 1) * es);
+    if (a->d_vec_block) {
+        *x_dev = (char *)a->d_vec_block + a->vec_x_off;
+        *y_dev = (char *)a->d_vec_block + a->vec_y_off;
+        return SPAL_OK;
+    }
+    const size_t block = std::max<size_t>((size_t)1 << 30, up(xb + yb));
+    hipStream_t st = (hipStream_t)stream;
+    // small products, empty matrices, row-block handles: nothing to place
+    const bool walk = a->parts.empty() && a->nnz != 0 && (size_t)a->nnz * (es + 2) >= ((size_t)256 << 20) && a->walk_max > 1;
+    std::vector<void *> blocks;
+    std::vector<float> us;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = SPAL_OK;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    const int nmax = walk ? a->walk_max : 1;
+    for (int k = 0; k < nmax && e == hipSuccess && rc == SPAL_OK; ++k) {
+        void *b = nullptr;
+        if (hipMalloc(&b, block) != hipSuccess) { (void)hipGetLastError(); break; }   // the device is full: what we have
+        blocks.push_back(b);
+        e = hipMemsetAsync(b, 0, xb + yb, st);      // x = 0 for the probes: the time of a product does not depend on the values
+        if (!walk) { us.push_back(0.f); break; }
+        void *xc = b, *yc = (char *)b + xb;
+        for (int i = 0; i < 3 && rc == SPAL_OK; ++i) rc = csr_launch(a, xc, yc, st);
+        if (e == hipSuccess) e = hipEventRecord(e0, st);
+        const int n = 8;
+        for (int i = 0; i < n && rc == SPAL_OK; ++i) rc = csr_launch(a, xc, yc, st);
+        if (e == hipSuccess) e = hipEventRecord(e1, st);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        us.push_back(ms * 1e3f / (float)n);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    size_t best = 0;
+    for (size_t k = 1; k < us.size(); ++k) if (us[k] < us[best]) best = k;
+    const bool ok = e == hipSuccess && rc == SPAL_OK && !blocks.empty() && us.size() == blocks.size();
+    for (size_t k = 0; k < blocks.size(); ++k)
+        if (!ok || k != best) (void)hipFree(blocks[k]);
+    if (rc != SPAL_OK) return rc;
+    if (!ok) return fail(e == hipSuccess ? SPAL_ERR_OUT_OF_MEMORY : SPAL_ERR_HIP, "spal_csr_alloc_vectors: %s",
+                         e == hipSuccess ? "no device memory for the vectors" : hipGetErrorString(e));
+    a->d_vec_block = blocks[best];
+    a->vec_x_off = 0;
+    a->vec_y_off = xb;
+    a->walk_blocks = (int)blocks.size();
+    a->walk_us[0] = us[best];
+    a->walk_us[1] = *std::max_element(us.begin(), us.end());
+    if (getenv("SPAL_WALK_DEBUG")) {
+        fprintf(stderr, "[spal walk] us per product by block:");
+        for (float t : us) fprintf(stderr, " %.1f", t);
+        fprintf(stderr, "  -> block %zu\n", best);
+    }
+    *x_dev = (char *)a->d_vec_block + a->vec_x_off;
+    *y_dev = (char *)a->d_vec_block + a->vec_y_off;
+    return SPAL_OK;
 }
 
 int spal_csr_autotune_f64(spal_csr_t a, const double *x_dev, double *y_dev, void *stream, int iters) {
@@ -1966,6 +2044,7 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f, "
              "\"overflow_tiles\": %u, \"skew\": %d, \"persistent\": %d, \"nt_store\": %d, \"uniform_row_fraction\": %.4f, "
              "\"prefetch\": %d, \"slide\": %d, \"ring_pages\": %d, \"tile_steps\": %d, \"split_tiles\": %u, \"panel_tiles\": %u, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f], \"placement_us\": [%.1f, %.1f], \"placement_tries\": %d, \"addr\": [\"%llx\", \"%llx\", \"%llx\"], "
+             "\"vectors_walk_us\": [%.1f, %.1f], \"vectors_walk_blocks\": %d, "
              "\"nonlocal_row_fraction\": %.4f, \"cblock\": %d, \"cblock_pending\": %d, \"cblock_rows\": %d, \"cblock_cols\": %llu, \"cblock_col_blocks\": %d, \"cblock_row_blocks\": %u, \"cblock_us\": [%.1f, %.1f]}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, (p.kernel == 2 || p.vec_col16) ? 16 : 32,
@@ -1985,6 +2064,7 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              (double)a->tuned_us[2], (double)a->tuned_us[3], (double)a->place_us[0], (double)a->place_us[1],
              a->place_tried, (unsigned long long)(uintptr_t)a->d_values,
              (unsigned long long)(uintptr_t)a->d_col16, (unsigned long long)(uintptr_t)a->d_rowptr,
+             (double)a->walk_us[0], (double)a->walk_us[1], a->walk_blocks,
              p.kernel == 2 ? p.nonlocal_row_fraction : 0.0, (p.cblock && p.cblock_on) ? 1 : 0, p.cblock_pending, p.cblock ? p.cblock_rows : 0,
              p.cblock ? (1ull << p.cblock_shift) : 0ull, p.cblock ? p.cblock_nbc : 0, p.cblock ? p.cblock_nrb : 0u,
              (double)a->cblock_us[0], (double)a->cblock_us[1]);

@@ -143,7 +143,7 @@ struct CsrPlan {
     double nonlocal_row_fraction = 0.0;   // rows of super-tiles that gather x from global memory over a span no panel holds
     int slide_S = 0;         // 128-entry steps of the largest streamed tile: every tile issues that many loads
     int slide_uniform = 0;   // 1 + the length of every row when all streamed rows have one length (rowptr is not read), else 0
-    int place_tries = 6;     // autotune: fresh allocations tried for the values array, at most (see csr_autotune)
+    int place_tries = 8;     // autotune: blocks of 1 GiB the 16-bit columns are tried in, at most (see csr_autotune)
     int split_tiles_on = 1;  // sliding kernel: tiles above 1024 entries whose halves fit go through the strip twice
     int diag = 0;            // ablation builds (-DSPAL_DIAG) only: parts of the stream kernel switched off
     int persistent_blocks = 0;    // its grid; 0 = what the device holds at once (LDS per workgroup decides: f64 band 512)
@@ -198,6 +198,12 @@ struct spal_csr {
     uint16_t *d_cb_row = nullptr;  // row of every entry inside its row block
     float cblock_us[2] = {0.f, 0.f};   // autotune: per launch {stream kernels, column-blocked kernel}
     int cblock_lazy = 0;           // build the tiled copy with the first product, not with the plan (csr_adopt_device)
+    // spal_csr_alloc_vectors: the block of 1 GiB (or more) that holds the caller's x and y, found by the placement walk
+    void *d_vec_block = nullptr;
+    size_t vec_x_off = 0, vec_y_off = 0;
+    float walk_us[2] = {0.f, 0.f};     // fastest / slowest candidate of the walk (per product)
+    int walk_blocks = 0;               // blocks probed
+    int walk_max = 12;                 // option "walk_blocks"
     std::mutex mu_cb;
     // autotune: microseconds per launch of {plain, persistent} x {plain, non-temporal y stores}
     float tuned_us[4] = {0.f, 0.f, 0.f, 0.f};

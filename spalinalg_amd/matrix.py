@@ -113,6 +113,28 @@ class _DeviceMatrix:
         """Device pointers; enqueued on `stream`, not synchronised."""
         check(self._fn(f"spmv_dev_{_sfx(self.dtype)}")(self._h, vp(x_ptr), vp(y_ptr), _stream_ptr(stream)))
 
+    def alloc_vectors(self, stream=None):
+        """Device pointers (x, y) of vectors owned by this handle and placed so that the stores of y do not collide
+        with the matrix stream (spal_csr_alloc_vectors: a walk over the device's memory, setup time).  CSR handles."""
+        x, y = vp(), vp()
+        check(_ffi.lib().spal_csr_alloc_vectors(self._h, C.byref(x), C.byref(y), _stream_ptr(stream)))
+        return x.value, y.value
+
+    def vectors_torch(self):
+        """alloc_vectors() as torch tensors (zero-copy views of the handle's block; they keep the handle alive)."""
+        import torch
+        nrows, ncols, _ = self.shape()
+        xp, yp = self.alloc_vectors(torch.cuda.current_stream(self.device))
+
+        class _View:
+            def __init__(self, owner, ptr, n, dtype):
+                self._owner = owner
+                self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": np.dtype(dtype).str, "data": (int(ptr), False),
+                                                 "version": 2, "strides": None}
+        dev = torch.device("cuda", self.device)
+        return (torch.as_tensor(_View(self, xp, ncols, self.dtype), device=dev),
+                torch.as_tensor(_View(self, yp, nrows, self.dtype), device=dev))
+
     def autotune(self, x, y, iters: int = 30) -> dict:
         """Times the plan's kernel variants on torch device vectors x, y and keeps
         the fastest (setup-time; synchronises the current stream)."""

@@ -1063,3 +1063,37 @@ def test_sliding_kernel_takes_oversized_tiles_in_halves(oracle, dtype):
     tiles = set((differ // 64).tolist())
     assert tiles <= set((heavy // 64).tolist())     # only rows of the tiles with a long row may differ (tree sums)
     dev.close()
+
+
+def test_handle_owned_vectors(oracle):
+    """spal_csr_alloc_vectors: x / y owned by the handle (for matrices of 256 MB and more the block is the fastest of a
+    walk over the device's memory; small ones take the first block), usable as any device vectors, stable across calls."""
+    import torch
+    n = 200_000
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, 3)
+    dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
+    x, y = dev.vectors_torch()
+    assert x.numel() == n and y.numel() == n and x.is_cuda and x.dtype == torch.float64
+    x2, y2 = dev.vectors_torch()
+    assert x2.data_ptr() == x.data_ptr() and y2.data_ptr() == y.data_ptr()
+    xh = synth.vector(n)
+    x.copy_(torch.from_numpy(xh))
+    y.fill_(float("nan"))
+    dev.spmv_torch(x, out=y)
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), oracle.csr_spmv(rp, ci, va, xh))
+    d = dev.describe()
+    assert d["vectors_walk_blocks"] == 1          # 2.8 MB of matrix: nothing to place
+    # a matrix large enough for the walk (330 MB): several blocks probed, the fastest kept
+    n = 2_000_000
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, 4)
+    dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
+    dev.set_option("walk_blocks", 4)
+    x, y = dev.vectors_torch()
+    d = dev.describe()
+    assert d["vectors_walk_blocks"] == 4 and 0 < d["vectors_walk_us"][0] <= d["vectors_walk_us"][1], d
+    xh = synth.vector(n)
+    x.copy_(torch.from_numpy(xh))
+    dev.spmv_torch(x, out=y)
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), oracle.csr_spmv(rp, ci, va, xh))
