@@ -590,28 +590,18 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
 
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
-    // The group this workgroup takes: its ticket (start order), not its blockIdx (see group_lookback).  The ticket is
-    // one more dependent round trip in every workgroup's life (ticket -> the group's offsets -> its entries): taken
-    // plainly it cost 0.11 of 1.80 ms per assembly at config 5.  Tickets stray from blockIdx by a hundred or so
-    // (tools/micro/ticket.hip: mean 112 at 7 workgroups per CU), so the offsets of the groups blockIdx - 512 ...
-    // blockIdx + 512 are fetched into LDS WHILE the atomic travels; a ticket outside that window reads its two
-    // offsets from memory as before.  (Several groups per ticket would serialise the launch: a workgroup's first
-    // group waits for the LAST group of the workgroup before it, which that one reaches only after its others.)
-    constexpr uint32_t kWinHalf = 512;
-    uint32_t *s_win = reinterpret_cast<uint32_t *>(s_region);            // 2 * kWinHalf + 1 offsets (dead before the sort starts)
-    static_assert(kRegion >= (2 * kWinHalf + 2) * sizeof(uint32_t), "the offset window fits the region");
-    const uint32_t wbase = blockIdx.x > kWinHalf ? blockIdx.x - kWinHalf : 0u;
+    // The group this workgroup takes: its ticket (start order), not its blockIdx (see group_lookback).  One atomic on
+    // one address per workgroup: the unit that serves it sustains 87 M/s (tools/micro/ticket.hip), the launch asks for
+    // 65 M/s -- the tickets cost this kernel 0.13 of 0.63 ms (profiles/r03/coo_assembly.txt).  Neither prefetching the
+    // groups' offsets around blockIdx while the atomic travels (no change: the wait is the queue at the atomic unit,
+    // not one more round trip) nor several groups per ticket (the launch serialises: a workgroup's first group waits
+    // for the LAST group of the workgroup before it) recovers it; a counter per blockIdx & 7 would (72 us per 39 063
+    // tickets) but needs a dispatcher that never starves a residue class -- an assumption again.
     if (t == 0) s_base = ticket ? atomicAdd(ticket, 1u) : blockIdx.x;
-    if (ticket) {
-#pragma unroll
-        for (uint32_t i = t; i < 2 * kWinHalf + 1; i += 256) s_win[i] = gstart[min(wbase + i, ngroups)];
-    }
     __syncthreads();
     const uint32_t grp = s_base;                          // < ngroups (ngroups workgroups, one ticket each)
-    uint32_t e0, e1;
-    if (ticket && grp >= wbase && grp - wbase < 2 * kWinHalf) { e0 = s_win[grp - wbase]; e1 = s_win[grp - wbase + 1]; }
-    else { e0 = gstart[grp]; e1 = gstart[grp + 1]; }
-    __syncthreads();                                      // (s_base and the region are written again below)
+    const uint32_t e0 = gstart[grp], e1 = gstart[grp + 1];
+    __syncthreads();                                      // (s_base is written again below)
     const uint32_t r0 = grp << gbits;                     // < nrows (there are ceil(nrows / 2^gbits) groups)
     const uint32_t nr = min(1u << gbits, nrows - r0);     // rows of this group, <= 256
     uint32_t n = e1 - e0;

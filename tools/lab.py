@@ -1493,6 +1493,49 @@ def cblock():
                   f"{t:7.1f} us   same bits as the stream kernels: {bool(torch.equal(y, ref))}", flush=True)
 
 
+@lab
+def csc_ypairs():
+    """Config 4 (CSC scatter kernel), ONE handle: the product into 12 different allocations of y (1 GiB of other
+    allocations between them) and with 6 allocations of x -- does the pair (matrix arrays, y) matter at this size too?"""
+    import numpy as np
+    import scipy.sparse as sps
+    import torch
+    import spalinalg_amd as sp
+    import spal_synth as synth
+    cfg = synth.CONFIGS[4]
+    n, per_row = cfg["nrows"], cfg["per_row"]
+    rp, ci, va = synth.banded_csr(n, n, per_row, cfg["window"], synth.matrix_seed(2))
+    csc = sps.csr_matrix((va, ci.astype(np.int64), rp.astype(np.int64)), shape=(n, n)).tocsc()
+    csc.sort_indices()
+    d = sp.CscMatrix(n, n, csc.indptr.astype(np.uint64), csc.indices.astype(np.uint64), csc.data).device()
+    d.set_option("kernel", 1)
+    xh = torch.from_numpy(synth.vector(n))
+    spacers, ys, xs = [], [], []
+    for _ in range(12):
+        ys.append(torch.empty(n, dtype=torch.float64, device="cuda"))
+        spacers.append(torch.empty(1 << 30, dtype=torch.uint8, device="cuda"))
+    for _ in range(6):
+        xs.append(xh.cuda())
+        spacers.append(torch.empty(1 << 30, dtype=torch.uint8, device="cuda"))
+    flush = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")     # 512 MB through the caches between products
+
+    def us(xx, yy, reps=30):
+        tot = 0.0
+        for i in range(reps + 3):
+            flush.add_(1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            d.spmv_torch(xx, out=yy)
+            e1.record()
+            torch.cuda.synchronize()
+            if i >= 3:
+                tot += e0.elapsed_time(e1)
+        return tot / reps * 1e3
+    print("y allocation:   " + "".join(f"{i:7d}" for i in range(len(ys))))
+    print("scatter kernel: " + "".join(f"{us(xs[0], y):7.1f}" for y in ys))
+    print("x allocation:   " + "".join(f"{us(xx, ys[0]):7.1f}" for xx in xs))
+
+
 def main():
     if len(sys.argv) < 2 or sys.argv[1] in ("--list", "-h", "--help") or sys.argv[1] not in LABS:
         for name, fn in sorted(LABS.items()):

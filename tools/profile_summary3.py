@@ -63,8 +63,8 @@ def main():
         steps, warm = d["steps"], d["warmup"]
         kept = d["roofline"]["kernel"]
         mine = [t for n, t in seq if n == kept]
-        tail = mine[-(warm + steps + 3 + steps):]
-        timed, after = tail[warm:warm + steps], tail[warm + steps:]
+        tail = mine[-(warm + steps):]          # (at N = 1 the timed region's launches are the process's last of this kernel)
+        timed, after = tail[warm:], []
         plan = d["config"]["plan"]
         B = d["roofline"]["algorithmic_bytes_per_launch"]
         txt = (f"# per-launch durations from rocprofv3 --kernel-trace of: python3 bench.py {'--dtype f32 ' if label == 'f32' else ''}--steps {steps} --warmup {warm} --no-cpu-baseline --no-ceiling --no-other-configs\n"
@@ -73,7 +73,7 @@ def main():
                f"  -> {B} algorithmic bytes / mean = {B / mean(timed) / 1e3:.1f} GB/s = {B / mean(timed) / 1e3 / 8000:.4f} of 8 TB/s\n"
                f"bench.py's HIP events on the same launches: {d['ms_per_step'] * 1e3:.2f} us = {d['value']:.1f} GFLOP/s, roofline.frac {d['roofline']['frac']}"
                f" (algorithmic bytes), moved_frac {d['roofline'].get('moved_frac')}\n"
-               f"kernel alone after it ({len(after)} launches): mean {mean(after):.2f} us\n")
+               f"(the launches before it: autotune -- both forms, two rounds -- the placement walks, {warm} warm-up)\n")
         for n in sorted({n for n, _ in seq}):
             v = [t for m, t in seq if m == n]
             txt += f"all launches of {n}: {len(v)}, mean {mean(v):.2f} us, min {min(v):.2f}\n"
