@@ -1959,12 +1959,12 @@ int spal_csr_alloc_vectors(spal_csr_t a, void **x_dev, void **y_dev, void *strea
         *y_dev = (char *)a->d_vec_block + a->vec_y_off;
         return SPAL_OK;
     }
-    const size_t block = std::max<size_t>((size_t)1 << 30, up(xb + yb));
     hipStream_t st = (hipStream_t)stream;
     // small products, empty matrices, row-block handles: nothing to place
     size_t walk_min = (size_t)256 << 20;    // matrices the caches do not hold
     if (const char *e = getenv("SPAL_WALK_MIN_BYTES")) walk_min = (size_t)strtoull(e, nullptr, 10);
     const bool walk = a->parts.empty() && a->nnz != 0 && (size_t)a->nnz * (es + 2) >= walk_min && a->walk_max > 1;
+    const size_t block = walk ? std::max<size_t>((size_t)1 << 30, up(xb + yb)) : up(xb + yb);   // (1 GiB: the stride of the walk)
     std::vector<void *> blocks;
     std::vector<float> us;
     hipEvent_t e0 = nullptr, e1 = nullptr;

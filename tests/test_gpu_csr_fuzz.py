@@ -87,3 +87,14 @@ def test_random_matrices_all_planner_paths(oracle, seed):
         dev.set_option("kernel", 2)      # the stream kernel on whatever this is
         assert dev.describe()["kernel"] == "stream"
         assert_spmv_close(dev.spmv(x), y_ref, bound, TOL[va.dtype])
+        # ... and the column-blocked kernel forced on whatever this is (random row-block height and column-block width):
+        # where the matrix qualifies (no row with more than 255 entries in one column block, every tile inside the strip)
+        # its rows must equal the oracle's BIT FOR BIT, heavy rows, empty stretches and all
+        dev.set_option("cblock_rows", int(rng.choice([0, 256, 700, 1024, 3000, 4096])))
+        dev.set_option("cblock_shift", int(rng.choice([0, 8, 11, 14, 17])))
+        dev.set_option("cblock", 1)
+        if dev.describe()["kernel"] == "cblock":
+            bits = np.uint64 if dtype == np.float64 else np.uint32
+            assert np.array_equal(dev.spmv(x).view(bits), y_ref.view(bits)), dev.describe()
+        else:
+            assert_spmv_close(dev.spmv(x), y_ref, bound, TOL[va.dtype])
