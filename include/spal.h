@@ -158,7 +158,8 @@ int spal_csr_autotune_f32(spal_csr_t a, const float *x_dev, float *y_dev,
  * of y do not collide with the matrix stream.  Why: on MI355X the time of a product depends on where y lies in the
  * device's memory RELATIVE to the matrix arrays (streams out of one class of region disturb each other: +-5 % at
  * config 3) -- a property of the pair that neither side can fix alone, and `hipMalloc` gives no say.
- * The call walks the device's memory in blocks of 1 GiB (at most "walk_blocks", default 12; ~3 ms each), times the
+ * The call walks the device's memory in blocks of 1 GiB ("walk_blocks", default 12, up to three times as many while all
+ * candidates so far ran alike; ~3 ms each), times the
  * handle's kernel into a candidate y in every block, keeps the block of the fastest and frees the rest.  The vectors
  * belong to the handle (freed by spal_csr_destroy; a second call returns the same pointers); any other device memory
  * works as x / y too, only possibly slower.  Not for handles above 2^32 - 65537 entries (row blocks): plain

@@ -1091,7 +1091,7 @@ def test_handle_owned_vectors(oracle):
     dev.set_option("walk_blocks", 4)
     x, y = dev.vectors_torch()
     d = dev.describe()
-    assert d["vectors_walk_blocks"] == 4 and 0 < d["vectors_walk_us"][0] <= d["vectors_walk_us"][1], d
+    assert 4 <= d["vectors_walk_blocks"] <= 12 and 0 < d["vectors_walk_us"][0] <= d["vectors_walk_us"][1], d   # (4, or more while all ran alike)
     xh = synth.vector(n)
     x.copy_(torch.from_numpy(xh))
     dev.spmv_torch(x, out=y)

@@ -11,6 +11,8 @@ run stats3 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats3 -o 
 run fetch3 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/fetch3 -o b -- python3 bench.py --steps 20 --warmup 5 $B
 run write3 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/write3 -o b -- python3 bench.py --steps 20 --warmup 5 $B
 run stats3f32 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats3f32 -o b -- python3 bench.py --dtype f32 --steps 100 --warmup 10 $B
+run fetch3f32 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/fetch3f32 -o b -- python3 bench.py --dtype f32 --steps 20 --warmup 5 $B
+run write3f32 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/write3f32 -o b -- python3 bench.py --dtype f32 --steps 20 --warmup 5 $B
 run stats2 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats2 -o b -- python3 bench.py --config 2 --steps 100 --warmup 10 $B
 run fetch2 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/fetch2 -o b -- python3 bench.py --config 2 --steps 20 --warmup 5 $B --copies 1
 run write2 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $P/write2 -o b -- python3 bench.py --config 2 --steps 20 --warmup 5 $B --copies 1

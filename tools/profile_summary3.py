@@ -92,6 +92,7 @@ def main():
                 f"WRITE_SIZE {wr / 1e6:9.2f} MB written\n=> {key}: {(rd + wr) / 1e6:.1f} MB per launch")
     t = []
     for tag, key, note in (("3", "config3_banded_f64_n1", "bench.py (config 3)"),
+                           ("3f32", "config3_banded_f32_n1", "bench.py --dtype f32 (config 3)"),
                            ("2", "config2_banded_f64_n1", "bench.py --config 2 --copies 1 (188 MB working set: the Infinity Cache serves part of it)"),
                            ("2u", "config2_uniform_f64_n1", "bench.py --config 2 --dist uniform --copies 1"),
                            ("4", "config4_scatter_f64", "bench.py --config 4 --copies 1")):
