@@ -1586,10 +1586,9 @@ static int csr_download(spal_csr_t a, uint64_t *rowptr, uint64_t *colind, T *val
 // work: it synchronises `stream`.
 //  1. form: one super-tile per workgroup, or the walking form -- the sliding-window kernel when the plan has
 //     it (bands), else the persistent form -- each with plain or non-temporal y stores;
-//  2. placement: the same kernel reading the same bytes ran in two classes 5 ... 14 % apart depending on
-//     WHICH allocation the values array (three quarters of the traffic) lives in -- not on its address
-//     bits, its offset, the other arrays or the XCD run length (profiles/r02/placement_*.txt).  Up to
-//     `place_tries` fresh allocations are tried for it and the fastest is kept.
+//  2. placement of the 16-bit columns relative to the values (two streams out of one class of region of the device's
+//     memory disturb each other): the columns are tried in up to `place_tries` blocks of 1 GiB taken one
+//     after the other from the device's memory; the fastest place is kept.
 template <typename T>
 static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, int iters) {
     if (!a) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_autotune: handle is NULL");
@@ -1893,7 +1892,7 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "split_tiles must be 0 or 1");
         p.split_tiles_on = (int)value;
     } else if (!strcmp(key, "place_tries")) {
-        // autotune: fresh allocations tried for the values array (0 = leave it where it is)
+        // autotune: blocks of 1 GiB the 16-bit columns are tried in (0 = leave them where they are)
         if (value < 0 || value > 16) return fail(SPAL_ERR_INVALID_ARGUMENT, "place_tries must be in [0, 16]");
         p.place_tries = (int)value;
     } else if (!strcmp(key, "uniform_rows")) {
