@@ -1536,6 +1536,25 @@ def csc_ypairs():
     print("x allocation:   " + "".join(f"{us(xx, ys[0]):7.1f}" for xx in xs))
 
 
+@lab
+def cblock_once():
+    """The column-blocked kernel's automatic plan on a uniform-column matrix, 30 products (for counter passes):
+    `lab.py cblock_once [nrows] [per_row]`."""
+    import torch
+    import spalinalg_amd as sp
+    import spal_synth as synth
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
+    per_row = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    rp, ci, va = synth.banded_csr(n, n, per_row, n, synth.matrix_seed(2))
+    d = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
+    x = torch.from_numpy(synth.vector(n)).cuda()
+    y = torch.empty_like(x)
+    for _ in range(30):
+        d.spmv_torch(x, out=y)
+    torch.cuda.synchronize()
+    print(d.describe())
+
+
 def main():
     if len(sys.argv) < 2 or sys.argv[1] in ("--list", "-h", "--help") or sys.argv[1] not in LABS:
         for name, fn in sorted(LABS.items()):
