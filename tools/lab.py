@@ -1480,8 +1480,10 @@ def cblock():
     t = us()
     print(f"  automatic plan: columns per block {p['cblock_cols']} ({p['cblock_col_blocks']} blocks), rows per block {p['cblock_rows']} "
           f"({p['cblock_row_blocks']} workgroups): {t:7.1f} us   same bits as the stream kernels: {bool(torch.equal(y, ref))}", flush=True)
-    for shift in (15, 16, 17, 18, 19):
-        for rows in (1024, 2048, 3072, 4096):
+    shifts = [int(v) for v in os.environ.get("LAB_SHIFTS", "15,16,17,18,19").split(",")]
+    heights = [int(v) for v in os.environ.get("LAB_ROWS", "1024,2048,3072,4096").split(",")]
+    for shift in shifts:
+        for rows in heights:
             d.set_option("cblock_shift", shift)
             d.set_option("cblock_rows", rows)
             p = d.describe()
@@ -1489,7 +1491,7 @@ def cblock():
                 print(f"  columns per block 2^{shift}, rows per block {rows}: does not qualify")
                 continue
             t = us()
-            print(f"  columns per block 2^{shift} ({p['cblock_col_blocks']} blocks), rows per block {rows} ({p['cblock_row_blocks']} workgroups): "
+            print(f"  columns per block 2^{shift} ({p['cblock_col_blocks']} blocks), rows per block {rows} ({p['cblock_row_blocks']} workgroups, strip {p.get('cblock_strip')}): "
                   f"{t:7.1f} us   same bits as the stream kernels: {bool(torch.equal(y, ref))}", flush=True)
 
 
