@@ -15,6 +15,9 @@
 // the reference's order (src/csr/ops/mul.rs:31-38) -- rows are bit-identical to the sequential CPU result.
 // (The running sums start at -0.0: -0.0 + p == p bit for bit for every p, which makes "add" the reference's
 //  "assign" for the first product; rows without entries store +0.0.)
+// Two kernels share the tiled copy: csr_spmv_cblock (entry-parallel, runs of about one entry per row and column
+// block) and csr_spmv_cblock_rows (threads own rows: runs of several entries); the plan counts the runs and chooses
+// (spal_csr_cblock.hip).
 #pragma once
 #include "csr_kernels.hpp"
 
@@ -119,6 +122,122 @@ __global__ __launch_bounds__(kCbThreads) void csr_spmv_cblock(const T *__restric
     }
 }
 
+// ---- the rows form: rows that hold SEVERAL entries per column block --------------------------------------------------
+// (14 per row over 8 column blocks, wide bands.)  The entry-parallel kernel above lets the thread that heads a row's run
+// add the whole run while the run's other threads idle, and pays six LDS accesses per entry to find the heads; here
+// thread t OWNS the RPT consecutive rows t * RPT ... of the row block: their running sums live in its registers from
+// the first column block to the last, the rows' entry counts in the tile (one byte per row and column block: cnt8, one
+// vector load per thread) give, by a block scan, where its products start in the strip, and it adds them one after the
+// other -- the same order, so the same bits.  Same tiled copy (values, columns, tile_ptr); cnt8 instead of rows16.
+template <int RPT> struct CbCounts;      // RPT bytes as one vector
+template <> struct CbCounts<16> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+template <> struct CbCounts<8> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct CbCounts<4> { typedef uint32_t type; };
+template <> struct CbCounts<2> { typedef uint16_t type; };
+template <> struct CbCounts<1> { typedef uint8_t type; };
+
+template <int RPT>
+__device__ __forceinline__ void cb_unpack(const typename CbCounts<RPT>::type &v, uint32_t (&c)[RPT]) {
+    if constexpr (RPT >= 8) {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) c[r] = (v[r >> 2] >> (8 * (r & 3))) & 0xffu;
+    } else {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) c[r] = ((uint32_t)v >> (8 * r)) & 0xffu;
+    }
+}
+
+// cnt8[(rb * nbc + cb) * RB + r] = entries of row r of the row block in column block cb (<= 255, checked by the plan);
+// RB = 256 * RPT; every tile holds at most kCbStrip entries (plan).
+template <typename T, int RPT, int U>
+__global__ __launch_bounds__(kCbThreads) void csr_spmv_cblock_rows(const T *__restrict__ vals, const uint32_t *__restrict__ cols,
+                                                                   const uint32_t *__restrict__ tile_ptr,
+                                                                   const uint8_t *__restrict__ cnt8, const T *__restrict__ x,
+                                                                   T *__restrict__ y, uint32_t nrows, uint32_t nbc) {
+    constexpr uint32_t RB = kCbThreads * RPT;
+    __shared__ __attribute__((aligned(16))) T strip[kCbStrip > RB ? kCbStrip : RB];
+    __shared__ uint32_t s_tp[kCbMaxBlocks + 1];
+    __shared__ uint32_t s_wsum[kCbThreads / 64];
+    using cnt_t = typename CbCounts<RPT>::type;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint32_t rb = blockIdx.x;
+    for (uint32_t i = tid; i <= nbc; i += kCbThreads) s_tp[i] = tile_ptr[(size_t)rb * nbc + i];
+    __syncthreads();
+    T acc[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) acc[r] = -T(0);
+    uint32_t seen = 0;                                    // bit r: row r of this thread holds an entry
+    const cnt_t *cnt_base = reinterpret_cast<const cnt_t *>(cnt8 + ((size_t)rb * nbc) * RB) + tid;
+
+    // the first non-empty tile's entries are requested here, every later tile's while the one before it is summed
+    T v[U];
+    uint32_t c[U];
+    uint32_t cb = 0;
+    while (cb < nbc && s_tp[cb + 1] == s_tp[cb]) ++cb;    // uniform
+    auto request = [&](uint32_t e0, uint32_t n) {         // one batch: entries e0 + tid + 256 * u (clamped: unconditional loads)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t i = e0 + min(tid + (uint32_t)u * kCbThreads, n - 1u);
+            v[u] = load_stream(vals + i);
+            c[u] = load_stream(cols + i);
+        }
+    };
+    auto products = [&](uint32_t b0, uint32_t n) {        // the batch in hand -> strip
+        T xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t i = b0 + tid + (uint32_t)u * kCbThreads;
+            if (i < n) strip[i] = v[u] * xv[u];
+        }
+    };
+    if (cb < nbc) request(s_tp[cb], s_tp[cb + 1] - s_tp[cb]);
+    while (cb < nbc) {
+        const uint32_t e0 = s_tp[cb], n = s_tp[cb + 1] - e0;   // 1 <= n <= kCbStrip
+        const cnt_t packed = cnt_base[(size_t)cb * (RB / RPT)];
+        products(0u, n);
+        for (uint32_t b0 = kCbThreads * U; b0 < n; b0 += kCbThreads * U) {   // uniform: tiles above 256 * U entries
+            request(e0 + b0, n - b0);
+            products(b0, n);
+        }
+        // the next non-empty tile's first batch travels while this one is summed
+        uint32_t nb = cb + 1;
+        while (nb < nbc && s_tp[nb + 1] == s_tp[nb]) ++nb;
+        if (nb < nbc) request(s_tp[nb], s_tp[nb + 1] - s_tp[nb]);
+        // where this thread's rows start in the strip: exclusive scan of the threads' entry counts
+        uint32_t cnt[RPT];
+        cb_unpack<RPT>(packed, cnt);
+        uint32_t mine = 0;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) mine += cnt[r];
+        const uint32_t inc = cb_wave_inclusive_scan(mine, lane);
+        if (lane == 63) s_wsum[w] = inc;
+        __syncthreads();                                   // (also: every product is in the strip)
+        uint32_t pos = inc - mine;
+#pragma unroll
+        for (uint32_t i = 0; i < kCbThreads / 64; ++i)
+            if (i < w) pos += s_wsum[i];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            for (uint32_t k = 0; k < cnt[r]; ++k) acc[r] = acc[r] + strip[pos++];
+            seen |= (cnt[r] ? 1u : 0u) << r;
+        }
+        __syncthreads();                                   // the strip is written again
+        cb = nb;
+    }
+    // y: through the strip, so that a wave stores 64 consecutive rows; rows without entries are +0.0
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) strip[tid * RPT + r] = ((seen >> r) & 1u) ? acc[r] : T(0);
+    __syncthreads();
+    const uint32_t r0 = rb * RB;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+        const uint32_t i = tid + (uint32_t)r * kCbThreads;
+        if (r0 + i < nrows) y[r0 + i] = strip[i];
+    }
+}
+
 // ---- plan-time kernels ------------------------------------------------------------------------------------------
 // cnt8[(rb * nbc + cb) * RB + row in block] = entries of the row in column block cb (columns ascend inside a row);
 // *flag |= 1 when a count exceeds 255.  cnt8 is zeroed by the caller.
@@ -140,18 +259,21 @@ __global__ __launch_bounds__(256) void cb_count(const uint32_t *__restrict__ row
     }
 }
 
-// tile_n[t] = entries of tile t = sum of its RB counts (one workgroup per tile)
+// tile_n[t] = entries of tile t = sum of its RB counts (one workgroup per tile); *runs += rows with entries in the tile
 __global__ __launch_bounds__(256) void cb_tile_totals(const uint8_t *__restrict__ cnt8, uint32_t RB,
-                                                      uint32_t *__restrict__ tile_n) {
-    __shared__ uint32_t s[4];
+                                                      uint32_t *__restrict__ tile_n, unsigned long long *__restrict__ runs) {
+    __shared__ uint32_t s[4], s_runs[4];
     const uint8_t *c = cnt8 + (size_t)blockIdx.x * RB;
-    uint32_t v = 0;
-    for (uint32_t i = threadIdx.x; i < RB; i += 256) v += c[i];
+    uint32_t v = 0, nz = 0;
+    for (uint32_t i = threadIdx.x; i < RB; i += 256) { v += c[i]; nz += c[i] ? 1u : 0u; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    for (int o = 32; o > 0; o >>= 1) { v += (uint32_t)__shfl_xor((int)v, o, 64); nz += (uint32_t)__shfl_xor((int)nz, o, 64); }
+    if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = v; s_runs[threadIdx.x >> 6] = nz; }
     __syncthreads();
-    if (threadIdx.x == 0) tile_n[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+    if (threadIdx.x == 0) {
+        tile_n[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+        atomicAdd(runs, (unsigned long long)(s_runs[0] + s_runs[1] + s_runs[2] + s_runs[3]));
+    }
 }
 
 // the tiled copy: one workgroup per row block; thread t owns the rpt = ceil(RB / 256) consecutive rows t * rpt ... of it
@@ -195,7 +317,7 @@ __global__ __launch_bounds__(kCbThreads) void cb_fill(const uint32_t *__restrict
             for (uint32_t k = 0; k < cnt[r]; ++k) {
                 out_col[pos] = colind[src[r]];
                 out_val[pos] = values[src[r]];
-                out_row[pos] = (uint16_t)(tid * rpt + (uint32_t)r);
+                if (out_row) out_row[pos] = (uint16_t)(tid * rpt + (uint32_t)r);
                 ++pos;
                 ++src[r];
             }

@@ -1932,6 +1932,10 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         if (value != 0 && (value < 8 || value > 24))
             return fail(SPAL_ERR_INVALID_ARGUMENT, "cblock_shift (log2 of the columns of a column block) must be 0 (auto: 2 MB of x) or in [8, 24]");
         p.cblock_shift_user = (int)value;
+    } else if (!strcmp(key, "cblock_form")) {
+        // -1 = by the entries per run, 0 = entry-parallel kernel, 1 = rows form (rows of a row block: 256 ... 4096, a power of two)
+        if (value < -1 || value > 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "cblock_form must be -1 (auto), 0 (entry-parallel) or 1 (rows form)");
+        p.cblock_form_user = (int)value;
     } else if (!strcmp(key, "threads")) {
         if (value == 0) p.user_threads = false;
         else if (value != 512 && value != 1024)
@@ -2052,7 +2056,7 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "\"overflow_tiles\": %u, \"skew\": %d, \"persistent\": %d, \"nt_store\": %d, \"uniform_row_fraction\": %.4f, "
              "\"prefetch\": %d, \"slide\": %d, \"ring_pages\": %d, \"tile_steps\": %d, \"split_tiles\": %u, \"panel_tiles\": %u, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f], \"placement_us\": [%.1f, %.1f], \"placement_tries\": %d, \"addr\": [\"%llx\", \"%llx\", \"%llx\"], "
              "\"vectors_walk_us\": [%.1f, %.1f], \"vectors_walk_blocks\": %d, "
-             "\"nonlocal_row_fraction\": %.4f, \"cblock\": %d, \"cblock_pending\": %d, \"cblock_rows\": %d, \"cblock_cols\": %llu, \"cblock_col_blocks\": %d, \"cblock_row_blocks\": %u, \"cblock_us\": [%.1f, %.1f]}",
+             "\"nonlocal_row_fraction\": %.4f, \"cblock\": %d, \"cblock_pending\": %d, \"cblock_rows\": %d, \"cblock_form\": \"%s\", \"cblock_run\": %.2f, \"cblock_cols\": %llu, \"cblock_col_blocks\": %d, \"cblock_row_blocks\": %u, \"cblock_us\": [%.1f, %.1f]}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, (p.kernel == 2 || p.vec_col16) ? 16 : 32,
              (p.cblock && p.cblock_on) ? "cblock" : p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
@@ -2072,7 +2076,7 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              a->place_tried, (unsigned long long)(uintptr_t)a->d_values,
              (unsigned long long)(uintptr_t)a->d_col16, (unsigned long long)(uintptr_t)a->d_rowptr,
              (double)a->walk_us[0], (double)a->walk_us[1], a->walk_blocks,
-             p.kernel == 2 ? p.nonlocal_row_fraction : 0.0, (p.cblock && p.cblock_on) ? 1 : 0, p.cblock_pending, p.cblock ? p.cblock_rows : 0,
+             p.kernel == 2 ? p.nonlocal_row_fraction : 0.0, (p.cblock && p.cblock_on) ? 1 : 0, p.cblock_pending, p.cblock ? p.cblock_rows : 0, !p.cblock ? "" : p.cblock_form ? "rows" : "entry", p.cblock ? (double)p.cblock_run : 0.0,
              p.cblock ? (1ull << p.cblock_shift) : 0ull, p.cblock ? p.cblock_nbc : 0, p.cblock ? p.cblock_nrb : 0u,
              (double)a->cblock_us[0], (double)a->cblock_us[1]);
     return SPAL_OK;

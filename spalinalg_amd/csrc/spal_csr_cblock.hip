@@ -27,25 +27,76 @@ static uint32_t cb_per_cu(size_t lds) {   // workgroups of 256 threads a CU hold
 // through the column blocks (that is what keeps one x slice in L2), so a launch of 1.2 rounds takes as long as one of
 // two -- 5M x 5M at 4096 rows per block: 1221 workgroups for 1024 places.  `force`: option "cblock" = 1 (tests: small
 // matrices).  Returns SPAL_OK with a->plan.cblock = 0 when the matrix does not qualify.
+// counts of one geometry: cnt8 (kept on the handle), the tiles' entry counts (host), the rows-with-entries-per-tile total
+static int cb_count_tiles(spal_csr *a, uint32_t RB, uint32_t nbc, uint32_t shift, std::vector<uint32_t> &tile_n, uint64_t &runs,
+                          bool &too_long) {
+    const uint32_t nrb = (uint32_t)((a->nrows + RB - 1) / RB);
+    const size_t cnt_bytes = (size_t)nrb * nbc * RB;
+    uint32_t *d_flag = nullptr, *d_tile_n = nullptr;
+    (void)dev_free(a->d_cb_cnt); a->d_cb_cnt = nullptr;
+    SPAL_HIP_TRY(dev_alloc((void **)&a->d_cb_cnt, cnt_bytes));
+    SPAL_HIP_TRY(dev_alloc((void **)&d_tile_n, (size_t)nrb * nbc * 4));
+    SPAL_HIP_TRY(dev_alloc((void **)&d_flag, 16));              // {a count above 255, -, runs (8 bytes)}
+    hipError_t e = hipMemsetAsync(a->d_cb_cnt, 0, cnt_bytes, a->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_flag, 0, 16, a->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(cb_count, dim3((uint32_t)((a->nrows + 255) / 256)), dim3(256), 0, a->stream, a->d_rowptr,
+                           a->d_colind, (uint32_t)a->nrows, RB, nbc, shift, a->d_cb_cnt, d_flag);
+        hipLaunchKernelGGL(cb_tile_totals, dim3(nrb * nbc), dim3(256), 0, a->stream, a->d_cb_cnt, RB, d_tile_n,
+                           reinterpret_cast<unsigned long long *>(d_flag + 2));
+        e = hipGetLastError();
+    }
+    uint32_t back[4] = {0, 0, 0, 0};
+    tile_n.resize((size_t)nrb * nbc);
+    if (e == hipSuccess) e = hipMemcpyAsync(back, d_flag, 16, hipMemcpyDeviceToHost, a->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(tile_n.data(), d_tile_n, tile_n.size() * 4, hipMemcpyDeviceToHost, a->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
+    (void)dev_free(d_flag);
+    (void)dev_free(d_tile_n);
+    SPAL_HIP_TRY(e);
+    too_long = back[0] != 0;
+    runs = (uint64_t)back[2] | ((uint64_t)back[3] << 32);
+    return SPAL_OK;
+}
+
 int cblock_plan(spal_csr *a, bool force) {
     CsrPlan &p = a->plan;
     cblock_free(a);
     if (a->nnz == 0 || !a->parts.empty()) return SPAL_OK;
     const size_t esz = (size_t)a->elem_size;
-    uint32_t shift = esz == 8 ? 18 : 19;                       // 2 MB of x per column block ...
-    // ... narrower where rows are long: the kernel is entry-parallel, the thread that heads a row's run inside a tile
-    // adds the whole run, so runs should hold about one entry (14 per row over 4 column blocks: 3.5 per run, a quarter
-    // of the threads busy in that phase)
-    const double mean_row = (double)a->nnz / (double)a->nrows;
-    while (shift > 15 && mean_row / (double)((a->ncols + (1ull << shift) - 1) >> shift) > 1.25 &&
-           ((a->ncols + (1ull << (shift - 1)) - 1) >> (shift - 1)) <= kCbMaxBlocks) --shift;
+    const uint32_t shift0 = esz == 8 ? 18 : 19;                // 2 MB of x per column block ...
+    if (((a->ncols + (1ull << shift0) - 1) >> shift0) > kCbMaxBlocks && p.cblock_shift_user <= 0) return SPAL_OK;
+    if (!force && a->ncols * esz <= (size_t)4 << 20) return SPAL_OK;   // x of 4 MB: the L2s hold it anyway
+    const double mean = (double)a->nnz / (double)a->nrows;
+    if (!force && mean > 64.0) return SPAL_OK;                 // long rows: the vector kernels' business
+    std::vector<uint32_t> tile_n;
+    uint64_t runs = 0;
+    bool too_long = false;
+    // Which form: how many entries a row holds per column block it touches (a RUN), counted at the 2 MB width.  Runs of
+    // about one entry (10 per row over 20 blocks): the entry-parallel kernel; two and more (14 per row over 4 ... 8
+    // blocks, wide bands): the rows form, whose threads own rows (csr_cblock.hpp).
+    int form = p.cblock_form_user;
+    if (form < 0) {
+        const uint32_t sh = p.cblock_shift_user > 0 ? (uint32_t)p.cblock_shift_user : shift0;
+        const uint64_t nb = (a->ncols + (1ull << sh) - 1) >> sh;
+        if (nb > kCbMaxBlocks) return SPAL_OK;
+        SPAL_TRY(cb_count_tiles(a, 1024, (uint32_t)nb, sh, tile_n, runs, too_long));
+        if (too_long) { cblock_free(a); return SPAL_OK; }
+        form = (runs && (double)a->nnz / (double)runs >= 1.6) ? 1 : 0;
+    }
+    uint32_t shift = shift0;
+    if (form == 0) {
+        // ... narrower where rows are long: the kernel is entry-parallel, the thread that heads a row's run inside a tile
+        // adds the whole run, so runs should hold about one entry
+        while (shift > 15 && mean / (double)((a->ncols + (1ull << shift) - 1) >> shift) > 1.25 &&
+               ((a->ncols + (1ull << (shift - 1)) - 1) >> (shift - 1)) <= kCbMaxBlocks) --shift;
+    } else if (((a->ncols + (1ull << (shift - 1)) - 1) >> (shift - 1)) <= kCbMaxBlocks) {
+        --shift;                                               // rows form: 1 MB slices measured best (profiles/r03/cblock_sweeps.txt)
+    }
     if (p.cblock_shift_user > 0) shift = (uint32_t)p.cblock_shift_user;
     const uint64_t nbc64 = (a->ncols + (1ull << shift) - 1) >> shift;
     if (nbc64 > kCbMaxBlocks) return SPAL_OK;
-    if (!force && a->ncols * esz <= (size_t)4 << 20) return SPAL_OK;   // x of 4 MB: the L2s hold it anyway
     const uint32_t nbc = (uint32_t)nbc64;
-    const double mean = (double)a->nnz / (double)a->nrows;
-    if (!force && mean > 64.0) return SPAL_OK;                 // long rows: the vector kernels' business
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, a->device);
     // candidate heights, tallest first: the tallest whose launch fills at least 92 % of its last round (or is long enough
@@ -57,7 +108,10 @@ int cblock_plan(spal_csr *a, bool force) {
     };
     std::vector<uint32_t> cands;
     if (p.cblock_rows_user > 0) cands.push_back((uint32_t)p.cblock_rows_user);
-    else {
+    else if (form == 1) {
+        for (uint32_t RB : {4096u, 2048u, 1024u, 512u, 256u})     // 256 threads x 16 ... 1 rows each; the tallest whose tiles fit
+            if ((double)RB * mean / (double)nbc <= 0.9 * (double)kCbStrip || RB == 256u) cands.push_back(RB);
+    } else {
         uint32_t best = 0;
         double best_eff = 0.0;
         for (uint32_t RB = kCbMaxRows; RB >= 256; RB -= 128) {
@@ -72,30 +126,14 @@ int cblock_plan(spal_csr *a, bool force) {
         if (cands.empty() && best) cands.push_back(best);
         for (uint32_t RB : {2048u, 1024u, 512u}) cands.push_back(RB);   // (when the fullest tile of the first choice does not fit)
     }
-    uint32_t *d_flag = nullptr, *d_tile_n = nullptr;
     uint32_t chosen = 0, S = 0;
-    std::vector<uint32_t> tile_n;
-    SPAL_HIP_TRY(dev_alloc((void **)&d_flag, 4));
     for (uint32_t RB : cands) {
         if (RB < 1 || RB > kCbMaxRows) continue;
+        if (form == 1 && RB != 4096 && RB != 2048 && RB != 1024 && RB != 512 && RB != 256) continue;   // whole rows per thread
         const uint32_t nrb = (uint32_t)((a->nrows + RB - 1) / RB);
-        const size_t cnt_bytes = (size_t)nrb * nbc * RB;
-        (void)dev_free(a->d_cb_cnt); a->d_cb_cnt = nullptr;
-        (void)dev_free(d_tile_n); d_tile_n = nullptr;
-        SPAL_HIP_TRY(dev_alloc((void **)&a->d_cb_cnt, cnt_bytes));
-        SPAL_HIP_TRY(dev_alloc((void **)&d_tile_n, (size_t)nrb * nbc * 4));
-        SPAL_HIP_TRY(hipMemsetAsync(a->d_cb_cnt, 0, cnt_bytes, a->stream));
-        SPAL_HIP_TRY(hipMemsetAsync(d_flag, 0, 4, a->stream));
-        hipLaunchKernelGGL(cb_count, dim3((uint32_t)((a->nrows + 255) / 256)), dim3(256), 0, a->stream, a->d_rowptr,
-                           a->d_colind, (uint32_t)a->nrows, RB, nbc, shift, a->d_cb_cnt, d_flag);
-        hipLaunchKernelGGL(cb_tile_totals, dim3(nrb * nbc), dim3(256), 0, a->stream, a->d_cb_cnt, RB, d_tile_n);
-        SPAL_HIP_TRY(hipGetLastError());
-        uint32_t flag = 0;
-        tile_n.resize((size_t)nrb * nbc);
-        SPAL_HIP_TRY(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, a->stream));
-        SPAL_HIP_TRY(hipMemcpyAsync(tile_n.data(), d_tile_n, tile_n.size() * 4, hipMemcpyDeviceToHost, a->stream));
-        SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
-        if (flag) break;                                       // a row with more than 255 entries in one column block
+        if (form == 1 && (size_t)nrb * nbc * RB > (size_t)a->nnz * 12 && !force) break;   // counts heavier than the entries
+        SPAL_TRY(cb_count_tiles(a, RB, nbc, shift, tile_n, runs, too_long));
+        if (too_long) break;                                   // a row with more than 255 entries in one column block
         uint32_t fullest = 0;
         for (uint32_t n : tile_n) fullest = std::max(fullest, n);
         if (fullest <= kCbStrip) {
@@ -105,11 +143,10 @@ int cblock_plan(spal_csr *a, bool force) {
             break;
         }
     }
-    (void)dev_free(d_flag);
-    (void)dev_free(d_tile_n);
     if (getenv("SPAL_CBLOCK_DEBUG"))
-        fprintf(stderr, "[spal cblock] %llu x %llu, %.2f per row, %u column blocks of 2^%u: %u rows per block, strip %u%s\n", (unsigned long long)a->nrows,
-                (unsigned long long)a->ncols, mean, nbc, shift, chosen, S, chosen ? "" : " (does not qualify)");
+        fprintf(stderr, "[spal cblock] %llu x %llu, %.2f per row, %s form, %u column blocks of 2^%u: %u rows per block, strip %u, %.2f entries per run%s\n",
+                (unsigned long long)a->nrows, (unsigned long long)a->ncols, mean, form ? "rows" : "entry", nbc, shift, chosen, S,
+                runs ? (double)a->nnz / (double)runs : 0.0, chosen ? "" : " (does not qualify)");
     if (!chosen) { cblock_free(a); return SPAL_OK; }
     const uint32_t RB = chosen;
     const uint32_t nrb = (uint32_t)((a->nrows + RB - 1) / RB);
@@ -121,7 +158,7 @@ int cblock_plan(spal_csr *a, bool force) {
     SPAL_HIP_TRY(dev_alloc((void **)&a->d_cb_tile, tp.size() * 4));
     SPAL_HIP_TRY(dev_alloc((void **)&a->d_cb_col, ((size_t)a->nnz + 256) * 4));
     SPAL_HIP_TRY(dev_alloc((void **)&a->d_cb_val, ((size_t)a->nnz + 256) * esz));
-    SPAL_HIP_TRY(dev_alloc((void **)&a->d_cb_row, ((size_t)a->nnz + 256) * 2));
+    if (form == 0) SPAL_HIP_TRY(dev_alloc((void **)&a->d_cb_row, ((size_t)a->nnz + 256) * 2));
     SPAL_HIP_TRY(hipMemcpyAsync(a->d_cb_tile, tp.data(), tp.size() * 4, hipMemcpyHostToDevice, a->stream));
     if (esz == 8)
         hipLaunchKernelGGL(cb_fill<double>, dim3(nrb), dim3(kCbThreads), 0, a->stream, a->d_rowptr, a->d_colind, (const double *)a->d_values,
@@ -131,8 +168,10 @@ int cblock_plan(spal_csr *a, bool force) {
                            a->d_cb_tile, a->d_cb_cnt, (uint32_t)a->nrows, nbc, RB, a->d_cb_col, (float *)a->d_cb_val, a->d_cb_row);
     SPAL_HIP_TRY(hipGetLastError());
     SPAL_HIP_TRY(hipStreamSynchronize(a->stream));             // `tp` goes out of scope
-    (void)dev_free(a->d_cb_cnt); a->d_cb_cnt = nullptr;       // the counts were the builder's; the kernel reads the entries' rows
+    if (form == 0) { (void)dev_free(a->d_cb_cnt); a->d_cb_cnt = nullptr; }   // the counts were the builder's; the entry form reads the entries' rows
     p.cblock = 1;
+    p.cblock_form = form;
+    p.cblock_run = runs ? (float)((double)a->nnz / (double)runs) : 0.f;
     p.cblock_rows = (int)RB;
     p.cblock_strip = (int)S;
     p.cblock_shift = (int)shift;
@@ -159,8 +198,23 @@ static hipError_t launch_cb(const spal_csr *a, const void *x, void *y, hipStream
     return hipGetLastError();
 }
 
+template <typename T, int RPT>
+static hipError_t launch_cb_rows(const spal_csr *a, const void *x, void *y, hipStream_t st) {
+    hipLaunchKernelGGL((csr_spmv_cblock_rows<T, RPT, 8>), dim3(a->plan.cblock_nrb), dim3(kCbThreads), 0, st,
+                       (const T *)a->d_cb_val, a->d_cb_col, a->d_cb_tile, a->d_cb_cnt, (const T *)x, (T *)y,
+                       (uint32_t)a->nrows, (uint32_t)a->plan.cblock_nbc);
+    return hipGetLastError();
+}
+
 hipError_t launch_cblock(const spal_csr *a, const void *x, void *y, hipStream_t st) {
-    return a->elem_size == 8 ? launch_cb<double>(a, x, y, st) : launch_cb<float>(a, x, y, st);
+    if (a->plan.cblock_form == 0) return a->elem_size == 8 ? launch_cb<double>(a, x, y, st) : launch_cb<float>(a, x, y, st);
+#define SPAL_CB_CASE(RPT) \
+    case RPT * 256: return a->elem_size == 8 ? launch_cb_rows<double, RPT>(a, x, y, st) : launch_cb_rows<float, RPT>(a, x, y, st);
+    switch (a->plan.cblock_rows) {
+        SPAL_CB_CASE(16) SPAL_CB_CASE(8) SPAL_CB_CASE(4) SPAL_CB_CASE(2) SPAL_CB_CASE(1)
+        default: return hipErrorInvalidValue;
+    }
+#undef SPAL_CB_CASE
 }
 
 }  // namespace spal

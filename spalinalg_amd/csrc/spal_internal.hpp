@@ -137,6 +137,9 @@ struct CsrPlan {
     int cblock_rows = 0;     // rows of a row block (one workgroup each)
     int cblock_strip = 0;    // entries of the product strip (the fullest tile fits)
     int cblock_rows_user = 0, cblock_shift_user = 0;   // options "cblock_rows", "cblock_shift"
+    int cblock_form_user = -1;   // option "cblock_form": -1 = by the entries per run, 0 = entry-parallel, 1 = rows form
+    int cblock_form = 0;         // 0: csr_spmv_cblock (entry-parallel, rows16), 1: csr_spmv_cblock_rows (threads own rows, cnt8)
+    float cblock_run = 0.f;      // entries per (row, column block) that holds any
     int cblock_shift = 0;    // a column block holds 2^shift columns
     int cblock_nbc = 0;      // column blocks
     uint32_t cblock_nrb = 0; // row blocks = workgroups

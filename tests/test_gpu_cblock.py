@@ -1,8 +1,9 @@
-"""GPU parity: the column-blocked CSR kernel (csr_cblock.hpp) -- matrices whose columns are anywhere.
+"""GPU parity: the column-blocked CSR kernels (csr_cblock.hpp) -- matrices whose columns are anywhere.
 
-A row's products are added in ascending column order by ONE thread whose running sum lives in a register from the
-first column block to the last (reference order: src/csr/ops/mul.rs:31-38), so every row must equal the oracle's
-bit for bit (f64 and f32), whatever the tile geometry."""
+Both forms (entry-parallel: the thread that heads a row's run in a tile adds the run to the row's running sum in LDS;
+rows form: a thread owns rows, their running sums in its registers) add a row's products in ascending column order, one
+after the other, from the first column block to the last (reference order: src/csr/ops/mul.rs:31-38), so every row must
+equal the oracle's bit for bit (f64 and f32), whatever the tile geometry."""
 import numpy as np
 import pytest
 
@@ -30,8 +31,9 @@ def random_rows(rng, nrows, ncols, lens, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("rows", [300, 512, 1000, 2048, 3333, 4096])
-def test_forced_geometries_bit_identical(oracle, dtype, rows):
+@pytest.mark.parametrize("form, rows", [(0, 300), (0, 512), (0, 1000), (0, 2048), (0, 3333), (0, 4096),
+                                        (1, 256), (1, 512), (1, 1024), (1, 2048), (1, 4096)])
+def test_forced_geometries_bit_identical(oracle, dtype, form, rows):
     """Row-block heights from 300 to 4096 rows (multiples of the workgroup size or not), small column blocks (many tiles, empty tiles, tiles of one entry),
     rows of 0 ... 40 entries, a row count that is no multiple of anything."""
     rng = np.random.default_rng(100 + rows)
@@ -47,12 +49,13 @@ def test_forced_geometries_bit_identical(oracle, dtype, rows):
     for shift in (10, 13, 16):                         # 49, 7 and 1 column blocks
         dev.set_option("cblock_shift", shift)
         dev.set_option("cblock_rows", rows)
+        dev.set_option("cblock_form", form)
         dev.set_option("cblock", 1)
         d = dev.describe()
         if d["kernel"] != "cblock":                   # (a tile above the strip's 4096 entries: this height does not qualify)
             continue
         ran += 1
-        assert d["cblock_rows"] == rows and d["cblock_cols"] == 1 << shift, d
+        assert d["cblock_rows"] == rows and d["cblock_cols"] == 1 << shift and d["cblock_form"] == ("rows" if form else "entry"), d
         y = dev.spmv(x)
         assert np.array_equal(bits(y), bits(y_ref)), (shift, d)
     assert ran >= 1
@@ -73,8 +76,11 @@ def test_first_product_is_assigned_and_signed_zeros(oracle):
     dev = sp.CsrMatrix(nrows, ncols, rp, ci, va).device()
     dev.set_option("cblock_shift", 11)
     dev.set_option("cblock", 1)
-    assert dev.describe()["kernel"] == "cblock"
-    assert np.array_equal(bits(dev.spmv(x)), bits(y_ref))
+    for form in (0, 1):
+        dev.set_option("cblock_form", form)
+        d = dev.describe()
+        assert d["kernel"] == "cblock" and d["cblock_form"] == ("rows" if form else "entry"), d
+        assert np.array_equal(bits(dev.spmv(x)), bits(y_ref))
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -90,6 +96,7 @@ def test_uniform_columns_take_the_column_blocked_kernel(oracle, dtype):
     dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
     d = dev.describe()
     assert d["kernel"] == "cblock" and d["nonlocal_row_fraction"] > 0.9, d
+    assert d["cblock_form"] == "rows" and d["cblock_run"] > 1.6, d     # 14 per row over 4 column blocks of 2 MB: runs of 3.6 entries
     y = dev.spmv(x)
     assert np.array_equal(bits(y), bits(y_ref))
     xt = torch.from_numpy(x).cuda()
@@ -131,3 +138,19 @@ def test_a_crowded_column_block_disqualifies(oracle):
     y_ref = oracle.csr_spmv(rp, ci, va, x)
     bound = oracle.csr_abs_bound(rp, ci, va, x)
     assert np.all(np.abs(dev.spmv(x) - y_ref) <= 1e-10 * bound + 1e-300)
+
+
+def test_form_follows_the_entries_per_run(oracle):
+    """10 entries per row over 20 column blocks (the shape of the matrix config 5 assembles, at a quarter of its size
+    with column blocks a quarter as wide): runs of about one entry -> the entry-parallel form; the same rows with their
+    columns inside a window of 2^16: runs of several entries -> the rows form.  Bit-identical either way."""
+    n = 1_250_000
+    for window, form in ((n, "entry"), (1 << 16, "rows")):
+        rp, ci, va = synth.banded_csr(n, n, 10, window, 7)
+        x = synth.vector(n)
+        dev = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
+        dev.set_option("cblock_shift", 16)
+        dev.set_option("cblock", 1)
+        d = dev.describe()
+        assert d["kernel"] == "cblock" and d["cblock_form"] == form, d
+        assert np.array_equal(bits(dev.spmv(x)), bits(oracle.csr_spmv(rp, ci, va, x)))

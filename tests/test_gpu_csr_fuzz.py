@@ -92,6 +92,7 @@ def test_random_matrices_all_planner_paths(oracle, seed):
         # its rows must equal the oracle's BIT FOR BIT, heavy rows, empty stretches and all
         dev.set_option("cblock_rows", int(rng.choice([0, 256, 700, 1024, 3000, 4096])))
         dev.set_option("cblock_shift", int(rng.choice([0, 8, 11, 14, 17])))
+        dev.set_option("cblock_form", int(rng.choice([-1, 0, 1])))      # (the rows form takes heights of 256 << k only: others fall to the stream kernels)
         dev.set_option("cblock", 1)
         if dev.describe()["kernel"] == "cblock":
             bits = np.uint64 if dtype == np.float64 else np.uint32

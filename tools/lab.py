@@ -1455,7 +1455,9 @@ def cblock():
     import spal_synth as synth
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
     per_row = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-    rp, ci, va = synth.banded_csr(n, n, per_row, n, synth.matrix_seed(2))
+    window = int(os.environ.get("LAB_WINDOW", "0")) or n          # (columns within a window this wide around the diagonal; default: anywhere)
+    form = int(os.environ.get("LAB_FORM", "-1"))                  # cblock_form: -1 auto, 0 entry-parallel, 1 rows form
+    rp, ci, va = synth.banded_csr(n, n, per_row, window, synth.matrix_seed(2))
     d = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
     x = torch.from_numpy(synth.vector(n)).cuda()
     y = torch.empty_like(x)
@@ -1474,11 +1476,12 @@ def cblock():
     d.set_option("cblock", 0)
     print(f"{n} x {n}, {per_row} per row, uniform columns: stream kernels {us():7.1f} us", flush=True)
     ref = y.clone()
-    d.set_option("cblock", -1)
+    d.set_option("cblock", 1 if window != n else -1)
     d.set_option("cblock_rows", 0)
+    d.set_option("cblock_form", form)
     p = d.describe()
     t = us()
-    print(f"  automatic plan: columns per block {p['cblock_cols']} ({p['cblock_col_blocks']} blocks), rows per block {p['cblock_rows']} "
+    print(f"  automatic plan ({p.get('cblock_form')} form, {p.get('cblock_run')} entries per run): columns per block {p['cblock_cols']} ({p['cblock_col_blocks']} blocks), rows per block {p['cblock_rows']} "
           f"({p['cblock_row_blocks']} workgroups): {t:7.1f} us   same bits as the stream kernels: {bool(torch.equal(y, ref))}", flush=True)
     shifts = [int(v) for v in os.environ.get("LAB_SHIFTS", "15,16,17,18,19").split(",")]
     heights = [int(v) for v in os.environ.get("LAB_ROWS", "1024,2048,3072,4096").split(",")]
@@ -1491,7 +1494,7 @@ def cblock():
                 print(f"  columns per block 2^{shift}, rows per block {rows}: does not qualify")
                 continue
             t = us()
-            print(f"  columns per block 2^{shift} ({p['cblock_col_blocks']} blocks), rows per block {rows} ({p['cblock_row_blocks']} workgroups, strip {p.get('cblock_strip')}): "
+            print(f"  {p.get('cblock_form')} form, columns per block 2^{shift} ({p['cblock_col_blocks']} blocks), rows per block {rows} ({p['cblock_row_blocks']} workgroups): "
                   f"{t:7.1f} us   same bits as the stream kernels: {bool(torch.equal(y, ref))}", flush=True)
 
 
