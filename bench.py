@@ -989,7 +989,8 @@ def main():
             "frac": round(achieved / peak, 4),
             "traffic": traffic,
             "traffic_source": "profiles/traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)",
-            "kernel": ("csr_spmv_slide" if plan.get("slide") and plan["kernel"] == "stream" else "csr_spmv_" + plan["kernel"]),
+            "kernel": ("csr_spmv_slide" if plan.get("slide") and plan["kernel"] == "stream" else
+                       "csr_spmv_cblock_rows" if plan["kernel"] == "cblock" and plan.get("cblock_form") == "rows" else "csr_spmv_" + plan["kernel"]),
             "kernel_ms": round(kern_ms, 6),
             "kernel_ms_max_over_ranks": round(kern_ms_max, 6),
             "algorithmic_bytes_per_launch": local_bytes,

@@ -114,7 +114,7 @@ def main():
             tot_w += wr
         out.append(f"=> config5_assembly_f64: {tot_r / 1e6:.1f} MB read + {tot_w / 1e6:.1f} MB written = {(tot_r + tot_w) / 1e6:.1f} MB per assembly")
         traffic["config5_assembly_f64"] = {"hbm_bytes_per_launch": int(tot_r + tot_w), "read": int(tot_r), "written": int(tot_w), "source": src}
-        for k in ("csr_spmv_cblock", "csr_spmv_stream"):
+        for k in ("csr_spmv_cblock", "csr_spmv_cblock_rows", "csr_spmv_stream"):
             if k in f5:
                 rd, wr = mean(f5[k]) * 2 * 1024, mean(w5.get(k, [0.0])) * 1024
                 out.append(f"the product on the result: {k}: {rd / 1e6:.1f} MB read + {wr / 1e6:.1f} MB written per launch")
