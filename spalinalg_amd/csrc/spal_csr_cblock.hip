@@ -1,4 +1,6 @@
 // spal_csr_cblock.hip -- plan and launch of the column-blocked CSR kernel (csr_cblock.hpp).
+#include <cmath>
+
 #include "csr_cblock.hpp"
 #include "spal_internal.hpp"
 
@@ -13,20 +15,13 @@ void cblock_free(spal_csr *a) {
     a->plan.cblock = 0;
 }
 
+// entry form: two product strips (producers fill one while consumers sum the other), the running sums, two row strips
 static size_t cb_lds_bytes(uint32_t RB, uint32_t S, size_t esz) {
-    return (size_t)S * esz + (size_t)((RB + 1u) & ~1u) * esz + ((size_t)S + 2) * 2;
+    return 2 * (size_t)S * esz + (size_t)((RB + 1u) & ~1u) * esz + 2 * ((size_t)S + 2) * 2;
 }
-static uint32_t cb_per_cu(size_t lds) {   // workgroups of 256 threads a CU holds: LDS decides (160 KiB), at most 8
-    return (uint32_t)std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / (lds + 512)));
-}
-
-// Builds the tiled copy when the matrix qualifies: x larger than an XCD's L2 keeps warm by itself, at most
-// kCbMaxBlocks column blocks of 2 MB of x, at most 255 entries of a row per column block (the builder's counts are
-// bytes), and a row-block height whose fullest tile fits the product strip.  The height is chosen so that the launch is
-// (nearly) a WHOLE number of rounds of the workgroups the device holds: the workgroups of a round run side by side
-// through the column blocks (that is what keeps one x slice in L2), so a launch of 1.2 rounds takes as long as one of
-// two -- 5M x 5M at 4096 rows per block: 1221 workgroups for 1024 places.  `force`: option "cblock" = 1 (tests: small
-// matrices).  Returns SPAL_OK with a->plan.cblock = 0 when the matrix does not qualify.
+// The entry form runs best with exactly TWO workgroups per CU (csr_cblock.hpp): the plan keeps a workgroup's LDS below
+// half a CU's, the launch pads a smaller request so that a third does not fit.
+constexpr size_t kCbLdsTwo = 79 * 1024, kCbLdsPad = 56 * 1024, kCbLdsMax = 159 * 1024;
 // counts of one geometry: cnt8 (kept on the handle), the tiles' entry counts (host), the rows-with-entries-per-tile total
 static int cb_count_tiles(spal_csr *a, uint32_t RB, uint32_t nbc, uint32_t shift, std::vector<uint32_t> &tile_n, uint64_t &runs,
                           bool &too_long) {
@@ -59,6 +54,13 @@ static int cb_count_tiles(spal_csr *a, uint32_t RB, uint32_t nbc, uint32_t shift
     return SPAL_OK;
 }
 
+// Builds the tiled copy when the matrix qualifies: x larger than an XCD's L2 keeps warm by itself, at most kCbMaxBlocks
+// column blocks, at most 255 entries of a row per column block (the builder's counts are bytes), and a row-block height
+// whose fullest tile fits the product strip.  Entry form: the height is chosen so that the launch is (nearly) a WHOLE
+// number of rounds of the two workgroups per CU the kernel runs with -- the workgroups of a round run side by side through
+// the column blocks (that is what keeps one x slice in L2), so a launch of 3.07 rounds takes as long as one of four
+// (5M x 5M: 1536 workgroups of 3256 rows 412 us, 1571 of 3184 rows 485 us).  `force`: option "cblock" = 1 (tests: small
+// matrices).  Returns SPAL_OK with a->plan.cblock = 0 when the matrix does not qualify.
 int cblock_plan(spal_csr *a, bool force) {
     CsrPlan &p = a->plan;
     cblock_free(a);
@@ -84,14 +86,17 @@ int cblock_plan(spal_csr *a, bool force) {
         if (too_long) { cblock_free(a); return SPAL_OK; }
         form = (runs && (double)a->nnz / (double)runs >= 1.6) ? 1 : 0;
     }
-    uint32_t shift = shift0;
+    // 1 MB of f64 x (2^17 columns; f32: 2^17 as well, 0.5 MB) per column block measured best for both forms: the slice
+    // shares its XCD's 4 MB L2 with the streamed entries and with the slices of workgroups a block ahead or behind
+    // (5M x 5M entry form, 3256 rows: 2^16 440 us, 2^17 383, 2^18 414, 2^19 595; f32 366 / 308 / 330; rows form:
+    // profiles/r03/cblock_sweeps.txt) -- wider only where the matrix has more than kCbMaxBlocks of them
+    uint32_t shift = form == 1 ? shift0 - 1 : 17;
+    while (((a->ncols + (1ull << shift) - 1) >> shift) > kCbMaxBlocks) ++shift;
     if (form == 0) {
-        // ... narrower where rows are long: the kernel is entry-parallel, the thread that heads a row's run inside a tile
-        // adds the whole run, so runs should hold about one entry
+        // ... narrower where rows are long: the thread that heads a row's run inside a tile adds the whole run, so runs
+        // should hold about one entry
         while (shift > 15 && mean / (double)((a->ncols + (1ull << shift) - 1) >> shift) > 1.25 &&
                ((a->ncols + (1ull << (shift - 1)) - 1) >> (shift - 1)) <= kCbMaxBlocks) --shift;
-    } else if (((a->ncols + (1ull << (shift - 1)) - 1) >> (shift - 1)) <= kCbMaxBlocks) {
-        --shift;                                               // rows form: 1 MB slices measured best (profiles/r03/cblock_sweeps.txt)
     }
     if (p.cblock_shift_user > 0) shift = (uint32_t)p.cblock_shift_user;
     const uint64_t nbc64 = (a->ncols + (1ull << shift) - 1) >> shift;
@@ -99,12 +104,11 @@ int cblock_plan(spal_csr *a, bool force) {
     const uint32_t nbc = (uint32_t)nbc64;
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, a->device);
-    // candidate heights, tallest first: the tallest whose launch fills at least 92 % of its last round (or is long enough
-    // -- 6 rounds and more -- for the last round not to matter), else the best filled
-    auto strip_for = [&](uint32_t RB) {   // entries: the average tile + 30 %, a power of two, at least 1024
-        uint32_t S = 1024;
-        while (S < kCbStrip && (double)S < 1.3 * (double)RB * mean / (double)nbc + 64.0) S <<= 1;
-        return S;
+    // what the fullest tile of a height is expected to hold (before the tiles are counted): the average + five sigma of
+    // a Poisson count, in steps of 256 entries
+    auto strip_for = [&](uint32_t RB) {
+        const double avg = (double)RB * mean / (double)nbc;
+        return std::min(kCbStrip, std::max(512u, ((uint32_t)(avg + 5.0 * std::sqrt(avg) + 32.0) + 255u) & ~255u));
     };
     std::vector<uint32_t> cands;
     if (p.cblock_rows_user > 0) cands.push_back((uint32_t)p.cblock_rows_user);
@@ -112,15 +116,17 @@ int cblock_plan(spal_csr *a, bool force) {
         for (uint32_t RB : {4096u, 2048u, 1024u, 512u, 256u})     // 256 threads x 16 ... 1 rows each; the tallest whose tiles fit
             if ((double)RB * mean / (double)nbc <= 0.9 * (double)kCbStrip || RB == 256u) cands.push_back(RB);
     } else {
+        // entry form, tallest first: the tallest height whose workgroup fits half a CU's LDS and whose launch fills 98.5 % of
+        // its last round (or is 8 rounds and more long), else the best filled
         uint32_t best = 0;
         double best_eff = 0.0;
-        for (uint32_t RB = kCbMaxRows; RB >= 256; RB -= 128) {
-            if (1.3 * (double)RB * mean / (double)nbc + 64.0 > (double)kCbStrip) continue;   // the average tile would not fit
+        const uint32_t slots = 2u * (uint32_t)cus;
+        for (uint32_t RB = kCbMaxRows; RB >= 256; RB -= 8) {
+            if (cb_lds_bytes(RB, strip_for(RB), esz) > kCbLdsTwo) continue;
             if ((size_t)((a->nrows + RB - 1) / RB) * nbc * RB > (size_t)a->nnz * 12 && !force) continue;   // counts heavier than the entries
-            const uint32_t slots = (uint32_t)cus * cb_per_cu(cb_lds_bytes(RB, strip_for(RB), esz));
             const double rounds = (double)((a->nrows + RB - 1) / RB) / (double)slots;
             const double eff = rounds / std::ceil(rounds);
-            if (eff >= 0.92 || rounds >= 6.0) { cands.push_back(RB); break; }
+            if (eff >= 0.985 || rounds >= 8.0) { cands.push_back(RB); break; }
             if (eff > best_eff) { best_eff = eff; best = RB; }
         }
         if (cands.empty() && best) cands.push_back(best);
@@ -136,12 +142,11 @@ int cblock_plan(spal_csr *a, bool force) {
         if (too_long) break;                                   // a row with more than 255 entries in one column block
         uint32_t fullest = 0;
         for (uint32_t n : tile_n) fullest = std::max(fullest, n);
-        if (fullest <= kCbStrip) {
-            chosen = RB;
-            S = strip_for(RB);
-            while (S < fullest) S <<= 1;
-            break;
-        }
+        if (fullest > kCbStrip) continue;
+        S = std::max(512u, (fullest + 255u) & ~255u);         // (the strips are LDS: what the fullest tile needs, no more)
+        if (form == 0 && cb_lds_bytes(RB, S, esz) > (p.cblock_rows_user > 0 || force ? kCbLdsMax : kCbLdsTwo)) continue;
+        chosen = RB;
+        break;
     }
     if (getenv("SPAL_CBLOCK_DEBUG"))
         fprintf(stderr, "[spal cblock] %llu x %llu, %.2f per row, %s form, %u column blocks of 2^%u: %u rows per block, strip %u, %.2f entries per run%s\n",
@@ -183,12 +188,13 @@ int cblock_plan(spal_csr *a, bool force) {
 template <typename T>
 static hipError_t launch_cb(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     const CsrPlan &p = a->plan;
-    const size_t lds = cb_lds_bytes((uint32_t)p.cblock_rows, (uint32_t)p.cblock_strip, sizeof(T));
-    auto kern = csr_spmv_cblock<T, 8>;
+    // (padded: a request below a third of a CU's LDS would let a third workgroup in -- two measured best, csr_cblock.hpp)
+    const size_t lds = std::max(cb_lds_bytes((uint32_t)p.cblock_rows, (uint32_t)p.cblock_strip, sizeof(T)), kCbLdsPad);
+    auto kern = csr_spmv_cblock<T, 2, 8>;
     static std::atomic<uint64_t> configured{0};
     const uint64_t bit = 1ull << (a->device & 63);
-    if (lds > 48 * 1024 && !(configured.load(std::memory_order_relaxed) & bit)) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+    if (!(configured.load(std::memory_order_relaxed) & bit)) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCbLdsMax);
         if (e != hipSuccess) return e;
         configured.fetch_or(bit, std::memory_order_relaxed);
     }

@@ -1457,9 +1457,10 @@ def cblock():
     per_row = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     window = int(os.environ.get("LAB_WINDOW", "0")) or n          # (columns within a window this wide around the diagonal; default: anywhere)
     form = int(os.environ.get("LAB_FORM", "-1"))                  # cblock_form: -1 auto, 0 entry-parallel, 1 rows form
-    rp, ci, va = synth.banded_csr(n, n, per_row, window, synth.matrix_seed(2))
+    dt = np.float32 if os.environ.get("LAB_DTYPE", "f64") == "f32" else np.float64
+    rp, ci, va = synth.banded_csr(n, n, per_row, window, synth.matrix_seed(2), dtype=dt)
     d = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
-    x = torch.from_numpy(synth.vector(n)).cuda()
+    x = torch.from_numpy(synth.vector(n, dtype=dt)).cuda()
     y = torch.empty_like(x)
 
     def us(reps=30):
