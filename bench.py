@@ -328,8 +328,14 @@ def bench_coo(args):
                        "note": "algorithmic = lower bound 16*len + 12*nnz_out + 4*(nrows+1); a multi-pass sort "
                                "inherently moves several times this",
                        "route": d.describe()}
+    rd = csr.describe()
+    rb = synth.spmv_bytes(nnz, nr, nr, nr, esz)
     out["spmv_on_result"] = {"ms": round(spmv_ms, 6),
-                             "gflops": round(synth.spmv_flops(nnz) / (spmv_ms * 1e-3) / 1e9, 2)}
+                             "gflops": round(synth.spmv_flops(nnz) / (spmv_ms * 1e-3) / 1e9, 2),
+                             "kernel": "csr_spmv_" + rd["kernel"] + ("_rows" if rd.get("cblock_form") == "rows" else ""),
+                             "algorithmic_bytes_per_launch": rb, "roofline_frac": round(rb / (spmv_ms * 1e-3) / 8e12, 4),
+                             "traffic": traffic_entry("config5_result_spmv_f64") if args.dtype == "f64" else None,
+                             "plan": {k: rd.get(k) for k in ("cblock_form", "cblock_run", "cblock_rows", "cblock_cols", "cblock_col_blocks", "cblock_row_blocks")}}
     if not args.no_cpu_baseline:
         import oracle  # CPU baseline leg only
         sample = min(length, 50_000_000)   # the whole config-5 input: 5-15 s on one core
