@@ -136,7 +136,11 @@ int spal_csr_download_f32(spal_csr_t a, uint64_t *rowptr, uint64_t *colind,
  * do not read rowptr), "prefetch" (1 / 2 tiles of loads ahead), "place_tries"
  * (autotune), "split_tiles" (1 default / 0: the sliding kernel computes tiles
  * above 1024 entries whose halves fit in two passes instead of leaving them to
- * the overflow kernel) (stream kernel).  Unknown key or a value
+ * the overflow kernel), "xcd_chunk", "walk_blocks" (stream kernel); "cblock"
+ * (-1 auto / 0 / 1: the column-blocked kernels for columns anywhere),
+ * "cblock_form" (-1 by the entries a row holds per column block / 0 entry-
+ * parallel / 1 rows form), "cblock_rows", "cblock_shift" (0 auto; rows of a row
+ * block, log2 of the columns of a column block).  Unknown key or a value
  * the kernels are not instantiated for: SPAL_ERR_INVALID_ARGUMENT. */
 int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value);
 /* Setup-time autotune: runs the planned kernel's variants (the stream kernel
