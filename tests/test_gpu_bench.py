@@ -42,3 +42,14 @@ def test_bench_line_contract(config, flags):
     if config == 2:
         assert c["gpu_equals_cpu_bit_for_bit"] is True          # every row of the stream path: the reference's order
         assert d["setup_s"]["autotune"] >= 0 and "place_vectors" in d["setup_s"]
+
+
+def test_config5_record_carries_the_product_on_the_result():
+    """config 5's second half ("then SpMV"): the assembled 5M x 5M matrix has its columns anywhere, so the product runs
+    on the column-blocked kernel (entry-parallel form), and the record says so"""
+    d = run_bench("--config", "5", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    assert d["unit"] == "Mentries/s" and d["value"] > 0 and d["roofline"]["bound"] == "hbm"
+    s = d["spmv_on_result"]
+    assert s["kernel"] == "csr_spmv_cblock" and s["plan"]["cblock_form"] == "entry", s
+    assert s["ms"] > 0 and abs(s["roofline_frac"] - s["algorithmic_bytes_per_launch"] / (s["ms"] * 1e-3) / 8e12) < 1e-3
+    assert d["config"]["plan"]["kernel"] == "cblock", d["config"]["plan"]     # (built by the first product on the assembled handle)
