@@ -25,7 +25,7 @@ namespace spal {
 
 constexpr int kCbThreads = 256;
 constexpr uint32_t kCbStrip = 4096;      // most products of one tile (entries)
-constexpr uint32_t kCbMaxRows = 4096;    // most rows of a row block (their running sums: 32 KiB of f64)
+constexpr uint32_t kCbMaxRows = 8192;    // most rows of a row block (their running sums: 64 KiB of f64; the plan keeps a workgroup under half a CU's LDS)
 constexpr uint32_t kCbMaxBlocks = 128;   // column blocks per matrix
 
 __device__ __forceinline__ uint32_t cb_wave_inclusive_scan(uint32_t v, uint32_t lane) {

@@ -1925,8 +1925,8 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         p.cblock_user = (int)value;
         p.cblock_on = 1;
     } else if (!strcmp(key, "cblock_rows")) {
-        if (value < 0 || value > 4096)
-            return fail(SPAL_ERR_INVALID_ARGUMENT, "cblock_rows (rows of a row block of the column-blocked kernel) must be 0 (auto) or in [1, 4096]");
+        if (value < 0 || value > 8192)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "cblock_rows (rows of a row block of the column-blocked kernel) must be 0 (auto) or in [1, 8192]");
         p.cblock_rows_user = (int)value;
     } else if (!strcmp(key, "cblock_shift")) {
         if (value != 0 && (value < 8 || value > 24))

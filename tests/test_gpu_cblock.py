@@ -31,7 +31,7 @@ def random_rows(rng, nrows, ncols, lens, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("form, rows", [(0, 300), (0, 512), (0, 1000), (0, 2048), (0, 3333), (0, 4096),
+@pytest.mark.parametrize("form, rows", [(0, 300), (0, 512), (0, 1000), (0, 2048), (0, 3333), (0, 4096), (0, 6001), (0, 8192),
                                         (1, 256), (1, 512), (1, 1024), (1, 2048), (1, 4096)])
 def test_forced_geometries_bit_identical(oracle, dtype, form, rows):
     """Row-block heights from 300 to 4096 rows (multiples of the workgroup size or not), small column blocks (many tiles, empty tiles, tiles of one entry),

@@ -90,7 +90,7 @@ def test_random_matrices_all_planner_paths(oracle, seed):
         # ... and the column-blocked kernel forced on whatever this is (random row-block height and column-block width):
         # where the matrix qualifies (no row with more than 255 entries in one column block, every tile inside the strip)
         # its rows must equal the oracle's BIT FOR BIT, heavy rows, empty stretches and all
-        dev.set_option("cblock_rows", int(rng.choice([0, 256, 700, 1024, 3000, 4096])))
+        dev.set_option("cblock_rows", int(rng.choice([0, 256, 700, 1024, 3000, 4096, 5555, 8192])))
         dev.set_option("cblock_shift", int(rng.choice([0, 8, 11, 14, 17])))
         dev.set_option("cblock_form", int(rng.choice([-1, 0, 1])))      # (the rows form takes heights of 256 << k only: others fall to the stream kernels)
         dev.set_option("cblock", 1)
