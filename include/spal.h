@@ -148,12 +148,13 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value);
  * kernel on band-like plans, else the persistent form -- each with plain or
  * non-temporal y stores; the column-blocked kernel against the stream kernels
  * where the plan built both) `iters` times each on the caller's device vectors
- * and keeps the fastest; then copies the 16-bit column array into up to
- * "place_tries" (default 8) blocks of 1 GiB taken one after the other from the
+ * and keeps the fastest; then copies the 16-bit column array into
+ * "place_tries" (default 8; up to three times as many while none is 3 % better)
+ * blocks of 1 GiB taken one after the other from the
  * device's memory and keeps the place where the kernel ran fastest (two streams
  * out of one class of region disturb each other).  All variants
  * produce identical y.  Synchronises `stream`.  Cost at config 3 with
- * iters = 30: about 0.1 s. */
+ * iters = 30: 0.1 ... 0.15 s. */
 int spal_csr_autotune_f64(spal_csr_t a, const double *x_dev, double *y_dev,
                           void *stream, int iters);
 int spal_csr_autotune_f32(spal_csr_t a, const float *x_dev, float *y_dev,

@@ -1675,7 +1675,7 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
     // disturb each other, +12 us at config 3; out of two classes they do not): the columns are copied into blocks of
     // 1 GiB taken one after the other from the device's memory, the kernel is timed on each, the fastest place is kept
     // (round 2 re-allocated the 1.1 GB values array up to 12 times and, the candidates lying side by side in one
-    // region, often found nothing).  At most `place_tries` blocks (default 8: ~25 ms).
+    // region, often found nothing).  `place_tries` blocks (default 8: ~25 ms), up to three times as many while nothing better turns up.
     int tries = p.place_tries;
     if (const char *e = getenv("SPAL_PLACE_TRIES")) tries = atoi(e);
     const size_t cbytes = a->d_col16 ? (size_t)a->cap_entries * sizeof(uint16_t) : 0;
@@ -1688,7 +1688,10 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
         uint16_t *const original = a->d_col16;
         std::vector<void *> blocks;
         std::vector<float> ms_of;
-        for (int k = 0; k < tries && rc == SPAL_OK; ++k) {
+        // (no place 3 % better among the first `tries` blocks -- they may all lie in the class of region the walk started
+        //  in, the classes come in runs of GiBs --: it goes on, up to three times as far)
+        float best_seen = cur_ms;
+        for (int k = 0; rc == SPAL_OK && (k < tries || (k < 3 * tries && best_seen > 0.97f * cur_ms)); ++k) {
             void *b = nullptr;
             if (hipMalloc(&b, block) != hipSuccess) { (void)hipGetLastError(); break; }   // the device is full: what we have
             blocks.push_back(b);
@@ -1698,6 +1701,7 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
             float ms = 0.f;
             timed(n, &ms);
             ms_of.push_back(ms);
+            best_seen = std::min(best_seen, ms);
             ++a->place_tried;
         }
         int best = -1;
