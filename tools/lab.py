@@ -1561,6 +1561,39 @@ def cblock_once():
     print(d.describe())
 
 
+@lab
+def bands_auto():
+    """What the plan picks BY ITSELF for bands of 16 384 ... 262 144 columns (4M x 4M, 14 per row): kernel, form, us per product."""
+    import torch
+    import spalinalg_amd as sp
+    import spal_synth as synth
+    n = 4_000_000
+    for W in (16384, 32768, 65536, 262144):
+        rp, ci, va = synth.banded_csr(n, n, 14, W, synth.matrix_seed(2))
+        d = sp.CsrMatrix._trusted(n, n, rp, ci, va).device()
+        x = torch.from_numpy(synth.vector(n)).cuda()
+        y = torch.empty_like(x)
+
+        def us(reps=30):
+            for _ in range(5):
+                d.spmv_torch(x, out=y)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                d.spmv_torch(x, out=y)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e3
+        p = d.describe()
+        t = us()
+        d.set_option("cblock", 0)
+        t0 = us()
+        print(f"band of {W:7d} columns: {p['kernel']:7s} {p.get('cblock_form') or '-':6s} nonlocal rows {p['nonlocal_row_fraction']:.3f} panel tiles {p['panel_tiles']:6d}  {t:7.1f} us"
+              f"   (cblock = 0: {t0:7.1f} us)", flush=True)
+        del d
+
+
 def main():
     if len(sys.argv) < 2 or sys.argv[1] in ("--list", "-h", "--help") or sys.argv[1] not in LABS:
         for name, fn in sorted(LABS.items()):
