@@ -191,12 +191,14 @@ def bench_csc(args):
     out["roofline"] = {"bound": "hbm", "achieved": round(B / (ms * 1e-3) / 1e9, 2), "peak": 8000.0,
                        "unit": "GB/s", "frac": round(B / (ms * 1e-3) / 8e12, 4),
                        "traffic": traffic_entry("config4_scatter_f64") if args.dtype == "f64" else None,
-                       "kernel": "csc_spmv_scatter" + (" (neighbour hand-off: no memset, no global atomics)"
-                                                       if dev.describe().get("flush") == "neighbour_handoff" else " (+ y zero fill)"),
+                       "kernel": ("csc_spmv_rowtiles (LDS-privatised atomic scatter over row tiles: no memset, no global atomics, no hand-off)"
+                                  if dev.describe().get("row_tiles") else
+                                  "csc_spmv_scatter" + (" (neighbour hand-off: no memset, no global atomics)"
+                                                        if dev.describe().get("flush") == "neighbour_handoff" else " (+ y zero fill)")),
                        "kernel_ms": round(ms, 6),
                        "algorithmic_bytes_per_launch": B,
-                       "note": "LDS float atomics per entry; y rows stored once per super-tile, rows shared with the "
-                               "neighbouring super-tile updated behind a flag"}
+                       "note": "LDS float atomics per entry; row tiles: every row of y belongs to one workgroup and is stored once "
+                               "(column tiles, option row_tiles = 0: rows shared with the neighbouring super-tile updated behind a flag)"}
     out["transposed_route"] = {"ms_per_step": round(ms_transposed, 6),
                                "gflops": round(synth.spmv_flops(nnz) / (ms_transposed * 1e-3) / 1e9, 2),
                                "roofline_frac": round(B / (ms_transposed * 1e-3) / 8e12, 4),

@@ -374,6 +374,8 @@ static hipError_t csc_launch_c(const spal_csc *a, const void *x, void *y, hipStr
 
 template <typename T>
 static hipError_t csc_launch_t(spal_csc *a, const void *x, void *y, hipStream_t st) {
+    // row tiles where the plan built them: a workgroup owns rows of y outright -- no memset, no hand-off, no launch chain
+    if (a->rowtiles && a->rowtiles_user != 0 && a->flush == 0 && a->nnz) return launch_csc_rowtiles(a, x, y, st);
     const bool two_phase = a->flush == 1 && a->d_windows;
     const bool assign = two_phase && a->all_lds;   // the reduce writes every row of y: no memset
     hipError_t e = hipSuccess;
@@ -650,7 +652,7 @@ static int csc_plan_build(spal_csc *a) {
         SPAL_HIP_TRY(hipGetLastError());
     }
     SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
-    return SPAL_OK;
+    return csc_rowtiles_plan(a);
 }
 
 // CSC -> CSR on the device (stable sort of the entries by row), kept on the handle.
@@ -686,6 +688,7 @@ int csc_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, 
         (void)dev_free(a->d_meta); (void)dev_free(a->d_desc);
         (void)dev_free(a->d_windows); (void)dev_free(a->d_chunk_ptr); (void)dev_free(a->d_chunk_blk);
         (void)dev_free(a->d_prev_hi); (void)dev_free(a->d_flags);
+        csc_rowtiles_free(a);
         if (a->h_gave_up) (void)hipHostFree(a->h_gave_up);
         stream_release(a->stream);
         delete a;
@@ -716,6 +719,7 @@ static void csc_free(spal_csc *a) {
     (void)dev_free(a->d_chunk_blk);
     (void)dev_free(a->d_prev_hi);
     (void)dev_free(a->d_flags);
+    csc_rowtiles_free(a);
     if (a->ev_last) (void)hipEventDestroy(a->ev_last);
     if (a->h_gave_up) (void)hipHostFree(a->h_gave_up);
     (void)dev_free(a->d_x);
@@ -993,6 +997,12 @@ int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value) {
         a->use_ticket = (int)value;
         return SPAL_OK;
     }
+    if (!strcmp(key, "row_tiles")) {
+        // the scatter path over row tiles (spal_csc_rowtiles.hip): -1 / 1 = where every tile's window of x fits LDS, 0 = never
+        if (value < -1 || value > 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "row_tiles must be -1 (auto), 0 or 1");
+        a->rowtiles_user = (int)value;
+        return csc_rowtiles_plan(a);
+    }
     if (!strcmp(key, "lds")) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "lds must be 0 or 1");
         a->use_lds = (int)value;
@@ -1006,7 +1016,8 @@ int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len) {
              "{\"format\": \"csc\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"nnz\": %llu, "
              "\"kernel\": \"%s\", \"cols_per_block\": %d, \"blocks\": %u, \"lanes_per_col\": %d, "
              "\"lds_window_bytes\": %llu, \"lds_col_fraction\": %.4f, \"flush\": \"%s\", "
-             "\"window_store_bytes\": %llu, \"ticket\": %d, \"handoff_timeouts\": %d, \"uniform_columns\": %d}",
+             "\"window_store_bytes\": %llu, \"ticket\": %d, \"handoff_timeouts\": %d, \"uniform_columns\": %d, "
+             "\"row_tiles\": %d, \"row_tile_rows\": %u, \"row_tile_count\": %u, \"row_tile_x_window\": %u}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz,
              a->kernel == 2 ? "transposed_csr" : a->lds_entries ? "lds_privatised_scatter" : "atomic_scatter",
@@ -1016,7 +1027,8 @@ int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len) {
                                   : (a->flush == 0 && a->ordered) ? "neighbour_handoff" : "global_atomics",
              (unsigned long long)a->windows_entries * (unsigned long long)a->elem_size, a->use_ticket < 0 ? a->ticket_auto : a->use_ticket,
              a->handoff_timeouts + ((a->h_gave_up && __atomic_load_n(a->h_gave_up, __ATOMIC_RELAXED)) ? 1 : 0),
-             a->uniform_cols ? 1 : 0);
+             a->uniform_cols ? 1 : 0,
+             (a->rowtiles && a->rowtiles_user != 0 && a->flush == 0) ? 1 : 0, a->rt_rows, a->rt_ntiles, a->rt_xcap);
     return SPAL_OK;
 }
 

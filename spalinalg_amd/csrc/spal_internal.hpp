@@ -259,6 +259,15 @@ struct spal_csc {
     hipStream_t last_stream = nullptr;
     int last_stream_valid = 0;
     std::mutex mu_launch;          // ... chained under this lock
+    // row tiles (spal_csc_rowtiles.hip): the entries a second time, ordered (row tile, column, row) -- a workgroup owns rows
+    // of y outright, no hand-off; built where every tile's window of x fits LDS, and then the scatter path's default
+    int rowtiles = 0;              // the copy is built
+    int rowtiles_user = -1;        // option "row_tiles": -1 / 1 = where it qualifies, 0 = never (the column tiles run)
+    uint32_t rt_rows = 0, rt_ntiles = 0, rt_xcap = 0;   // rows of a tile, tiles, widest x window (elements)
+    void *d_rt_val = nullptr;      // nnz (+pad)
+    uint32_t *d_rt_meta = nullptr; // nnz (+pad): (row - tile's first row) | (col - window's first column) << 16
+    uint32_t *d_rt_ptr = nullptr;  // ntiles + 1
+    uint4 *d_rt_desc = nullptr;    // {first row, rows, first column of the x window, columns}
     int all_lds = 0;               // every super-tile with entries is in LDS mode: y needs no memset
     int cols_per_block = 1024;     // columns of a super-tile: 4096 / 2048 / 1024 (the widest whose row windows fit LDS)
     int user_cols = 0;             // option "cols_per_block" (0 = automatic)
@@ -300,6 +309,10 @@ int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream);
 hipError_t launch_slide(const spal_csr *a, const void *x, void *y, hipStream_t st);
 // ... and the column-panel kernel over a->d_ptiles
 hipError_t launch_panel(const spal_csr *a, const void *x, void *y, hipStream_t st);
+// implemented in spal_csc_rowtiles.hip: CSC scatter over row tiles
+int csc_rowtiles_plan(spal_csc *a);
+void csc_rowtiles_free(spal_csc *a);
+hipError_t launch_csc_rowtiles(const spal_csc *a, const void *x, void *y, hipStream_t st);
 // implemented in spal_csr_cblock.hip: the column-blocked kernel (tiled copy of the matrix, x slices kept in L2)
 int cblock_plan(spal_csr *a, bool force);
 void cblock_free(spal_csr *a);

@@ -69,7 +69,11 @@ def test_csc_transposed_kernel_is_bit_identical(oracle):
     y = dev.spmv(x)
     assert np.array_equal(y, oracle.csc_spmv(n, cp, ri, cv, x))
     dev.set_option("kernel", 1)
-    assert dev.describe()["kernel"] == "lds_privatised_scatter"
+    d = dev.describe()
+    assert d["kernel"] == "lds_privatised_scatter" and d["row_tiles"] == 1 and d["row_tile_rows"] == 4096, d
+    np.testing.assert_allclose(dev.spmv(x), y, rtol=1e-10, atol=1e-13)
+    dev.set_option("row_tiles", 0)
+    assert dev.describe()["row_tiles"] == 0
     np.testing.assert_allclose(dev.spmv(x), y, rtol=1e-10, atol=1e-13)
 
 
@@ -121,6 +125,7 @@ def test_csc_lds_and_global_paths(oracle):
     dev = m.device()
     assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10)        # default: transposed
     dev.set_option("kernel", 1)
+    dev.set_option("row_tiles", 0)                           # (this test is about the COLUMN tiles)
     d = dev.describe()
     assert d["kernel"] == "lds_privatised_scatter" and 0.8 < d["lds_col_fraction"] < 1.0
     assert d["flush"] == "global_atomics"                    # default: window rows flushed with atomics
@@ -180,6 +185,7 @@ def test_csc_neighbour_handoff_flush(oracle, dtype):
     bound = oracle.csr_abs_bound(rp, ci, va, x)
     dev = sp.CscMatrix(n, n, cp, ri, cv).device()
     dev.set_option("kernel", 1)
+    dev.set_option("row_tiles", 0)                           # (this test is about the COLUMN tiles)
     xt = torch.from_numpy(x).cuda()
     for cols in (0, 1024, 2048, 4096):
         dev.set_option("cols_per_block", cols)
@@ -247,6 +253,7 @@ def test_csc_handoff_tile_ids_by_ticket_or_block_index(oracle, ticket):
     cp, ri, cv, x, y_ref, bound = _band_csc(oracle, n)
     dev = sp.CscMatrix(n, n, cp, ri, cv).device()
     dev.set_option("kernel", 1)
+    dev.set_option("row_tiles", 0)                           # (this test is about the COLUMN tiles)
     dev.set_option("ticket", ticket)
     d = dev.describe()
     assert d["flush"] == "neighbour_handoff" and d["ticket"] == ticket and d["blocks"] > 512, d
@@ -276,6 +283,7 @@ def test_csc_handoff_backstop_is_reported(oracle, monkeypatch):
     # host-vector path
     dev = sp.CscMatrix(n, n, cp, ri, cv).device()
     dev.set_option("kernel", 1)
+    dev.set_option("row_tiles", 0)                           # (this test is about the COLUMN tiles)
     assert dev.describe()["flush"] == "neighbour_handoff"
     for _ in range(30):                              # (all super-tiles finish together: some find a flag missing soon)
         assert_spmv_close(dev.spmv(x), y_ref, bound, 1e-10)
@@ -287,6 +295,7 @@ def test_csc_handoff_backstop_is_reported(oracle, monkeypatch):
     # device path
     dev = sp.CscMatrix(n, n, cp, ri, cv).device()
     dev.set_option("kernel", 1)
+    dev.set_option("row_tiles", 0)                           # (this test is about the COLUMN tiles)
     xt = torch.from_numpy(x).cuda()
     yt = torch.empty(n, dtype=torch.float64, device="cuda")
     raised = False
@@ -316,6 +325,7 @@ def test_csc_handoff_not_taken_when_windows_interleave(oracle):
     x = synth.vector(n)
     dev = sp.CscMatrix(n, n, cp, ri, cv).device()
     dev.set_option("kernel", 1)
+    dev.set_option("row_tiles", 0)                           # (this test is about the COLUMN tiles)
     assert dev.describe()["flush"] == "global_atomics"
     assert_spmv_close(dev.spmv(x), oracle.csc_spmv(n, cp, ri, cv, x), oracle.csr_abs_bound(rp, ci, va, x), 1e-10)
 
@@ -354,6 +364,17 @@ def test_csc_scatter_randomised_bands(oracle, seed):
     dev = sp.CscMatrix(nrows, ncols, cp, ri, cv).device()
     dev.set_option("kernel", 1)
     xt = torch.from_numpy(x).cuda()
+    # the row tiles (the scatter path's default where every tile's window of x fits LDS) ...
+    if dev.describe()["row_tiles"]:
+        for _ in range(2):
+            yt = torch.full((nrows,), float("nan"), dtype=xt.dtype, device="cuda")
+            dev.spmv_torch(xt, yt)
+        torch.cuda.synchronize()
+        assert_spmv_close(yt.cpu().numpy(), y_ref, bound, tol)
+    if width <= 3000 and seed % 4 != 3:
+        assert dev.describe()["row_tiles"] == 1, dev.describe()
+    # ... and the column tiles
+    dev.set_option("row_tiles", 0)
     seen = set()
     for cols_opt in (0, 1024, 2048, 4096):
         dev.set_option("cols_per_block", cols_opt)
@@ -369,6 +390,76 @@ def test_csc_scatter_randomised_bands(oracle, seed):
     dev.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_csc_row_tiles(oracle, dtype):
+    """The scatter path over ROW tiles (a workgroup owns rows of y: no hand-off, no memset, no global atomics): a band with
+    empty rows at the head, in the middle and at the tail and a stretch of empty columns; y pre-filled with NaN; several
+    streams at once and a captured graph (nothing is shared between launches); tall columns disqualify the tiling."""
+    import torch
+    tol = 1e-10 if dtype == np.float64 else 1e-4
+    n = 300_000
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, 34, dtype=dtype)
+    keep = np.ones(n, bool)
+    keep[:700] = False
+    keep[150_000:159_000] = False                      # more than two whole row tiles without entries
+    keep[-1200:] = False
+    lens = np.diff(rp.astype(np.int64)) * keep
+    sel = np.repeat(keep, np.diff(rp.astype(np.int64)))
+    rp = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    ci, va = ci[sel], va[sel]
+    cp, ri, cv = oracle.transpose(n, n, rp, ci, va)
+    x = synth.vector(n, dtype=dtype)
+    y_ref = oracle.csc_spmv(n, cp, ri, cv, x)
+    bound = oracle.csr_abs_bound(rp, ci, va, x)
+    dev = sp.CscMatrix(n, n, cp, ri, cv).device()
+    dev.set_option("kernel", 1)
+    d = dev.describe()
+    assert d["row_tiles"] == 1 and d["row_tile_rows"] == 4096 and d["row_tile_x_window"] <= 8194, d
+    xt = torch.from_numpy(x).cuda()
+    yt = torch.full((n,), float("nan"), dtype=xt.dtype, device="cuda")
+    for _ in range(3):
+        dev.spmv_torch(xt, yt)
+    torch.cuda.synchronize()
+    y = yt.cpu().numpy()
+    assert_spmv_close(y, y_ref, bound, tol)
+    assert np.all(y[:700] == 0) and np.all(y[150_000:159_000] == 0) and np.all(y[-1200:] == 0)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    outs = [torch.full((n,), float("nan"), dtype=xt.dtype, device="cuda") for _ in streams]
+    torch.cuda.synchronize()
+    for _ in range(5):
+        for st, out in zip(streams, outs):
+            with torch.cuda.stream(st):
+                dev.spmv_torch(xt, out)
+    torch.cuda.synchronize()
+    for out in outs:
+        assert_spmv_close(out.cpu().numpy(), y_ref, bound, tol)
+    g = torch.cuda.CUDAGraph()
+    yg = torch.full((n,), float("nan"), dtype=xt.dtype, device="cuda")
+    with torch.cuda.graph(g):
+        dev.spmv_torch(xt, yg)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert_spmv_close(yg.cpu().numpy(), y_ref, bound, tol)
+    # smaller tiles where 4096 rows + their columns do not fit: a band of 14 000 columns (f64: 4096 + 18 000 > 20 352 elements)
+    rp2, ci2, va2 = synth.banded_csr(60_000, 60_000, 10, 14_000, 35, dtype=dtype)
+    cp2, ri2, cv2 = oracle.transpose(60_000, 60_000, rp2, ci2, va2)
+    x2 = synth.vector(60_000, dtype=dtype)
+    dev2 = sp.CscMatrix(60_000, 60_000, cp2, ri2, cv2).device()
+    dev2.set_option("kernel", 1)
+    d2 = dev2.describe()
+    assert d2["row_tiles"] == 1 and d2["row_tile_rows"] == (2048 if dtype == np.float64 else 4096), d2
+    assert_spmv_close(dev2.spmv(x2), oracle.csc_spmv(60_000, cp2, ri2, cv2, x2), oracle.csr_abs_bound(rp2, ci2, va2, x2), tol)
+    # columns anywhere: no tiling of the rows keeps its columns inside LDS
+    rp3, ci3, va3 = synth.banded_csr(100_000, 100_000, 8, 100_000, 36, dtype=dtype)
+    cp3, ri3, cv3 = oracle.transpose(100_000, 100_000, rp3, ci3, va3)
+    dev3 = sp.CscMatrix(100_000, 100_000, cp3, ri3, cv3).device()
+    dev3.set_option("kernel", 1)
+    assert dev3.describe()["row_tiles"] == 0
+    x3 = synth.vector(100_000, dtype=dtype)
+    assert_spmv_close(dev3.spmv(x3), oracle.csc_spmv(100_000, cp3, ri3, cv3, x3), oracle.csr_abs_bound(rp3, ci3, va3, x3), tol)
+
+
 def test_csc_config4(oracle):
     """BASELINE config 4: CSC of the config-2 matrix, 1M x 1M."""
     n = 1_000_000
@@ -377,9 +468,14 @@ def test_csc_config4(oracle):
     x = synth.vector(n)
     m = sp.CscMatrix(n, n, cp, ri, cv)
     m.device().set_option("kernel", 1)          # the atomic scatter path config 4 names
+    d = m.device().describe()
+    assert d["row_tiles"] == 1 and d["row_tile_rows"] == 4096 and d["row_tile_count"] == 245, d   # rows of y owned by one workgroup each
     y = m * x
     y_ref = oracle.csc_spmv(n, cp, ri, cv, x)
     assert_spmv_close(y, y_ref, oracle.csr_abs_bound(rp, ci, va, x), 1e-10)
+    m.device().set_option("row_tiles", 0)       # the column tiles with their neighbour hand-off
+    assert m.device().describe()["flush"] == "neighbour_handoff"
+    assert_spmv_close(m * x, y_ref, oracle.csr_abs_bound(rp, ci, va, x), 1e-10)
     assert m.device().describe()["lds_col_fraction"] > 0.99
     assert m.device().describe()["cols_per_block"] == 4096      # the band's windows fit beside 4096 columns of x
     m.device().set_option("flush", 1)           # windows + ordered reduce (writes y without a memset here)
@@ -387,8 +483,11 @@ def test_csc_config4(oracle):
     m.device().set_option("flush", 0)
     m32 = sp.CscMatrix(n, n, cp, ri, cv.astype(np.float32))
     m32.device().set_option("kernel", 1)
+    assert m32.device().describe()["row_tiles"] == 1
     y32 = m32 * x.astype(np.float32)
     assert_spmv_close(y32, y_ref, oracle.csr_abs_bound(rp, ci, va, x), 1e-4)
+    m32.device().set_option("row_tiles", 0)
+    assert_spmv_close(m32 * x.astype(np.float32), y_ref, oracle.csr_abs_bound(rp, ci, va, x), 1e-4)
     with pytest.raises(sp.Panic):
         m * np.ones(n - 1)
 
