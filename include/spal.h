@@ -210,12 +210,16 @@ int spal_csc_download_f64(spal_csc_t a, uint64_t *colptr, uint64_t *rowind,
                           double *values);
 int spal_csc_download_f32(spal_csc_t a, uint64_t *colptr, uint64_t *rowind,
                           float *values);
-/* Keys: "kernel" 1 = atomic scatter (LDS-privatised where the row window of a
+/* Keys: "kernel" 1 = atomic scatter (over ROW tiles where every tile's window
+ * of x fits LDS beside its rows -- a workgroup owns rows of y, nothing is shared
+ * between workgroups or launches; "row_tiles" -1 auto / 0 / 1 --, else over
+ * column tiles: LDS-privatised where the row window of a
  * 1024-column block fits LDS, global atomics otherwise), 2 = transposed: the
  * matrix is converted to CSR on the device once and the CSR kernels run
  * (deterministic; bit-identical to the reference's k-ascending order), 0 = auto
  * (= 2).  "lds" 0/1, "cols_per_block" (0 auto / 1024 / 2048 / 4096 columns per
- * super-tile), "flush" tune kernel 1.  flush 0 (default): where the super-tiles'
+ * super-tile), "flush" tune kernel 1's column tiles (a flush other than 0 also
+ * selects them).  flush 0 (default): where the super-tiles'
  * row windows ascend and overlap their neighbours' only (bands), every row of y
  * is stored by the first super-tile that covers it and completed by the next one
  * behind a flag -- no zero fill of y, no global atomics; launches of one handle
