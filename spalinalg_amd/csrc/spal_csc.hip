@@ -1003,6 +1003,12 @@ int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value) {
         a->rowtiles_user = (int)value;
         return csc_rowtiles_plan(a);
     }
+    if (!strcmp(key, "row_tile_rows")) {
+        if (value != 0 && value != 1024 && value != 2048 && value != 4096)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "row_tile_rows must be 0 (auto), 1024, 2048 or 4096");
+        a->rt_rows_user = (uint32_t)value;
+        return csc_rowtiles_plan(a);
+    }
     if (!strcmp(key, "lds")) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "lds must be 0 or 1");
         a->use_lds = (int)value;

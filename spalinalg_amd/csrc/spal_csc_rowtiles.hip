@@ -177,6 +177,7 @@ static int rowtiles_plan_t(spal_csc *a) {
     if (a->nnz == 0 || a->rowtiles_user == 0 || !a->use_lds) return SPAL_OK;
     const size_t budget = ((size_t)159 * 1024) / sizeof(T);   // elements of x window + rows (one workgroup per CU)
     for (uint32_t RT : {4096u, 2048u, 1024u}) {
+        if (a->rt_rows_user && RT != a->rt_rows_user) continue;
         const uint32_t nt = (uint32_t)((a->nrows + RT - 1) / RT);
         uint32_t *d_s = nullptr;   // cmin | cmax | cnt | flag
         SPAL_HIP_TRY(dev_alloc((void **)&d_s, ((size_t)3 * nt + 1) * 4));

@@ -264,6 +264,7 @@ struct spal_csc {
     int rowtiles = 0;              // the copy is built
     int rowtiles_user = -1;        // option "row_tiles": -1 / 1 = where it qualifies, 0 = never (the column tiles run)
     uint32_t rt_rows = 0, rt_ntiles = 0, rt_xcap = 0;   // rows of a tile, tiles, widest x window (elements)
+    uint32_t rt_rows_user = 0;     // option "row_tile_rows": 0 = the tallest of 4096 / 2048 / 1024 that fits
     void *d_rt_val = nullptr;      // nnz (+pad)
     uint32_t *d_rt_meta = nullptr; // nnz (+pad): (row - tile's first row) | (col - window's first column) << 16
     uint32_t *d_rt_ptr = nullptr;  // ntiles + 1
