@@ -158,7 +158,7 @@ def bench_csc(args):
     m = sp.CscMatrix(n, n, cp, ri, cv)
     # 188 MB of matrix + vectors would sit in the 256 MB Infinity Cache: rotate over copies
     copies = args.copies if args.copies > 0 else 3
-    devs = [m.device() for _ in range(copies)]
+    devs = [m.device()] + [m.device_copy() for _ in range(copies - 1)]   # (handles with arrays of their own)
     for d in devs:
         for kv in args.opt:
             k, v = kv.split("=")
@@ -726,7 +726,7 @@ def main():
     single = [lambda: dev.spmv_torch(x, out=y)]     # y is the rank's (= the whole) slice
     keep = []
     for _ in range(copies - 1):
-        d2 = shard.device(local_rank)
+        d2 = shard.device_copy(local_rank)            # (a handle with arrays of its own)
         for kv in args.opt:
             k, v = kv.split("=")
             d2.set_option(k, int(v))

@@ -427,6 +427,16 @@ class _Compressed:
             self._dev[device] = h
         return h
 
+    def device_copy(self, device: int = 0):
+        """ANOTHER device-resident copy with arrays of its own, not cached on the matrix (benchmarks rotate their
+        launches over several, so that a matrix smaller than the 256 MB Infinity Cache is not served from it)."""
+        out = vp()
+        check(getattr(_ffi.lib(), f"spal_{self._kind}_create_{_sfx(self.dtype)}")(
+            C.c_int(device), u64(self._nrows), u64(self._ncols), _p(self._ptr),
+            u64(self._ptr.size), _p(self._ind), u64(self._ind.size), _p(self._values),
+            u64(self._values.size), C.byref(out)))
+        return self._dev_cls(out, self.dtype, device)
+
     def _mul_vec(self, x):
         x = np.asarray(x)
         if x.ndim != 1:
