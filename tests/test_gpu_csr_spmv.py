@@ -1097,3 +1097,19 @@ def test_handle_owned_vectors(oracle):
     dev.spmv_torch(x, out=y)
     torch.cuda.synchronize()
     assert np.array_equal(y.cpu().numpy(), oracle.csr_spmv(rp, ci, va, xh))
+
+
+def test_device_copy_is_a_handle_of_its_own(oracle):
+    """`device()` caches ONE handle per matrix and device; `device_copy()` uploads again -- what a benchmark rotates its
+    launches over, so that a matrix below the Infinity Cache's 256 MB is not served from it (bench.py, configs 2 and 4)."""
+    n = 50_000
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, 3)
+    a = sp.CsrMatrix(n, n, rp, ci, va)
+    x = synth.vector(n)
+    d0, d1, d2 = a.device(), a.device(), a.device_copy()
+    assert d0 is d1 and d2 is not d0
+    assert d2.describe()["addr"] != d0.describe()["addr"]          # (its arrays lie elsewhere)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    assert np.array_equal(d0.spmv(x), y_ref) and np.array_equal(d2.spmv(x), y_ref)
+    d2.close()
+    assert np.array_equal(a.device().spmv(x), y_ref)               # the cached handle is untouched
