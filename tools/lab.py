@@ -1594,6 +1594,43 @@ def bands_auto():
         del d
 
 
+@lab
+def tiny():
+    """BASELINE config 1 (10k x 10k, 100k triplets): the product on the assembled matrix, per plan form (us per launch)."""
+    import torch
+    import spalinalg_amd as sp
+    import spal_synth as synth
+    cfg = synth.CONFIGS[1]
+    nr, nc, length = cfg["nrows"], cfg["ncols"], cfg["length"]
+    r, c, v = synth.coo(nr, nc, length, synth.matrix_seed(1))
+    csr = sp.CooMatrix.with_triplets(nr, nc, r, c, v).upload().assemble_csr()
+    x = torch.from_numpy(synth.vector(nc)).cuda()
+    y = torch.empty(nr, dtype=x.dtype, device="cuda")
+
+    def us(reps=200):
+        for _ in range(20):
+            csr.spmv_torch(x, out=y)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            csr.spmv_torch(x, out=y)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+    print("default plan:", {k: csr.describe()[k] for k in ("kernel", "slide", "rows_per_tile", "blocks", "persistent", "lds_x")}, f"{us():.2f} us")
+    for opts in ([("tiles_per_wave", 2)], [("tiles_per_wave", 1)], [("slide_on", 0)], [("slide_on", 0), ("tiles_per_wave", 1), ("rows_per_tile", 64)], [("rows_per_tile", 16)], [("tiles_per_wave", 4), ("slide_on", 0), ("rows_per_tile", 32)], [("slide_on", 0), ("rows_per_tile", 16)], [("slide_on", 0), ("rows_per_tile", 8)],
+                 [("kernel", 1)], [("kernel", 1), ("lanes_per_row", 8)], [("kernel", 1), ("lanes_per_row", 4), ("rows_per_block", 512)]):
+        try:
+            for k, val in opts:
+                csr.set_option(k, val)
+        except Exception as e:  # noqa: BLE001
+            print(opts, "rejected:", e)
+            continue
+        d = csr.describe()
+        print(opts, {k: d[k] for k in ("kernel", "slide", "rows_per_tile", "blocks", "lanes_per_row")}, f"{us():.2f} us", flush=True)
+
+
 def main():
     if len(sys.argv) < 2 or sys.argv[1] in ("--list", "-h", "--help") or sys.argv[1] not in LABS:
         for name, fn in sorted(LABS.items()):
