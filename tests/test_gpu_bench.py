@@ -53,3 +53,12 @@ def test_config5_record_carries_the_product_on_the_result():
     assert s["kernel"] == "csr_spmv_cblock" and s["plan"]["cblock_form"] == "entry", s
     assert s["ms"] > 0 and abs(s["roofline_frac"] - s["algorithmic_bytes_per_launch"] / (s["ms"] * 1e-3) / 8e12) < 1e-3
     assert d["config"]["plan"]["kernel"] == "cblock", d["config"]["plan"]     # (built by the first product on the assembled handle)
+
+
+def test_config4_record_is_the_scatter_path_over_row_tiles():
+    """config 4 names the atomic scatter path: `value` is that path (over row tiles on this band), the transposed route is
+    reported beside it and agrees; the launches rotate over handles that own their arrays"""
+    d = run_bench("--config", "4", "--steps", "50", "--warmup", "5", "--cpu-seconds", "1")
+    assert d["roofline"]["kernel"].startswith("csc_spmv_rowtiles") and d["config"]["plan"]["row_tiles"] == 1, d["roofline"]
+    assert d["transposed_route"]["agrees_with_scatter"] is True and d["cpu_baseline"]["gpu_agrees_with_cpu"] is True
+    assert "3 independent copies" in d["config"]["workload"]
