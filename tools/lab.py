@@ -1631,6 +1631,56 @@ def tiny():
         print(opts, {k: d[k] for k in ("kernel", "slide", "rows_per_tile", "blocks", "lanes_per_row")}, f"{us():.2f} us", flush=True)
 
 
+@lab
+def csc_big():
+    """CSC scatter over row tiles on a larger band (default 20M x 20M, 14 per row: 280M entries, 78K tiles): against the
+    transposed route (bit-identical to the reference's order) and per launch -- `lab.py csc_big [n]`."""
+    import numpy as np
+    import scipy.sparse as sps
+    import torch
+    import spalinalg_amd as sp
+    import spal_synth as synth
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, synth.matrix_seed(2))
+    csc = sps.csr_matrix((va, ci.astype(np.int64), rp.astype(np.int64)), shape=(n, n)).tocsc()
+    csc.sort_indices()
+    d = sp.CscMatrix(n, n, csc.indptr.astype(np.uint64), csc.indices.astype(np.uint64), csc.data).device()
+    x = torch.from_numpy(synth.vector(n)).cuda()
+    y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+
+    def us(reps=20):
+        for _ in range(3):
+            d.spmv_torch(x, out=y)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            d.spmv_torch(x, out=y)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+    B = synth.spmv_bytes(int(rp[-1]), n, n, n, 8)
+    t2 = us()
+    y2 = y.clone()
+    d.set_option("kernel", 1)
+    p = d.describe()
+    t1 = us()
+    print(f"{n} x {n}, {int(rp[-1])} entries: transposed route {t2:8.1f} us = {B / t2 / 8e6:.3f}; scatter over row tiles ({p['row_tiles']}, {p['row_tile_count']} tiles of "
+          f"{p['row_tile_rows']} rows, x window {p['row_tile_x_window']}) {t1:8.1f} us = {B / t1 / 8e6:.3f}; max |diff| / max |y| = "
+          f"{float((y - y2).abs().max() / y2.abs().max()):.2e}")
+    for rows in (2048, 1024):
+        d.set_option("row_tile_rows", rows)
+        p = d.describe()
+        y.fill_(float("nan"))
+        t = us()
+        print(f"  row tiles of {p['row_tile_rows']} rows ({p['row_tile_count']} tiles, x window {p['row_tile_x_window']}): {t:8.1f} us = {B / t / 8e6:.3f}; "
+              f"max |diff| / max |y| = {float((y - y2).abs().max() / y2.abs().max()):.2e}")
+    d.set_option("row_tiles", 0)
+    y.fill_(float("nan"))
+    t0 = us()
+    print(f"  column tiles ({d.describe()['flush']}): {t0:8.1f} us = {B / t0 / 8e6:.3f}; max |diff| / max |y| = {float((y - y2).abs().max() / y2.abs().max()):.2e}")
+
+
 def main():
     if len(sys.argv) < 2 or sys.argv[1] in ("--list", "-h", "--help") or sys.argv[1] not in LABS:
         for name, fn in sorted(LABS.items()):
