@@ -162,38 +162,51 @@ constexpr int kHistThreads = 256;
 constexpr int kHistItems = kSortTile / kHistThreads;
 
 // counts[d * nblk + blk] = number of keys of tile blk with digit d
-// (the order inside the tile does not matter here: 16-byte loads, 4 keys per lane)
+// (the order inside the tile does not matter here: 16-byte loads, 4 keys per lane).  A workgroup counts kHistGroup
+// consecutive tiles and writes, per digit, their counts as ONE run of kHistGroup words: the digit-major layout the scan
+// wants puts the counts of one tile 4 * nblk bytes apart, and one tile per workgroup wrote 107 MB for 12.5 MB of counts
+// at config 5 (profiles/r03/pmc_traffic.txt).
+constexpr int kHistGroup = 16;
 __global__ __launch_bounds__(kHistThreads) void radix_hist(const uint32_t *__restrict__ keys,
                                                            uint64_t len, uint32_t shift,
                                                            uint32_t *__restrict__ counts,
                                                            uint32_t nblk) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    __shared__ uint32_t h[kHistGroup][257];   // (257: the transposed read below walks a column)
+    for (int j = 0; j < kHistGroup; ++j) h[j][threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t t0 = (uint64_t)blockIdx.x * kSortTile;  // multiple of 4: 16-byte aligned
+    const uint32_t blk0 = blockIdx.x * kHistGroup;
     static_assert(kSortTile % (4 * kHistThreads) == 0, "tile = whole rounds of 4 keys per thread");
-    if (t0 + kSortTile <= len) {
-        u32x4 k[kHistItems / 4];
+    for (int g = 0; g < kHistGroup; ++g) {   // uniform
+        const uint32_t blk = blk0 + (uint32_t)g;
+        if (blk >= nblk) break;
+        const uint64_t t0 = (uint64_t)blk * kSortTile;  // multiple of 4: 16-byte aligned
+        if (t0 + kSortTile <= len) {
+            u32x4 k[kHistItems / 4];
 #pragma unroll
-        for (int j = 0; j < kHistItems / 4; ++j)
-            k[j] = *reinterpret_cast<const u32x4 *>(keys + t0 + ((uint64_t)j * kHistThreads + threadIdx.x) * 4);
+            for (int j = 0; j < kHistItems / 4; ++j)
+                k[j] = *reinterpret_cast<const u32x4 *>(keys + t0 + ((uint64_t)j * kHistThreads + threadIdx.x) * 4);
 #pragma unroll
-        for (int j = 0; j < kHistItems / 4; ++j) {
-            atomicAdd(&h[(k[j].x >> shift) & 0xffu], 1u);
-            atomicAdd(&h[(k[j].y >> shift) & 0xffu], 1u);
-            atomicAdd(&h[(k[j].z >> shift) & 0xffu], 1u);
-            atomicAdd(&h[(k[j].w >> shift) & 0xffu], 1u);
-        }
-    } else {
+            for (int j = 0; j < kHistItems / 4; ++j) {
+                atomicAdd(&h[g][(k[j].x >> shift) & 0xffu], 1u);
+                atomicAdd(&h[g][(k[j].y >> shift) & 0xffu], 1u);
+                atomicAdd(&h[g][(k[j].z >> shift) & 0xffu], 1u);
+                atomicAdd(&h[g][(k[j].w >> shift) & 0xffu], 1u);
+            }
+        } else {
 #pragma unroll
-        for (int j = 0; j < kHistItems; ++j) {
-            const uint64_t i = t0 + (uint64_t)j * kHistThreads + threadIdx.x;
-            if (i < len) atomicAdd(&h[(keys[i] >> shift) & 0xffu], 1u);
+            for (int j = 0; j < kHistItems; ++j) {
+                const uint64_t i = t0 + (uint64_t)j * kHistThreads + threadIdx.x;
+                if (i < len) atomicAdd(&h[g][(keys[i] >> shift) & 0xffu], 1u);
+            }
         }
     }
     __syncthreads();
-    counts[(uint64_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+    // sixteen lanes write one digit's run of sixteen counts (64 contiguous bytes), a wave four digits' runs
+    const uint32_t n = min((uint32_t)kHistGroup, nblk - blk0);
+    const uint32_t g = threadIdx.x % kHistGroup;
+    for (uint32_t d = threadIdx.x / kHistGroup; d < 256; d += kHistThreads / kHistGroup)
+        if (g < n) counts[(uint64_t)d * nblk + blk0 + g] = h[g][d];
 }
 
 // Stable scatter of one tile.  Wave w owns the tile's entries [w*1024, (w+1)*1024)
@@ -354,8 +367,8 @@ static hipError_t radix_sort_bits(SortBuffers<T> &b, uint64_t len, uint32_t lo_b
         const int dst = k_in ? cur : (cur ^ 1);
         const uint32_t *offs = b.counts;
         {
-            hipLaunchKernelGGL(radix_hist, dim3(nblk), dim3(kHistThreads), 0, st, ki, len, shift, b.counts,
-                               nblk);
+            hipLaunchKernelGGL(radix_hist, dim3((nblk + kHistGroup - 1) / kHistGroup), dim3(kHistThreads), 0, st, ki, len, shift,
+                               b.counts, nblk);
             hipError_t e = exclusive_scan_u32(b.counts, b.counts, ncounts, b.sums, nullptr, st);
             if (e != hipSuccess) return e;
         }
