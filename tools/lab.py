@@ -1619,7 +1619,7 @@ def tiny():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps * 1e3
     print("default plan:", {k: csr.describe()[k] for k in ("kernel", "slide", "rows_per_tile", "blocks", "persistent", "lds_x")}, f"{us():.2f} us")
-    for opts in ([("tiles_per_wave", 2)], [("tiles_per_wave", 1)], [("slide_on", 0)], [("slide_on", 0), ("tiles_per_wave", 1), ("rows_per_tile", 64)], [("rows_per_tile", 16)], [("tiles_per_wave", 4), ("slide_on", 0), ("rows_per_tile", 32)], [("slide_on", 0), ("rows_per_tile", 16)], [("slide_on", 0), ("rows_per_tile", 8)],
+    for opts in ([("window_pages", 8)], [("window_pages", 8), ("rows_per_tile", 16)], [("window_pages", 8), ("rows_per_tile", 8)], [("window_pages", 0), ("rows_per_tile", 0), ("slide_on", 0)], [("slide_on", 0), ("tiles_per_wave", 1), ("rows_per_tile", 64)], [("rows_per_tile", 16)], [("tiles_per_wave", 4), ("slide_on", 0), ("rows_per_tile", 32)], [("slide_on", 0), ("rows_per_tile", 16)], [("slide_on", 0), ("rows_per_tile", 8)],
                  [("kernel", 1)], [("kernel", 1), ("lanes_per_row", 8)], [("kernel", 1), ("lanes_per_row", 4), ("rows_per_block", 512)]):
         try:
             for k, val in opts:
