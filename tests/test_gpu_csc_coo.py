@@ -819,3 +819,19 @@ def test_full_size_config5_properties():
     a2 = dcoo.assemble_csr()
     rp3, ci3, va3 = a2.download()
     assert np.array_equal(rp3, rp) and np.array_equal(ci3, ci) and np.array_equal(va3.view(np.uint64), va.view(np.uint64))
+
+
+def test_csc_handle_converted_on_the_device_scatters_over_row_tiles(oracle):
+    """CSR -> CSC on the device (`DeviceCsr.to_csc`: the handle adopts the converted arrays) and the scatter path on the
+    result: the row tiles are planned for adopted handles as for uploaded ones."""
+    n = 200_000
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, 41)
+    x = synth.vector(n)
+    dcsc = sp.CsrMatrix(n, n, rp, ci, va).device().to_csc()
+    dcsc.set_option("kernel", 1)
+    d = dcsc.describe()
+    assert d["row_tiles"] == 1 and d["row_tile_rows"] == 4096, d
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    assert_spmv_close(dcsc.spmv(x), y_ref, oracle.csr_abs_bound(rp, ci, va, x), 1e-10)
+    dcsc.set_option("row_tiles", 0)
+    assert_spmv_close(dcsc.spmv(x), y_ref, oracle.csr_abs_bound(rp, ci, va, x), 1e-10)
