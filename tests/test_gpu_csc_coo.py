@@ -450,6 +450,13 @@ def test_csc_row_tiles(oracle, dtype):
     d2 = dev2.describe()
     assert d2["row_tiles"] == 1 and d2["row_tile_rows"] == (2048 if dtype == np.float64 else 4096), d2
     assert_spmv_close(dev2.spmv(x2), oracle.csc_spmv(60_000, cp2, ri2, cv2, x2), oracle.csr_abs_bound(rp2, ci2, va2, x2), tol)
+    for rows in (1024, 2048, 0):                      # the height as an option; 0 = the tallest that fits again
+        dev2.set_option("row_tile_rows", rows)
+        d2 = dev2.describe()
+        assert d2["row_tiles"] == 1 and (rows == 0 or d2["row_tile_rows"] == rows), d2
+        assert_spmv_close(dev2.spmv(x2), oracle.csc_spmv(60_000, cp2, ri2, cv2, x2), oracle.csr_abs_bound(rp2, ci2, va2, x2), tol)
+    with pytest.raises(sp.Panic):
+        dev2.set_option("row_tile_rows", 3000)
     # columns anywhere: no tiling of the rows keeps its columns inside LDS
     rp3, ci3, va3 = synth.banded_csr(100_000, 100_000, 8, 100_000, 36, dtype=dtype)
     cp3, ri3, cv3 = oracle.transpose(100_000, 100_000, rp3, ci3, va3)
