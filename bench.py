@@ -1113,14 +1113,14 @@ def main():
                     el = time.perf_counter() - t0
                     if el >= min(args.cpu_seconds, 4.0) or passes >= 50:
                         break
-            out["cpu_baseline_all_cores"] = {
+            out["cpu_baseline_threads"] = {
                 "value": round(synth.spmv_flops(nnz) * passes / el / 1e9, 4), "unit": "GFLOP/s",
-                "cores": threads, "kind": "port",
+                "cores": threads, "host_threads_available": len(os.sched_getaffinity(0)), "kind": "port",
                 "sample": f"{passes} full passes in {el:.1f} s, {threads} threads, one row range each "
                           f"(informational: the reference has no threads)",
                 "same_result_as_1_thread": bool(np.array_equal(y_mt, yh))}
         except Exception as exc:  # noqa: BLE001  (informational only)
-            out["cpu_baseline_all_cores"] = {"error": str(exc)}
+            out["cpu_baseline_threads"] = {"error": str(exc)}
     if (world == 1 and args.config == 3 and args.dist == "banded" and args.dtype == "f64" and not args.opt
             and not args.no_other_configs):
         # the driver runs only this default line: every other BASELINE config rides along as a compact record

@@ -1226,21 +1226,30 @@ static int coo_upload(int device, uint64_t nrows, uint64_t ncols, uint64_t len, 
     // CooMatrix::new asserts (src/coo.rs:105-106)
     if (!(nrows > 0)) return fail(SPAL_ERR_INVARIANT, "CooMatrix::new would panic: assertion failed: nrows > 0");
     if (!(ncols > 0)) return fail(SPAL_ERR_INVARIANT, "CooMatrix::new would panic: assertion failed: ncols > 0");
-    if (nrows >= 0xffffffffull || ncols > 0xffffffffull || len > kMaxEntries)
-        return fail(SPAL_ERR_UNSUPPORTED, "COO shape does not fit 32-bit device indices");
+    // A COO handle assembles to CSR (pointer array over nrows + 1) and to CSC (over ncols + 1): whichever becomes
+    // the MAJOR dimension needs dim + 1 to fit 32 bits, so both are bounded alike here (spal_csr_create / spal_csc_create
+    // know their major dimension and allow the minor one to be exactly 2^32 - 1).
+    if (nrows >= 0xffffffffull || ncols >= 0xffffffffull || len > kMaxEntries)
+        return fail(SPAL_ERR_UNSUPPORTED, "COO shape does not fit 32-bit device indices (nrows, ncols < 2^32 - 1)");
     // every entry inside the matrix (push asserts, src/coo.rs:432-433)
     std::vector<uint32_t> r32(len), c32(len);
-    std::vector<int> bad(host_threads(), 0);
+    std::vector<uint64_t> bad(host_threads(), UINT64_MAX);  // first offending entry of every thread's range
     parallel_for(len, [&](uint64_t b, uint64_t e, unsigned t) {
         for (uint64_t i = b; i < e; ++i) {
-            if (rows[i] >= nrows || cols[i] >= ncols) { bad[t] = 1; return; }
+            if (rows[i] >= nrows || cols[i] >= ncols) { bad[t] = i; return; }
             r32[i] = (uint32_t)rows[i];
             c32[i] = (uint32_t)cols[i];
         }
     });
-    for (int f : bad)
-        if (f) return fail(SPAL_ERR_INDEX_OUT_OF_BOUNDS,
-                           "CooMatrix::push would panic: assertion failed: row < nrows && col < ncols");
+    uint64_t first_bad = UINT64_MAX;
+    for (uint64_t f : bad) first_bad = std::min(first_bad, f);
+    if (first_bad != UINT64_MAX) {  // the entry a sequence of push() calls would have panicked on (row is asserted first)
+        const bool row_bad = rows[first_bad] >= nrows;
+        return fail(SPAL_ERR_INDEX_OUT_OF_BOUNDS,
+                    "CooMatrix::push would panic: assertion failed: %s (entry %llu: %s %llu)",
+                    row_bad ? "row < nrows" : "col < ncols", (unsigned long long)first_bad, row_bad ? "row" : "col",
+                    (unsigned long long)(row_bad ? rows[first_bad] : cols[first_bad]));
+    }
     DeviceGuard guard(device);
     if (guard.status != SPAL_OK) return guard.status;
     spal_coo *c = new spal_coo;

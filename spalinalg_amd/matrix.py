@@ -587,9 +587,9 @@ class CooMatrix:
         if cols.size != vals.size:
             raise Panic(_ffi.SPAL_ERR_INVARIANT, "assertion failed: colind.len() == values.len()")
         if rows.size and int(rows.max()) >= self._nrows:
-            raise Panic(_ffi.SPAL_ERR_INDEX_OUT_OF_BOUNDS, "assertion failed: *row < nrows")
+            raise Panic(_ffi.SPAL_ERR_INDEX_OUT_OF_BOUNDS, "assertion failed: *row < nrows (row < nrows)")
         if cols.size and int(cols.max()) >= self._ncols:
-            raise Panic(_ffi.SPAL_ERR_INDEX_OUT_OF_BOUNDS, "assertion failed: *col < ncols")
+            raise Panic(_ffi.SPAL_ERR_INDEX_OUT_OF_BOUNDS, "assertion failed: *col < ncols (col < ncols)")
         self._rows, self._cols, self._vals = rows, cols, vals
         return self
 

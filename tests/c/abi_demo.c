@@ -32,6 +32,28 @@ int main(int argc, char **argv) {
         fprintf(stderr, "validation did not reject unsorted columns (reason %d)\n", reason);
         return 1;
     }
+    {   /* KAT G9 (src/coo.rs:876-886, 1000-1012): entries outside the matrix are refused by the ABI itself,
+         * before any device is touched */
+        const uint64_t r_bad[1] = {1}, c_ok[1] = {0}, r_ok[1] = {0}, c_bad[1] = {1};
+        const double one[1] = {1.0};
+        spal_coo_t coo = NULL;
+        spal_csr_t csr = NULL;
+        if (spal_coo_upload_f64(0, 1, 1, 1, r_bad, c_ok, one, &coo) != SPAL_ERR_INDEX_OUT_OF_BOUNDS || coo != NULL ||
+            !strstr(spal_last_error(), "row < nrows")) {
+            fprintf(stderr, "row outside the matrix accepted: %s\n", spal_last_error());
+            return 1;
+        }
+        if (spal_coo_to_csr_f64(0, 1, 1, 1, r_ok, c_bad, one, &csr) != SPAL_ERR_INDEX_OUT_OF_BOUNDS || csr != NULL ||
+            !strstr(spal_last_error(), "col < ncols")) {
+            fprintf(stderr, "column outside the matrix accepted: %s\n", spal_last_error());
+            return 1;
+        }
+        if (spal_coo_upload_f64(0, 0, 1, 0, NULL, NULL, NULL, &coo) != SPAL_ERR_INVARIANT) { /* src/coo.rs:819-823 */
+            fprintf(stderr, "nrows == 0 accepted\n");
+            return 1;
+        }
+        printf("coo rejections ok\n");
+    }
     if (argc > 1 && strcmp(argv[1], "gpu") == 0) {
         spal_csr_t a = NULL;
         uint64_t nr = 0, nc = 0, nnz = 0, rp[3], ci[4];

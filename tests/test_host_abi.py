@@ -209,3 +209,75 @@ def test_rust_ffi_declares_every_export():
     for f in ("scalar.rs", "device.rs", "ops.rs", "multi.rs"):
         for used in set(re.findall(r"ffi::(spal_[a-z0-9_]+)\(", open(os.path.join(root, "rust_shim", "src", f)).read())):
             assert used in _ffi.exported_names(), (f, used)
+
+
+def _coo_abi_call(lib, entry, case, dtype=np.float64):
+    """Call spal_coo_upload_* / spal_coo_to_csr_* with ctypes directly (not through matrix.py, whose own checks
+    would fire first).  The ABI takes ONE len for the three arrays."""
+    rows = np.asarray(case["rows"], dtype=U)
+    cols = np.asarray(case["cols"], dtype=U)
+    vals = np.ones(case["nvalues"], dtype=dtype)
+    out = C.c_void_p()
+    sfx = "f64" if dtype == np.float64 else "f32"
+    fp = C.POINTER(C.c_double if dtype == np.float64 else C.c_float)
+    st = getattr(lib, f"spal_coo_{entry}_{sfx}")(
+        C.c_int(0), C.c_uint64(case["nrows"]), C.c_uint64(case["ncols"]), C.c_uint64(vals.size),
+        rows.ctypes.data_as(_ffi.u64p), cols.ctypes.data_as(_ffi.u64p), vals.ctypes.data_as(fp), C.byref(out))
+    return st, out
+
+
+@pytest.mark.parametrize("entry", ["upload", "to_csr", "to_csc"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_g9_coo_rejections_through_the_c_abi(kats, entry, dtype):
+    """a-6: the reference's CooMatrix #[should_panic] fixtures (src/coo.rs:819-1012) against the C ABI's OWN checks.
+    They run before any device is touched, so this is a CPU test."""
+    lib = _ffi.lib()
+    for case in kats["G9_coo_rejections"]["cases"]:
+        if case["layer"] != "abi":
+            continue
+        st, out = _coo_abi_call(lib, entry, case, dtype)
+        assert st == getattr(_ffi, case["status"]), (case["name"], st)
+        assert not out.value, case["name"]
+        text = lib.spal_last_error().decode()
+        assert "would panic" in text and case["text"] in text, (case["name"], text)
+
+
+def test_g9_coo_rejections_through_the_mirror(kats):
+    """the same fixtures through the host mirror (the layer that sees three array lengths)."""
+    for case in kats["G9_coo_rejections"]["cases"]:
+        with pytest.raises(sp.Panic) as e:
+            if case.get("via_push"):
+                m = sp.CooMatrix.new(case["nrows"], case["ncols"])
+                m.push(case["rows"][0], case["cols"][0], 1.0)
+            else:
+                sp.CooMatrix.with_triplets(case["nrows"], case["ncols"], case["rows"], case["cols"],
+                                           np.ones(case["nvalues"]))
+        assert e.value.status == getattr(_ffi, case["status"]), case["name"]
+        assert case["text"] in str(e.value).replace("self.", ""), (case["name"], str(e.value))
+    for case in kats["G9_coo_rejections"]["accepted"]:
+        m = sp.CooMatrix.with_triplets(case["nrows"], case["ncols"], case["rows"], case["cols"],
+                                       np.ones(case["nvalues"]))
+        assert m.length() == case["nvalues"]
+
+
+def test_coo_abi_reports_the_first_offending_entry_and_shape_limits():
+    lib = _ffi.lib()
+    # entry 2 is the first out of bounds (its row); entry 3 (a column) comes later
+    case = dict(nrows=4, ncols=4, rows=[0, 3, 4, 1], cols=[0, 3, 0, 9], nvalues=4)
+    st, _ = _coo_abi_call(lib, "upload", case)
+    assert st == _ffi.SPAL_ERR_INDEX_OUT_OF_BOUNDS
+    assert "row < nrows (entry 2: row 4)" in lib.spal_last_error().decode()
+    case = dict(nrows=4, ncols=4, rows=[0, 3, 3, 1], cols=[0, 3, 0, 9], nvalues=4)
+    st, _ = _coo_abi_call(lib, "to_csr", case)
+    assert st == _ffi.SPAL_ERR_INDEX_OUT_OF_BOUNDS
+    assert "col < ncols (entry 3: col 9)" in lib.spal_last_error().decode()
+    # 32-bit device indices: a COO handle may become CSR or CSC, so both dimensions are bounded alike
+    for nr, nc in ((0xffffffff, 1), (1, 0xffffffff), (1 << 40, 1 << 40)):
+        st, _ = _coo_abi_call(lib, "upload", dict(nrows=nr, ncols=nc, rows=[], cols=[], nvalues=0))
+        assert st == _ffi.SPAL_ERR_UNSUPPORTED, (nr, nc)
+    # null arrays with len > 0, and a null out pointer
+    st = lib.spal_coo_upload_f64(C.c_int(0), C.c_uint64(1), C.c_uint64(1), C.c_uint64(1), None, None, None,
+                                 C.byref(C.c_void_p()))
+    assert st == _ffi.SPAL_ERR_INVALID_ARGUMENT
+    st = lib.spal_coo_upload_f64(C.c_int(0), C.c_uint64(1), C.c_uint64(1), C.c_uint64(0), None, None, None, None)
+    assert st == _ffi.SPAL_ERR_INVALID_ARGUMENT
