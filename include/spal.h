@@ -235,6 +235,15 @@ int spal_csc_autotune_f64(spal_csc_t a, const double *x_dev, double *y_dev,
 int spal_csc_autotune_f32(spal_csc_t a, const float *x_dev, float *y_dev,
                           void *stream, int iters);
 int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len);
+/* Health of the device-pointer products (spal_csc_spmv_dev_*) issued so far; call it after synchronising their stream.
+ * *invalid_products = products of this handle whose neighbour hand-off (kernel 1 over column tiles, flush 0) hit its
+ * spin bound: their y was NOT valid.  The library also reports such a product by failing the NEXT product on the
+ * handle (SPAL_ERR_HIP) and flushes with atomics from then on; a caller whose last product it was learns it here.
+ * Always 0 for the transposed route, the row tiles and the atomics forms (nothing is handed over there).
+ * Stream lifetime with the hand-off form: the handle remembers the stream of its last product and, when the next product
+ * comes on ANOTHER stream, records an event on the remembered one -- so a stream that carried a product of this handle
+ * must stay alive until the handle has been used on another stream or destroyed (or use one stream per handle). */
+int spal_csc_status(spal_csc_t a, int *invalid_products);
 
 /* ---- CSR <-> CSC on the device ------------------------------------------------
  * Replace `impl From<&CscMatrix<T>> for CsrMatrix<T>` (src/csr/conv/csc.rs:4-52)

@@ -58,6 +58,7 @@ extern "C" {
     pub fn spal_csc_autotune_f64(a: *mut spal_csc, x_dev: *const f64, y_dev: *mut f64, stream: *mut c_void, iters: c_int) -> c_int;
     pub fn spal_csc_autotune_f32(a: *mut spal_csc, x_dev: *const f32, y_dev: *mut f32, stream: *mut c_void, iters: c_int) -> c_int;
     pub fn spal_csc_describe(a: *mut spal_csc, buf: *mut c_char, buf_len: usize) -> c_int;
+    pub fn spal_csc_status(a: *mut spal_csc, invalid_products: *mut c_int) -> c_int;
     pub fn spal_csc_to_csr(a: *mut spal_csc, out: *mut *mut spal_csr) -> c_int;
     pub fn spal_csr_to_csc(a: *mut spal_csr, out: *mut *mut spal_csc) -> c_int;
     pub fn spal_coo_upload_f64(device: c_int, nrows: u64, ncols: u64, len: u64, rows: *const u64, cols: *const u64, vals: *const f64, out: *mut *mut spal_coo) -> c_int;

@@ -344,6 +344,32 @@ static int pick_lanes_csc(double mean) {
     return L;
 }
 
+// workgroups of csc_spmv_scatter<T, COLS> one CU holds at once with `lds` bytes of dynamic LDS -- asked of the runtime
+// (registers, LDS and wave slots of the compiled kernel), not derived from LDS alone; 0 when it cannot say
+template <typename T, int COLS>
+static int csc_scatter_per_cu(size_t lds) {
+    auto kern = csc_spmv_scatter<T, COLS>;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, (int)kCscBlock, lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+static int csc_scatter_per_cu(const spal_csc *a, size_t lds) {
+    const bool d = a->elem_size == 8;
+    switch (a->cols_per_block) {
+        case 4096: return d ? csc_scatter_per_cu<double, 4096>(lds) : csc_scatter_per_cu<float, 4096>(lds);
+        case 2048: return d ? csc_scatter_per_cu<double, 2048>(lds) : csc_scatter_per_cu<float, 2048>(lds);
+        default: return d ? csc_scatter_per_cu<double, 1024>(lds) : csc_scatter_per_cu<float, 1024>(lds);
+    }
+}
+
 template <typename T, int COLS>
 static hipError_t csc_launch_c(const spal_csc *a, const void *x, void *y, hipStream_t st, uint32_t epoch, uint32_t ticket_base) {
     const uint32_t per_xcd = (a->nblocks + 7) / 8;
@@ -621,8 +647,8 @@ static int csc_plan_build(spal_csc *a) {
                     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
                     const size_t lds = std::max(((size_t)kCscCols + a->lds_entries) * (size_t)a->elem_size,
                                                 (size_t)kCscCols * (size_t)a->elem_size + ((size_t)kCscCols + 2) * 4);
-                    per_cu = lds > 80u * 1024u ? 1 : 2;       // (1024-thread workgroups: at most two per CU)
-                    a->ticket_auto = (uint64_t)((a->nblocks + 7) / 8) * 8 > (uint64_t)cus * (uint64_t)per_cu ? 1 : 0;
+                    per_cu = csc_scatter_per_cu(a, lds);      // the runtime's occupancy of the compiled kernel; 0 = unknown: ticket
+                    a->ticket_auto = (per_cu <= 0 || (uint64_t)((a->nblocks + 7) / 8) * 8 > (uint64_t)cus * (uint64_t)per_cu) ? 1 : 0;
                 }
             }
         }
@@ -972,6 +998,7 @@ int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value) {
         if (value < 0 || value > 2) return fail(SPAL_ERR_INVALID_ARGUMENT, "kernel must be 0, 1 or 2");
         a->kernel = value == 1 ? 1 : 2;
         if (a->kernel == 2) return csc_ensure_csr(a);
+        if (!a->rowtiles) return csc_rowtiles_plan(a);   // the scatter path's row tiles: built when the path is selected
         return SPAL_OK;
     }
     if (!strcmp(key, "flush")) {
@@ -1016,6 +1043,12 @@ int spal_csc_set_option(spal_csc_t a, const char *key, int64_t value) {
     }
     return fail(SPAL_ERR_INVALID_ARGUMENT, "unknown option '%s'", key);
 }
+int spal_csc_status(spal_csc_t a, int *invalid_products) {
+    if (!a || !invalid_products) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csc_status: null argument");
+    std::lock_guard<std::mutex> chain(a->mu_launch);
+    *invalid_products = a->handoff_timeouts + ((a->h_gave_up && __atomic_load_n(a->h_gave_up, __ATOMIC_RELAXED)) ? 1 : 0);
+    return SPAL_OK;
+}
 int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len) {
     if (!a || !buf || !buf_len) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csc_describe: null argument");
     snprintf(buf, buf_len,
@@ -1023,7 +1056,7 @@ int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len) {
              "\"kernel\": \"%s\", \"cols_per_block\": %d, \"blocks\": %u, \"lanes_per_col\": %d, "
              "\"lds_window_bytes\": %llu, \"lds_col_fraction\": %.4f, \"flush\": \"%s\", "
              "\"window_store_bytes\": %llu, \"ticket\": %d, \"handoff_timeouts\": %d, \"uniform_columns\": %d, "
-             "\"row_tiles\": %d, \"row_tile_rows\": %u, \"row_tile_count\": %u, \"row_tile_x_window\": %u}",
+             "\"row_tiles\": %d, \"row_tile_rows\": %u, \"row_tile_count\": %u, \"row_tile_x_window\": %u, \"row_tiles_failed\": %d}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz,
              a->kernel == 2 ? "transposed_csr" : a->lds_entries ? "lds_privatised_scatter" : "atomic_scatter",
@@ -1034,7 +1067,7 @@ int spal_csc_describe(spal_csc_t a, char *buf, size_t buf_len) {
              (unsigned long long)a->windows_entries * (unsigned long long)a->elem_size, a->use_ticket < 0 ? a->ticket_auto : a->use_ticket,
              a->handoff_timeouts + ((a->h_gave_up && __atomic_load_n(a->h_gave_up, __ATOMIC_RELAXED)) ? 1 : 0),
              a->uniform_cols ? 1 : 0,
-             (a->rowtiles && a->rowtiles_user != 0 && a->flush == 0) ? 1 : 0, a->rt_rows, a->rt_ntiles, a->rt_xcap);
+             (a->rowtiles && a->rowtiles_user != 0 && a->flush == 0) ? 1 : 0, a->rt_rows, a->rt_ntiles, a->rt_xcap, a->rowtiles_failed);
     return SPAL_OK;
 }
 

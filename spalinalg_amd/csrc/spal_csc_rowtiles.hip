@@ -271,8 +271,20 @@ static int rowtiles_plan_t(spal_csc *a) {
     return SPAL_OK;
 }
 
+// The row tiles are an OPTIONAL second copy of the entries (12 bytes each) that only the scatter path reads: built when
+// kernel 1 is selected (spal_csc_set_option "kernel" = 1), not for the default transposed route; a failure to build it --
+// out of memory, an inconsistent count -- means "does not qualify": the copy is freed, the error cleared and the column
+// tiles run.  `rowtiles_failed` in spal_csc_describe says so.
 int csc_rowtiles_plan(spal_csc *a) {
-    return a->elem_size == 8 ? rowtiles_plan_t<double>(a) : rowtiles_plan_t<float>(a);
+    a->rowtiles_failed = 0;
+    if (a->kernel != 1) { csc_rowtiles_free(a); return SPAL_OK; }
+    const int st = a->elem_size == 8 ? rowtiles_plan_t<double>(a) : rowtiles_plan_t<float>(a);
+    if (st != SPAL_OK) {
+        csc_rowtiles_free(a);
+        (void)hipGetLastError();
+        a->rowtiles_failed = 1;
+    }
+    return SPAL_OK;
 }
 
 template <typename T>

@@ -816,7 +816,7 @@ static hipError_t launch_stream_main(const spal_csr *a, const void *x, void *y, 
 
 template <typename T>
 static hipError_t launch_lanes(const spal_csr *a, const void *x, void *y, hipStream_t st) {
-    if (a->plan.cblock && a->plan.cblock_on) return launch_cblock(a, x, y, st);   // columns anywhere: csr_cblock.hpp
+    if (__atomic_load_n(&a->plan.cblock, __ATOMIC_ACQUIRE) && a->plan.cblock_on) return launch_cblock(a, x, y, st);   // columns anywhere: csr_cblock.hpp
     if (a->plan.kernel == 2) return launch_stream<T>(a, x, y, st);
     switch (a->plan.lanes_per_row) {
 #define SPAL_LANES_CASE(LL) \
@@ -845,12 +845,15 @@ int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream) 
         SPAL_HIP_TRY(hipGetLastError());
         return SPAL_OK;
     }
-    if (a->plan.cblock_pending) {   // a handle assembled on the device whose columns are anywhere: the tiled copy, once
+    if (__atomic_load_n(&a->plan.cblock_pending, __ATOMIC_ACQUIRE)) {
+        // a handle assembled on the device whose columns are anywhere: the tiled copy, built once by the first product.
+        // `cblock_pending` stays set until the build has FINISHED, so every concurrent caller takes the lock and waits
+        // for it (spal.h: products on one handle may run concurrently); the builder publishes plan.cblock last.
         std::lock_guard<std::mutex> lock(a->mu_cb);
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (a->plan.cblock_pending && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
-            a->plan.cblock_pending = 0;
-            SPAL_TRY(cblock_plan(a, false));
+            (void)cblock_plan(a, false);    // a failure means "does not qualify": the stream kernels run
+            __atomic_store_n(&a->plan.cblock_pending, 0, __ATOMIC_RELEASE);
         }
     }
     hipError_t e = a->elem_size == 8 ? launch_lanes<double>(a, x_dev, y_dev, stream)
@@ -1230,7 +1233,7 @@ int csr_plan_build(spal_csr *a) {
                     fprintf(stderr, "[spal cblock] plan: nonlocal rows %.3f, user %d, lazy %d\n", p.nonlocal_row_fraction, p.cblock_user, a->cblock_lazy);
                 if (p.cblock_user == 1 || (p.cblock_user < 0 && p.nonlocal_row_fraction >= 0.5)) {
                     if (a->cblock_lazy && p.cblock_user < 0) { cblock_free(a); p.cblock_pending = 1; }   // built by the first product
-                    else SPAL_TRY(cblock_plan(a, p.cblock_user == 1));
+                    else (void)cblock_plan(a, p.cblock_user == 1);   // (a failure: the stream kernels run, `cblock_failed`)
                 } else {
                     cblock_free(a);
                 }
@@ -1635,7 +1638,13 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
     };
     // ---- 0. columns anywhere: the column-blocked kernel against the stream kernels (results are bit-identical)
     a->cblock_us[0] = a->cblock_us[1] = 0.f;
-    if (p.cblock_pending) { p.cblock_pending = 0; rc = cblock_plan(a, false); }
+    {   // (under the lock a first product on another thread takes for the same build, csr_launch)
+        std::lock_guard<std::mutex> lock(a->mu_cb);
+        if (p.cblock_pending) {
+            (void)cblock_plan(a, false);
+            __atomic_store_n(&p.cblock_pending, 0, __ATOMIC_RELEASE);
+        }
+    }
     if (p.cblock) {
         float ms[2] = {0.f, 0.f};
         for (int round = 0; round < 2 && rc == SPAL_OK; ++round)
@@ -2060,7 +2069,7 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "\"overflow_tiles\": %u, \"skew\": %d, \"persistent\": %d, \"nt_store\": %d, \"uniform_row_fraction\": %.4f, "
              "\"prefetch\": %d, \"slide\": %d, \"ring_pages\": %d, \"tile_steps\": %d, \"split_tiles\": %u, \"panel_tiles\": %u, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f], \"placement_us\": [%.1f, %.1f], \"placement_tries\": %d, \"addr\": [\"%llx\", \"%llx\", \"%llx\"], "
              "\"vectors_walk_us\": [%.1f, %.1f], \"vectors_walk_blocks\": %d, "
-             "\"nonlocal_row_fraction\": %.4f, \"cblock\": %d, \"cblock_pending\": %d, \"cblock_rows\": %d, \"cblock_form\": \"%s\", \"cblock_run\": %.2f, \"cblock_cols\": %llu, \"cblock_col_blocks\": %d, \"cblock_row_blocks\": %u, \"cblock_us\": [%.1f, %.1f]}",
+             "\"nonlocal_row_fraction\": %.4f, \"cblock\": %d, \"cblock_pending\": %d, \"cblock_rows\": %d, \"cblock_form\": \"%s\", \"cblock_run\": %.2f, \"cblock_cols\": %llu, \"cblock_col_blocks\": %d, \"cblock_row_blocks\": %u, \"cblock_us\": [%.1f, %.1f], \"cblock_failed\": %d}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, (p.kernel == 2 || p.vec_col16) ? 16 : 32,
              (p.cblock && p.cblock_on) ? "cblock" : p.kernel == 2 ? "stream" : "vector", p.lanes_per_row, p.kernel == 2 ? 2 : p.unroll,
@@ -2082,7 +2091,7 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              (double)a->walk_us[0], (double)a->walk_us[1], a->walk_blocks,
              p.kernel == 2 ? p.nonlocal_row_fraction : 0.0, (p.cblock && p.cblock_on) ? 1 : 0, p.cblock_pending, p.cblock ? p.cblock_rows : 0, !p.cblock ? "" : p.cblock_form ? "rows" : "entry", p.cblock ? (double)p.cblock_run : 0.0,
              p.cblock ? (1ull << p.cblock_shift) : 0ull, p.cblock ? p.cblock_nbc : 0, p.cblock ? p.cblock_nrb : 0u,
-             (double)a->cblock_us[0], (double)a->cblock_us[1]);
+             (double)a->cblock_us[0], (double)a->cblock_us[1], a->cblock_failed);
     return SPAL_OK;
 }
 

@@ -7,12 +7,13 @@
 namespace spal {
 
 void cblock_free(spal_csr *a) {
+    __atomic_store_n(&a->plan.cblock, 0, __ATOMIC_RELEASE);
     (void)dev_free(a->d_cb_val); a->d_cb_val = nullptr;
     (void)dev_free(a->d_cb_col); a->d_cb_col = nullptr;
     (void)dev_free(a->d_cb_tile); a->d_cb_tile = nullptr;
     (void)dev_free(a->d_cb_cnt); a->d_cb_cnt = nullptr;
     (void)dev_free(a->d_cb_row); a->d_cb_row = nullptr;
-    a->plan.cblock = 0;
+    __atomic_store_n(&a->plan.cblock, 0, __ATOMIC_RELEASE);
 }
 
 // entry form: two product strips (producers fill one while consumers sum the other), the running sums, two row strips
@@ -61,7 +62,7 @@ static int cb_count_tiles(spal_csr *a, uint32_t RB, uint32_t nbc, uint32_t shift
 // the column blocks (that is what keeps one x slice in L2), so a launch of 3.07 rounds takes as long as one of four
 // (5M x 5M: 1536 workgroups of 3256 rows 412 us, 1571 of 3184 rows 485 us).  `force`: option "cblock" = 1 (tests: small
 // matrices).  Returns SPAL_OK with a->plan.cblock = 0 when the matrix does not qualify.
-int cblock_plan(spal_csr *a, bool force) {
+static int cblock_build(spal_csr *a, bool force) {
     CsrPlan &p = a->plan;
     cblock_free(a);
     if (a->nnz == 0 || !a->parts.empty()) return SPAL_OK;
@@ -82,9 +83,15 @@ int cblock_plan(spal_csr *a, bool force) {
         const uint32_t sh = p.cblock_shift_user > 0 ? (uint32_t)p.cblock_shift_user : shift0;
         const uint64_t nb = (a->ncols + (1ull << sh) - 1) >> sh;
         if (nb > kCbMaxBlocks) return SPAL_OK;
-        SPAL_TRY(cb_count_tiles(a, 1024, (uint32_t)nb, sh, tile_n, runs, too_long));
-        if (too_long) { cblock_free(a); return SPAL_OK; }
-        form = (runs && (double)a->nnz / (double)runs >= 1.6) ? 1 : 0;
+        if ((size_t)((a->nrows + 1023) / 1024) * nb * 1024 > (size_t)a->nnz * 12 && !force) {
+            // the counts (a byte per row and column block) would be heavier than the entries: rows this sparse per
+            // column block hold about one entry per run -- the entry form, whose candidates carry the same cap below
+            form = 0;
+        } else {
+            SPAL_TRY(cb_count_tiles(a, 1024, (uint32_t)nb, sh, tile_n, runs, too_long));
+            if (too_long) { cblock_free(a); return SPAL_OK; }
+            form = (runs && (double)a->nnz / (double)runs >= 1.6) ? 1 : 0;
+        }
     }
     // 1 MB of f64 x (2^17 columns; f32: 2^17 as well, 0.5 MB) per column block measured best for both forms: the slice
     // shares its XCD's 4 MB L2 with the streamed entries and with the slices of workgroups a block ahead or behind
@@ -174,7 +181,6 @@ int cblock_plan(spal_csr *a, bool force) {
     SPAL_HIP_TRY(hipGetLastError());
     SPAL_HIP_TRY(hipStreamSynchronize(a->stream));             // `tp` goes out of scope
     if (form == 0) { (void)dev_free(a->d_cb_cnt); a->d_cb_cnt = nullptr; }   // the counts were the builder's; the entry form reads the entries' rows
-    p.cblock = 1;
     p.cblock_form = form;
     p.cblock_run = runs ? (float)((double)a->nnz / (double)runs) : 0.f;
     p.cblock_rows = (int)RB;
@@ -182,6 +188,24 @@ int cblock_plan(spal_csr *a, bool force) {
     p.cblock_shift = (int)shift;
     p.cblock_nbc = (int)nbc;
     p.cblock_nrb = nrb;
+    // published LAST and with release: a product running on another thread (spal_csr_spmv_dev takes no lock) reads it
+    // with acquire in launch_lanes and then sees either 0 -- the stream kernels, which touch none of this -- or the
+    // complete geometry and arrays
+    __atomic_store_n(&p.cblock, 1, __ATOMIC_RELEASE);
+    return SPAL_OK;
+}
+
+// The tiled copy is OPTIONAL (the stream kernels compute the same product): when building it fails -- out of memory for
+// the second copy, counts that do not add up -- the matrix "does not qualify": what was allocated is freed, the error is
+// cleared and the handle keeps running the kernels it has.  `cblock_failed` in spal_csr_describe says so.
+int cblock_plan(spal_csr *a, bool force) {
+    a->cblock_failed = 0;
+    const int st = cblock_build(a, force);
+    if (st != SPAL_OK) {
+        cblock_free(a);
+        (void)hipGetLastError();
+        a->cblock_failed = 1;
+    }
     return SPAL_OK;
 }
 

@@ -201,6 +201,7 @@ struct spal_csr {
     uint16_t *d_cb_row = nullptr;  // row of every entry inside its row block
     float cblock_us[2] = {0.f, 0.f};   // autotune: per launch {stream kernels, column-blocked kernel}
     int cblock_lazy = 0;           // build the tiled copy with the first product, not with the plan (csr_adopt_device)
+    int cblock_failed = 0;         // building it failed (out of memory, ...): the stream kernels run instead
     // spal_csr_alloc_vectors: the block of 1 GiB (or more) that holds the caller's x and y, found by the placement walk
     void *d_vec_block = nullptr;
     size_t vec_x_off = 0, vec_y_off = 0;
@@ -262,6 +263,7 @@ struct spal_csc {
     // row tiles (spal_csc_rowtiles.hip): the entries a second time, ordered (row tile, column, row) -- a workgroup owns rows
     // of y outright, no hand-off; built where every tile's window of x fits LDS, and then the scatter path's default
     int rowtiles = 0;              // the copy is built
+    int rowtiles_failed = 0;       // building it failed (out of memory, ...): the column tiles run instead
     int rowtiles_user = -1;        // option "row_tiles": -1 / 1 = where it qualifies, 0 = never (the column tiles run)
     uint32_t rt_rows = 0, rt_ntiles = 0, rt_xcap = 0;   // rows of a tile, tiles, widest x window (elements)
     uint32_t rt_rows_user = 0;     // option "row_tile_rows": 0 = the tallest of 4096 / 2048 / 1024 that fits

@@ -116,6 +116,8 @@ class _DeviceMatrix:
     def alloc_vectors(self, stream=None):
         """Device pointers (x, y) of vectors owned by this handle and placed so that the stores of y do not collide
         with the matrix stream (spal_csr_alloc_vectors: a walk over the device's memory, setup time).  CSR handles."""
+        if self._kind != "csr":   # the entry point reads a spal_csr: never hand it another handle type (ADVICE r03)
+            raise TypeError("alloc_vectors() exists for CSR handles only (spal_csr_alloc_vectors)")
         x, y = vp(), vp()
         check(_ffi.lib().spal_csr_alloc_vectors(self._h, C.byref(x), C.byref(y), _stream_ptr(stream)))
         return x.value, y.value
@@ -200,6 +202,13 @@ class DeviceCsc(_DeviceMatrix):
         va = np.empty(nnz, dtype=self.dtype)
         check(self._fn(f"download_{_sfx(self.dtype)}")(self._h, _p(cp), _p(ri), _p(va)))
         return cp, ri, va
+
+    def invalid_products(self) -> int:
+        """spal_csc_status: device-pointer products of this handle whose hand-off hit its spin bound (their y was not
+        valid); call after synchronising the stream."""
+        n = C.c_int(-1)
+        check(_ffi.lib().spal_csc_status(self._h, C.byref(n)))
+        return n.value
 
     def to_csr(self) -> DeviceCsr:
         """device CSC -> CSR (stable sort by row; src/csr/conv/csc.rs:4-52)"""

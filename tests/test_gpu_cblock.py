@@ -154,3 +154,46 @@ def test_form_follows_the_entries_per_run(oracle):
         d = dev.describe()
         assert d["kernel"] == "cblock" and d["cblock_form"] == form, d
         assert np.array_equal(bits(dev.spmv(x)), bits(oracle.csr_spmv(rp, ci, va, x)))
+
+
+def test_first_products_from_two_threads_on_a_device_assembled_handle(oracle):
+    """a handle assembled on the device builds its column-blocked copy with its FIRST product, and
+    spal_csr_spmv_dev may be called concurrently on one handle.  Two threads issue the first product together, each on
+    its own stream: the build happens once, under the handle's lock, both wait for it, both results carry the oracle's
+    bits."""
+    import threading
+    import torch
+    n, per_row = 1_000_000, 10
+    r, c, v = synth.coo(n, n, n * per_row, synth.matrix_seed(5), 10, 1)
+    x = synth.vector(n)
+    p, i, w = oracle.coo_to_csr(n, n, r, c, v)
+    y_ref = oracle.csr_spmv(p, i, w, x)
+    for attempt in range(3):
+        dev = sp.CooMatrix.with_triplets(n, n, r, c, v).upload().assemble_csr()
+        d = dev.describe()
+        assert d["cblock_pending"] == 1 and d["cblock"] == 0, d
+        xt = torch.from_numpy(x).cuda()
+        ys = [torch.full((n,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2)]
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        torch.cuda.synchronize()
+        gate, errors = threading.Barrier(2), []
+
+        def work(k):
+            try:
+                gate.wait()
+                for _ in range(3):
+                    dev.spmv_dev(xt.data_ptr(), ys[k].data_ptr(), streams[k])
+                streams[k].synchronize()
+            except Exception as exc:  # noqa: BLE001
+                errors.append(exc)
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        d = dev.describe()
+        assert d["cblock_pending"] == 0 and d["cblock"] == 1 and d["cblock_failed"] == 0, d
+        for k in range(2):
+            assert np.array_equal(bits(ys[k].cpu().numpy()), bits(y_ref))

@@ -299,6 +299,7 @@ def test_csc_handoff_backstop_is_reported(oracle, monkeypatch):
     xt = torch.from_numpy(x).cuda()
     yt = torch.empty(n, dtype=torch.float64, device="cuda")
     raised = False
+    assert dev.invalid_products() == 0
     for _ in range(60):
         try:
             dev.spmv_torch(xt, yt)
@@ -307,7 +308,10 @@ def test_csc_handoff_backstop_is_reported(oracle, monkeypatch):
             assert "hand-off" in str(e), e
             break
         torch.cuda.synchronize()
+        if dev.invalid_products():                    # spal_csc_status: visible right after the synchronisation,
+            assert dev.invalid_products() == 1         # before the next product fails loudly
     assert raised, "no super-tile ever took the backstop"
+    assert dev.invalid_products() == 1
     d = dev.describe()
     assert d["handoff_timeouts"] == 1 and d["flush"] == "global_atomics", d
     yt.fill_(float("nan"))
