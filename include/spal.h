@@ -272,6 +272,13 @@ int spal_coo_destroy(spal_coo_t c);
  * new CSR handle.  Synchronises the stream once (the output size is data
  * dependent). */
 int spal_coo_assemble_csr(spal_coo_t c, void *stream, spal_csr_t *out);
+/* The handle spal_coo_assemble_csr / spal_coo_to_csr_* return is the complete matrix `CsrMatrix::from(&coo)` produces
+ * (shape, download, conversions); the plan of the PRODUCT kernels on it (tile heights, x windows, 16-bit columns: ~0.3 ms
+ * of small kernels and host round trips at 50M entries) is built by whatever needs it first -- the first product,
+ * spal_csr_set_option, spal_csr_autotune_*, spal_csr_alloc_vectors, spal_csr_describe -- or, explicitly, here.  A first
+ * product cannot be captured into a graph: plan before capturing.  No-op on handles created from host arrays (planned at
+ * create time).  SPAL_COO_EAGER_PLAN=1 plans inside the assembly call as rounds 1-3 did. */
+int spal_csr_plan(spal_csr_t a);
 /* Same assembly compressed by columns: replaces
  * `impl From<&CooMatrix<T>> for CscMatrix<T>` (src/csc/conv/coo.rs:4-115). */
 int spal_coo_assemble_csc(spal_coo_t c, void *stream, spal_csc_t *out);

@@ -65,6 +65,7 @@ extern "C" {
     pub fn spal_coo_upload_f32(device: c_int, nrows: u64, ncols: u64, len: u64, rows: *const u64, cols: *const u64, vals: *const f32, out: *mut *mut spal_coo) -> c_int;
     pub fn spal_coo_destroy(c: *mut spal_coo) -> c_int;
     pub fn spal_coo_assemble_csr(c: *mut spal_coo, stream: *mut c_void, out: *mut *mut spal_csr) -> c_int;
+    pub fn spal_csr_plan(a: *mut spal_csr) -> c_int;
     pub fn spal_coo_assemble_csc(c: *mut spal_coo, stream: *mut c_void, out: *mut *mut spal_csc) -> c_int;
     pub fn spal_coo_describe(c: *mut spal_coo, buf: *mut c_char, buf_len: usize) -> c_int;
     pub fn spal_coo_to_csr_f64(device: c_int, nrows: u64, ncols: u64, len: u64, rows: *const u64, cols: *const u64, vals: *const f64, out: *mut *mut spal_csr) -> c_int;

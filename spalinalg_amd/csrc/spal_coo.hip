@@ -48,6 +48,19 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     return v;
 }
 
+// Counters in LDS that the lanes of ONE wave hand to each other between two rounds of a ranking loop (the lowest lane of
+// a digit publishes the new count, the next round's lanes read it).  The compiler must re-read them every round; declared
+// `volatile` it did -- but through FLAT instructions (address-space inference leaves volatile accesses alone), each followed
+// by s_waitcnt vmcnt(0): 32 serialised flat round trips per tile in radix_scatter, and in the group kernel a wait for every
+// load in flight.  Relaxed atomics at wavefront scope are plain ds_read / ds_write, re-read every time, and LDS
+// instructions of one wave execute in order.
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ void lds_poke(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
 // block-wide exclusive scan of one value per thread (256 threads); returns the
 // exclusive prefix, *total receives the block sum
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *total) {
@@ -218,19 +231,22 @@ __global__ __launch_bounds__(kHistThreads) void radix_hist(const uint32_t *__res
 // and stable.  The tile is first written to LDS in digit order, then copied out
 // linearly, so each digit leaves the workgroup as ONE contiguous run
 // (coalesced stores) that starts at the scanned global offset of (digit, tile).
-template <typename T>
+// PACK (the last pass before the group kernel, when the minor index and the row inside its group fit one word): the
+// key is not written at all and the payload leaves as aux | (key & (2^pack_bits - 1)) << (32 - pack_bits) -- the group a
+// sorted entry belongs to is its position, all the group kernel still needs of the row are its low bits: 12 instead of 16
+// bytes per entry written here and read there.
+template <typename T, bool PACK = false>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter(
     const uint32_t *__restrict__ kin, const uint32_t *__restrict__ ain, const T *__restrict__ vin,
     uint32_t *__restrict__ kout, uint32_t *__restrict__ aout, T *__restrict__ vout, uint64_t len,
-    uint32_t shift, const uint32_t *__restrict__ offs, uint32_t nblk, uint32_t per_xcd) {
+    uint32_t shift, const uint32_t *__restrict__ offs, uint32_t nblk, uint32_t per_xcd, uint32_t pack_bits = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_sort_smem[];
     T *s_val = reinterpret_cast<T *>(spal_sort_smem);                       // kSortTile
     uint32_t *s_key = reinterpret_cast<uint32_t *>(s_val + kSortTile);      // kSortTile
     uint32_t *s_aux = s_key + kSortTile;                                    // kSortTile
-    // volatile: lanes of a wave hand counts to each other through this array
-    // between two rounds; the compiler must re-read it every round
-    volatile uint32_t *cnt = s_aux + kSortTile;                             // [kSortWaves][256]
-    uint32_t *s_start = const_cast<uint32_t *>(cnt) + kSortWaves * 256;      // [256] tile-local digit start
+    // lanes of a wave hand counts to each other through this array between two rounds (lds_peek / lds_poke)
+    uint32_t *cnt = s_aux + kSortTile;                                       // [kSortWaves][256]
+    uint32_t *s_start = cnt + kSortWaves * 256;                              // [256] tile-local digit start
     uint32_t *s_delta = s_start + 256;                                       // [256] global - local
     uint32_t *s_wsum = s_delta + 256;                                        // [4] digit-scan wave sums
 
@@ -271,10 +287,10 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(
             const uint64_t m = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? m : ~m;
         }
-        const uint32_t before = ok ? cnt[w * 256 + d] : 0u;
+        const uint32_t before = ok ? lds_peek(&cnt[w * 256 + d]) : 0u;
         rank[j] = before + (uint32_t)__popcll(peers & lt);
         // the lowest peer lane publishes the new count (one writer per digit)
-        if (ok && (peers & lt) == 0) cnt[w * 256 + d] = before + (uint32_t)__popcll(peers);
+        if (ok && (peers & lt) == 0) lds_poke(&cnt[w * 256 + d], before + (uint32_t)__popcll(peers));
     }
     __syncthreads();
     // per digit: exclusive prefix over the waves; tile-local start of the digit;
@@ -323,8 +339,12 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(
         if (lp < n_tile) {
             const uint32_t k = s_key[lp];
             const uint32_t gp = s_delta[(k >> shift) & 0xffu] + lp;
-            kout[gp] = k;
-            aout[gp] = s_aux[lp];
+            if (PACK) {
+                aout[gp] = pack_bits ? (s_aux[lp] | ((k & ((1u << pack_bits) - 1u)) << (32u - pack_bits))) : s_aux[lp];
+            } else {
+                kout[gp] = k;
+                aout[gp] = s_aux[lp];
+            }
             vout[gp] = s_val[lp];
         }
     }
@@ -336,6 +356,7 @@ struct SortBuffers {
     uint32_t *aux[2] = {nullptr, nullptr};
     T *val[2] = {nullptr, nullptr};
     uint32_t *counts = nullptr;  // 256 * nblk
+    uint32_t *counts2 = nullptr; // the same again: the second pass's, when the first pass's scanned counts must survive it
     uint32_t *sums = nullptr;    // scan scratch
 };
 
@@ -347,39 +368,80 @@ static size_t sort_lds_bytes() {
 // Sorts by bits [lo_bit, lo_bit + nbits) of key, stably.  The first pass reads
 // (k_in, a_in, v_in) when given (the caller's arrays, left untouched), else
 // buffer set `cur`; `cur` is updated to the set that holds the result.
+// `two_counts`: the second pass counts into b.counts2, so that the first pass's scanned counts (the digit buckets'
+// starts) are still there afterwards.  `pack_bits` >= 0: the LAST pass writes the packed payload (radix_scatter<T, true>)
+// and no keys.
 template <typename T>
 static hipError_t radix_sort_bits(SortBuffers<T> &b, uint64_t len, uint32_t lo_bit, uint32_t nbits,
                                   int &cur, hipStream_t st, const uint32_t *k_in = nullptr,
-                                  const uint32_t *a_in = nullptr, const T *v_in = nullptr) {
+                                  const uint32_t *a_in = nullptr, const T *v_in = nullptr,
+                                  bool two_counts = false, int pack_bits = -1) {
     if (len == 0) return hipSuccess;
     const uint32_t nblk = (uint32_t)((len + kSortTile - 1) / kSortTile);
     const uint64_t ncounts = 256ull * nblk;
     const size_t lds = sort_lds_bytes<T>();
     {  // > 64 KiB of dynamic LDS needs the cap raised (per device; cheap, so every call)
-        hipError_t e = hipFuncSetAttribute((const void *)radix_scatter<T>,
+        hipError_t e = hipFuncSetAttribute((const void *)radix_scatter<T, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess && pack_bits >= 0)
+            e = hipFuncSetAttribute((const void *)radix_scatter<T, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    for (uint32_t shift = lo_bit; shift < lo_bit + nbits; shift += 8) {
+    int pass = 0;
+    for (uint32_t shift = lo_bit; shift < lo_bit + nbits; shift += 8, ++pass) {
         const uint32_t *ki = k_in ? k_in : b.key[cur];
         const uint32_t *ai = k_in ? a_in : b.aux[cur];
         const T *vi = k_in ? v_in : b.val[cur];
         const int dst = k_in ? cur : (cur ^ 1);
-        const uint32_t *offs = b.counts;
+        uint32_t *counts = (two_counts && pass == 1) ? b.counts2 : b.counts;
         {
             hipLaunchKernelGGL(radix_hist, dim3((nblk + kHistGroup - 1) / kHistGroup), dim3(kHistThreads), 0, st, ki, len, shift,
-                               b.counts, nblk);
-            hipError_t e = exclusive_scan_u32(b.counts, b.counts, ncounts, b.sums, nullptr, st);
+                               counts, nblk);
+            hipError_t e = exclusive_scan_u32(counts, counts, ncounts, b.sums, nullptr, st);
             if (e != hipSuccess) return e;
         }
         const uint32_t per_xcd = (nblk + 7) / 8;
-        hipLaunchKernelGGL(radix_scatter<T>, dim3(SPAL_SORT_XCD ? per_xcd * 8 : nblk), dim3(kSortThreads),
-                           lds, st, ki, ai, vi, b.key[dst], b.aux[dst], b.val[dst], len, shift, offs,
-                           nblk, per_xcd);
+        const bool last = shift + 8 >= lo_bit + nbits;
+        if (last && pack_bits >= 0)
+            hipLaunchKernelGGL((radix_scatter<T, true>), dim3(SPAL_SORT_XCD ? per_xcd * 8 : nblk), dim3(kSortThreads),
+                               lds, st, ki, ai, vi, b.key[dst], b.aux[dst], b.val[dst], len, shift, counts,
+                               nblk, per_xcd, (uint32_t)pack_bits);
+        else
+            hipLaunchKernelGGL((radix_scatter<T, false>), dim3(SPAL_SORT_XCD ? per_xcd * 8 : nblk), dim3(kSortThreads),
+                               lds, st, ki, ai, vi, b.key[dst], b.aux[dst], b.val[dst], len, shift, counts,
+                               nblk, per_xcd, 0u);
         cur = dst;
         k_in = nullptr;
     }
     return hipGetLastError();
+}
+
+// The groups' offsets after exactly TWO passes, from the passes' own scanned counts (round 4; round 3 read all sorted
+// keys once more for them, rows_boundaries: 206 MB and 45 us at config 5).  Group g = d2 << 8 | d1 (d1 = the first
+// pass's digit, d2 = the second's).  The second pass's input is ordered by d1: bucket d1 begins at B[d1] = offs1[d1][tile
+// 0], inside tile t* = B[d1] / tile.  Entries ordered before group g in the result: every entry with a smaller d2, and of
+// those with the same d2 the ones in buckets before d1 -- that is offs2[d2][t*] (same d2, tiles before t*) plus the
+// entries with digit d2 inside tile t* that lie before B[d1], which workgroup d1 counts here (at most one tile of keys).
+__global__ __launch_bounds__(256) void group_offsets(const uint32_t *__restrict__ offs1, const uint32_t *__restrict__ offs2,
+                                                     const uint32_t *__restrict__ keys1, uint32_t len, uint32_t nblk,
+                                                     uint32_t shift2, uint32_t ngroups, uint32_t *__restrict__ gstart) {
+    __shared__ uint32_t h[256];
+    const uint32_t d1 = blockIdx.x, t = threadIdx.x;
+    h[t] = 0;
+    __syncthreads();
+    const uint32_t b = offs1[(uint64_t)d1 * nblk];
+    const uint32_t tstar = b / (uint32_t)kSortTile, t0 = tstar * (uint32_t)kSortTile;
+    for (uint32_t i = t0 + t; i < b; i += 256) atomicAdd(&h[(keys1[i] >> shift2) & 0xffu], 1u);
+    __syncthreads();
+    const uint32_t d2 = t, g = d2 << 8 | d1;
+    if (g < ngroups) {
+        uint32_t v;
+        if (tstar < nblk) v = offs2[(uint64_t)d2 * nblk + tstar] + h[d2];
+        else v = d2 == 255u ? len : offs2[(uint64_t)(d2 + 1) * nblk];   // (the bucket begins at the very end: nothing of it exists)
+        gstart[g] = v;
+    }
+    if (d1 == 0 && t == 0) gstart[ngroups] = len;
 }
 
 static uint32_t bits_for(uint64_t n) {  // bits needed for values in [0, n)
@@ -452,12 +514,10 @@ static void launch_row_starts(const uint32_t *sorted_row, uint32_t n, uint32_t n
 
 constexpr int kGroupCap = 2048;  // entries a group of rows may hold for the LDS local sort
 
-// part[blk] = entries of the fullest group among those this workgroup visits
-// (no atomics: thousands of waves raising one shared maximum serialise on it;
-// groups_check_final folds the partial results)
-constexpr int kCheckBlocks = 1024;
+// *fullest = max(*fullest, entries of the fullest group): one atomicMax per workgroup (a few hundred at most -- thousands
+// of waves raising one shared maximum would serialise on it)
 __global__ __launch_bounds__(256) void groups_check(const uint32_t *__restrict__ gstart, uint32_t ngroups,
-                                                    uint32_t *__restrict__ part) {
+                                                    uint32_t *__restrict__ fullest) {
     __shared__ uint32_t s_max[4];
     uint32_t v = 0;
 #pragma unroll 4
@@ -467,18 +527,7 @@ __global__ __launch_bounds__(256) void groups_check(const uint32_t *__restrict__
     for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
     if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-}
-__global__ __launch_bounds__(256) void groups_check_final(const uint32_t *__restrict__ part, uint32_t nparts,
-                                                          uint32_t *__restrict__ m) {
-    __shared__ uint32_t s_max[4];
-    uint32_t v = 0;
-    for (uint32_t i = threadIdx.x; i < nparts; i += 256) v = max(v, part[i]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
-    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) m[0] = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    if (threadIdx.x == 0) atomicMax(fullest, max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
 }
 
 // The local sort.  The radix passes order the entries by the row bits ABOVE gbits
@@ -570,14 +619,46 @@ __device__ __forceinline__ uint32_t group_lookback(unsigned long long *state, ui
     return mine;
 }
 
-template <typename T, int CAP>
-// (waves per SIMD the LDS footprint allows; eight at CAP = 1536 -- 63 registers, 2 spilled -- measured level with seven)
+// ---- the group kernel (round 4) ------------------------------------------------------------------------------------
+// One workgroup per group, as in round 3; what changed:
+//  * ids come from kTicketClasses = 8 counters: workgroup b draws from counter b & 7 and takes id = 8 * ticket + (b & 7)
+//    (class c has exactly as many workgroups as ids).  One device atomic on ONE address per workgroup is served at 87 M/s
+//    (tools/micro/ticket.hip): 39 063 tickets cost 447 us whatever else happens, +0.13 ms per assembly in round 3; eight
+//    addresses are served side by side (72 us per 39 063, spread over the launch).
+//  * the per-wave counters of the counting sort are read and written as LDS (lds_peek / lds_poke), not as volatile flat
+//    accesses with a full wait each.
+//  * PACKED: the last radix pass left column | row-in-group << (32 - gbits) in ONE word (12 instead of 16 bytes per entry).
+// Progress.  A group waits only for groups with SMALLER ids.  Class c hands its ids out in the order in which its
+// workgroups actually start, so inside a class the holder of an id started after the holders of all smaller ids of that
+// class.  Let g* be the lowest unfinished id, of class c.  If a workgroup holds it, it waits for nobody.  If nobody holds
+// it yet, every class-c workgroup that has started holds a smaller id and is therefore finished and gone; g* goes to the
+// next class-c workgroup the dispatcher starts.  That this workgroup does start is where the single counter of round 3
+// assumed nothing and this form assumes something: workgroups b & 7 == c run on XCD c (round-robin dispatch), whose slots
+// are only ever taken by class-c workgroups -- all finished, so free; what is assumed is that the dispatcher hands XCD c
+// its next workgroup while other XCDs are full of waiting workgroups (no head-of-line blocking across XCDs beyond what
+// blockIdx order already implies: under strictly ordered dispatch ids equal blockIdx and no workgroup ever waits for one
+// dispatched after it).  The spin bound is the backstop it always was: a look-back that gives up raises the error flag and
+// the host repeats the assembly on the general route (tested: SPAL_COO_LOOKBACK_SPINS=0); SPAL_COO_TICKET=1 takes the
+// single counter again, 0 takes blockIdx.
+// Measured and not kept (profiles/r04/coo_assembly.txt): a RESIDENT grid of occupancy x CUs workgroups walking through
+// dynamically drawn groups with the next group's entries in flight in a second register set, its bounds and the ticket
+// after that in flight too -- 1.39-1.59 ms for this kernel instead of 0.74, whatever the occupancy (3, 4, 5 workgroups per
+// CU): every workgroup holds the ids of its next groups while it works on (or waits in the look-back of) the current one,
+// every other workgroup's look-back needs those ids' counts, and whoever falls behind by one iteration stalls everyone by
+// one iteration.  One group per workgroup lets the dispatcher start the next group the moment a slot is free; a waiting
+// workgroup holds nothing anybody needs.
+constexpr uint32_t kTicketClasses = 8;
+// state[] tail behind the groups' look-back words: {error flags, fullest group, single ticket, -, tickets[kTicketClasses]}
+constexpr uint32_t kTailWords = 4 + kTicketClasses;
+
+template <typename T, int CAP, bool PACKED>
+// (workgroups per CU the LDS footprint allows; eight at CAP = 1536 measured level with seven in round 3)
 __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void coo_group_sort(const uint32_t *__restrict__ gstart,
                                                       const uint32_t *__restrict__ sorted_row,
                                                       const uint32_t *__restrict__ cols, const T *__restrict__ vals,
                                                       uint32_t nrows, uint32_t gbits, uint32_t ngroups,
                                                       unsigned long long *__restrict__ state, uint32_t *__restrict__ err,
-                                                      uint32_t *__restrict__ ticket, uint32_t spin_bound,
+                                                      uint32_t *__restrict__ tickets, uint32_t ticket_classes, uint32_t spin_bound,
                                                       uint32_t *__restrict__ rowptr, uint32_t *__restrict__ out_col,
                                                       T *__restrict__ out_val, uint2 *__restrict__ gwin) {
     constexpr int K = CAP / 256;  // rounds per wave = sorted positions per thread
@@ -588,9 +669,8 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
     constexpr size_t kRegion = CAP * sizeof(T) > kCntBytes + kRsBytes ? CAP * sizeof(T) : kCntBytes + kRsBytes;
     __shared__ __attribute__((aligned(16))) unsigned char s_region[kRegion];
     T *s_v2 = reinterpret_cast<T *>(s_region);
-    // volatile: lanes of a wave hand counts to each other through this array
-    // between two rounds; the compiler must re-read it every round
-    volatile uint32_t (*s_cnt)[256] = reinterpret_cast<volatile uint32_t (*)[256]>(s_region);
+    // lanes of a wave hand counts to each other through this array between two rounds (lds_peek / lds_poke)
+    uint32_t (*s_cnt)[256] = reinterpret_cast<uint32_t (*)[256]>(s_region);
     uint32_t *s_rs = reinterpret_cast<uint32_t *>(s_region + kCntBytes);   // 257 row starts
     __shared__ uint32_t s_c1[CAP];
     uint32_t *s_c2 = s_c1;   // (row, col) order replaces the row order in place (a barrier in between)
@@ -603,16 +683,21 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
 
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
-    // The group this workgroup takes: its ticket (start order), not its blockIdx (see group_lookback).  One atomic on
-    // one address per workgroup: the unit that serves it sustains 87 M/s (tools/micro/ticket.hip), the launch asks for
-    // 65 M/s -- the tickets cost this kernel 0.13 of 0.63 ms (profiles/r03/coo_assembly.txt).  Neither prefetching the
-    // groups' offsets around blockIdx while the atomic travels (no change: the wait is the queue at the atomic unit,
-    // not one more round trip) nor several groups per ticket (the launch serialises: a workgroup's first group waits
-    // for the LAST group of the workgroup before it) recovers it; a counter per blockIdx & 7 would (72 us per 39 063
-    // tickets) but needs a dispatcher that never starves a residue class -- an assumption again.
-    if (t == 0) s_base = ticket ? atomicAdd(ticket, 1u) : blockIdx.x;
+    // The group this workgroup takes: its ticket (start order inside its class), not its blockIdx (see above).
+    if (t == 0) {
+        uint32_t id = blockIdx.x;
+        if (tickets) {
+            if (ticket_classes > 1) {
+                const uint32_t cls = blockIdx.x & (kTicketClasses - 1);
+                id = atomicInc(&tickets[cls], 0xffffffffu) * kTicketClasses + cls;
+            } else {
+                id = atomicInc(tickets, 0xffffffffu);
+            }
+        }
+        s_base = id;
+    }
     __syncthreads();
-    const uint32_t grp = s_base;                          // < ngroups (ngroups workgroups, one ticket each)
+    const uint32_t grp = s_base;                          // < ngroups (ngroups workgroups; every class has as many workgroups as ids)
     const uint32_t e0 = gstart[grp], e1 = gstart[grp + 1];
     __syncthreads();                                      // (s_base is written again below)
     const uint32_t r0 = grp << gbits;                     // < nrows (there are ceil(nrows / 2^gbits) groups)
@@ -621,7 +706,7 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
     const bool last = grp + 1 == ngroups;
     // The capacity is the host's guess (the last assembly's fullest group, or mean + 6 sigma): a group that does not
     // fit raises *err bit 1, takes part in the look-back as an empty group (nobody waits for it) and the host runs
-    // the kernel again at the capacity the fullest group needs -- the device computes that beside (groups_check).
+    // the kernel again at the capacity the fullest group needs -- the device computes that beside (group_offsets / groups_check).
     if (n > (uint32_t)CAP) {
         if (t == 0) atomicOr(err, 2u);
         n = 0;
@@ -647,12 +732,21 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
     const uint32_t chunk = ((n + 255) / 256) * 64;        // entries per wave, a multiple of 64, <= 64 K
     uint32_t rc[K], pr[K];   // column; (row inside the group) << 16 | position (step 1: among the row's entries, then in the group)
     T rv[K];
+    {
+        const uint32_t cmask = gbits ? (0xffffffffu >> gbits) : 0xffffffffu, rshift = 32u - gbits;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const uint32_t ic = min(w * chunk + 64u * k + lane, n - 1);
-        rc[k] = cols[e0 + ic];
-        rv[k] = vals[e0 + ic];
-        pr[k] = (sorted_row[e0 + ic] - r0) << 16;
+        for (int k = 0; k < K; ++k) {
+            const uint32_t ic = min(w * chunk + 64u * k + lane, n - 1);
+            if (PACKED) {
+                const uint32_t q = cols[e0 + ic];
+                rc[k] = q & cmask;
+                pr[k] = (gbits ? (q >> rshift) : 0u) << 16;
+            } else {
+                rc[k] = cols[e0 + ic];
+                pr[k] = (sorted_row[e0 + ic] - r0) << 16;
+            }
+            rv[k] = vals[e0 + ic];
+        }
     }
     {
         for (uint32_t i = t; i < 4 * 256; i += 256) s_cnt[i >> 8][i & 255] = 0;
@@ -670,10 +764,10 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
                 const uint64_t m = __ballot((d >> b) & 1u);
                 peers &= ((d >> b) & 1u) ? m : ~m;
             }
-            const uint32_t before = ok ? s_cnt[w][d] : 0u;
+            const uint32_t before = ok ? lds_peek(&s_cnt[w][d]) : 0u;
             pr[k] |= before + (uint32_t)__popcll(peers & lt);
             // the lowest peer lane publishes the new count (one writer per row)
-            if (ok && (peers & lt) == 0) s_cnt[w][d] = before + (uint32_t)__popcll(peers);
+            if (ok && (peers & lt) == 0) lds_poke(&s_cnt[w][d], before + (uint32_t)__popcll(peers));
         }
         __syncthreads();
         {   // thread d: exclusive prefix of row d's counts over the waves, then the row starts
@@ -870,7 +964,7 @@ struct DevView {
 // when the COO matrix is uploaded (setup, not the timed path).
 struct CooWorkspace {
     size_t bytes = 0;
-    size_t off_key[2], off_aux[2], off_val[2], off_counts, off_sums, off_state, off_total, off_gwin, off_gstart, off_part;
+    size_t off_key[2], off_aux[2], off_val[2], off_counts, off_counts2, off_sums, off_state, off_total, off_gwin, off_gstart;
 };
 
 #ifndef SPAL_COO_GROUP_TARGET
@@ -904,12 +998,12 @@ static CooWorkspace coo_workspace_layout(uint64_t len, uint64_t nrows, size_t el
         w.off_val[i] = take(len * elem);
     }
     w.off_counts = take(ncounts * 4);
+    w.off_counts2 = take(ncounts * 4);
     w.off_sums = take(((scan_n + kScanTile - 1) / kScanTile) * 4);
-    w.off_state = take(ngroups * 8 + 16);   // the look-back words of coo_group_sort, then {error flags, ticket, fullest group, -}
+    w.off_state = take(ngroups * 8 + kTailWords * 4);   // the look-back words of coo_group_sort, then {error flags, fullest group, -, -, tickets[8]}
     w.off_total = take(4);
     w.off_gwin = take(ngroups * 8);         // one uint2 per group of rows
     w.off_gstart = take((ngroups + 1) * 4); // first sorted entry of every group
-    w.off_part = take((size_t)kCheckBlocks * 4);
     w.bytes = o;
     return w;
 }
@@ -964,6 +1058,7 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
         sb.val[i] = (T *)(wb + ws.off_val[i]);
     }
     sb.counts = (uint32_t *)(wb + ws.off_counts);
+    sb.counts2 = (uint32_t *)(wb + ws.off_counts2);
     sb.sums = sums.as<uint32_t>();
 
     // The groups of 2^gbits rows (about a thousand entries on average) that are finished in LDS.  EVERYTHING that
@@ -991,7 +1086,8 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
     if (const char *e = getenv("SPAL_COO_ROUTE")) if (!strcmp(e, "general")) group_cap = 0;
     uint32_t spin_bound = kLookbackSpins;
     if (const char *e = getenv("SPAL_COO_LOOKBACK_SPINS")) spin_bound = (uint32_t)strtoul(e, nullptr, 10);
-    const bool use_ticket = !(getenv("SPAL_COO_TICKET") && getenv("SPAL_COO_TICKET")[0] == '0');
+    int ticket_mode = 8;   // SPAL_COO_TICKET: 0 = blockIdx, 1 = one counter (round 3), anything else = the 8 class counters
+    if (const char *e = getenv("SPAL_COO_TICKET")) ticket_mode = e[0] == '0' ? 0 : (e[0] == '1' && !e[1]) ? 1 : 8;
     c->last_group_rows = 0;
     c->last_group_cap = 0;
     c->last_relaunches = 0;
@@ -1000,55 +1096,87 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
     DevBuf ocol, oval;
     int cur = 0;
     if (group_cap) {
-        // ---- 1. stable sort by the row bits above gbits, (col, value) carried along; the first pass reads the
-        // uploaded triplets directly (they stay untouched)
-        SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, gbits, rbits - gbits, cur, st, d_major, d_minor, (const T *)c->d_vals));
-        // ---- 2. the groups' offsets in the sorted triplets (one streaming pass over the sorted keys) and the fullest
         uint32_t *d_gstart = reinterpret_cast<uint32_t *>(wb + ws.off_gstart);
-        uint32_t *d_part = reinterpret_cast<uint32_t *>(wb + ws.off_part);
         uint2 *d_gwin = reinterpret_cast<uint2 *>(wb + ws.off_gwin);
         unsigned long long *d_state = reinterpret_cast<unsigned long long *>(wb + ws.off_state);
-        uint32_t *d_err = reinterpret_cast<uint32_t *>(d_state + ngroups);   // {flags, ticket, fullest, -}
-        launch_row_starts(sb.key[cur], (uint32_t)len, ngroups, d_gstart, st, gbits);
-        SPAL_HIP_TRY(hipMemsetAsync(d_state, 0, (size_t)ngroups * 8 + 16, st));
-        {
-            const uint32_t nparts = std::max<uint32_t>(std::min<uint32_t>((ngroups + 255) / 256, (uint32_t)kCheckBlocks), 1u);
-            hipLaunchKernelGGL(groups_check, dim3(nparts), dim3(256), 0, st, d_gstart, ngroups, d_part);
-            hipLaunchKernelGGL(groups_check_final, dim3(1), dim3(256), 0, st, d_part, nparts, d_err + 2);
+        uint32_t *d_err = reinterpret_cast<uint32_t *>(d_state + ngroups);   // {flags, fullest, -, -, tickets[8]}
+        SPAL_HIP_TRY(hipMemsetAsync(d_state, 0, (size_t)ngroups * 8 + kTailWords * 4, st));
+        // ---- 1. stable sort by the row bits above gbits, (col, value) carried along; the first pass reads the
+        // uploaded triplets directly (they stay untouched).  Exactly two passes (config 5: 16 bits): the groups' offsets
+        // come out of the passes' scanned counts (group_offsets), and when a column and the row inside its group fit one
+        // word the second pass writes that word instead of key + column (radix_scatter<T, true>).
+        const uint32_t sort_bits = rbits - gbits;
+        const bool two_pass = sort_bits > 8 && sort_bits <= 16 && !getenv("SPAL_COO_NO_OFFSETS");
+        const bool packed = two_pass && cbits + gbits <= 32 && !getenv("SPAL_COO_NO_PACK");
+        SPAL_HIP_TRY(radix_sort_bits<T>(sb, len, gbits, sort_bits, cur, st, d_major, d_minor, (const T *)c->d_vals,
+                                        two_pass, packed ? (int)gbits : -1));
+        // ---- 2. the groups' offsets in the sorted triplets
+        if (two_pass) {
+            const uint32_t nblk = (uint32_t)((len + kSortTile - 1) / kSortTile);
+            hipLaunchKernelGGL(group_offsets, dim3(256), dim3(256), 0, st, sb.counts, sb.counts2, sb.key[cur ^ 1], (uint32_t)len,
+                               nblk, gbits + 8, ngroups, d_gstart);
+        } else {
+            launch_row_starts(sb.key[cur], (uint32_t)len, ngroups, d_gstart, st, gbits);   // (one streaming pass over the sorted keys)
         }
+        hipLaunchKernelGGL(groups_check, dim3(std::max<uint32_t>(std::min<uint32_t>((ngroups + 255) / 256, 1024u), 1u)), dim3(256), 0, st,
+                           d_gstart, ngroups, d_err + 1);   // the fullest group (the kernel's capacity is a guess: see above)
         // ---- 3. per group: rows, columns, run sums, zero drop in LDS; its place in the result by look-back over
         // the groups before it; survivors and rowptr written at their final offsets.  The result arrays are sized
         // for no entry dropped (the count is only known afterwards) and trimmed when a quarter or more is unused.
         uint64_t cap = len + 256;  // + the stream kernel's over-read margin
         SPAL_HIP_TRY(ocol.alloc(cap * 4));
         SPAL_HIP_TRY(oval.alloc(cap * sizeof(T)));
-        std::vector<uint2> gwin(ngroups);
-        unsigned long long tail[3] = {0, 0, 0};   // the last group's state word (survivors of all groups); {flags, ticket}; {fullest, -}
+        // what comes back: the last group's state word (survivors of all groups), {flags, fullest}, the groups' column
+        // spans -- into PINNED host memory kept on the handle (two copies into pageable memory cost 0.12 ms of the call)
+        const size_t back_bytes = 16 + (size_t)ngroups * sizeof(uint2);
+        if (!c->h_back || c->h_back_bytes < back_bytes) {
+            if (c->h_back) { (void)hipHostFree(c->h_back); c->h_back = nullptr; c->h_back_bytes = 0; }
+            SPAL_HIP_TRY(hipHostMalloc(&c->h_back, back_bytes, hipHostMallocDefault));
+            c->h_back_bytes = back_bytes;
+        }
+        unsigned long long *tail = reinterpret_cast<unsigned long long *>(c->h_back);
+        uint2 *gwin = reinterpret_cast<uint2 *>(tail + 2);
+        tail[0] = tail[1] = 0;
         for (int attempt = 0; attempt < 2 && group_cap; ++attempt) {
-            auto k_sort = group_cap == 512 ? coo_group_sort<T, 512> : group_cap == 1024 ? coo_group_sort<T, 1024>
-                          : group_cap == 1536 ? coo_group_sort<T, 1536> : coo_group_sort<T, kGroupCap>;
+            typedef void (*group_kernel_t)(const uint32_t *, const uint32_t *, const uint32_t *, const T *, uint32_t, uint32_t,
+                                           uint32_t, unsigned long long *, uint32_t *, uint32_t *, uint32_t, uint32_t,
+                                           uint32_t *, uint32_t *, T *, uint2 *);
+            group_kernel_t k_sort;
+            if (packed)
+                k_sort = group_cap == 512 ? coo_group_sort<T, 512, true> : group_cap == 1024 ? coo_group_sort<T, 1024, true>
+                         : group_cap == 1536 ? coo_group_sort<T, 1536, true> : coo_group_sort<T, kGroupCap, true>;
+            else
+                k_sort = group_cap == 512 ? coo_group_sort<T, 512, false> : group_cap == 1024 ? coo_group_sort<T, 1024, false>
+                         : group_cap == 1536 ? coo_group_sort<T, 1536, false> : coo_group_sort<T, kGroupCap, false>;
+            // ids: 8 class counters (default), the single counter of round 3 (SPAL_COO_TICKET=1) or blockIdx (=0)
+            uint32_t *d_tickets = ticket_mode == 0 ? nullptr : ticket_mode == 1 ? d_err + 2 : d_err + 4;
             hipLaunchKernelGGL(k_sort, dim3(ngroups), dim3(256), 0, st, d_gstart, sb.key[cur], sb.aux[cur],
-                               sb.val[cur], nrows, gbits, ngroups, d_state, d_err, use_ticket ? d_err + 1 : nullptr, spin_bound,
-                               rowptr.as<uint32_t>(), ocol.as<uint32_t>(), oval.as<T>(), d_gwin);
+                               sb.val[cur], nrows, gbits, ngroups, d_state, d_err, d_tickets, ticket_mode == 1 ? 1u : kTicketClasses,
+                               spin_bound, rowptr.as<uint32_t>(), ocol.as<uint32_t>(), oval.as<T>(), d_gwin);
             SPAL_HIP_TRY(hipGetLastError());
-            SPAL_HIP_TRY(hipMemcpyAsync(tail, d_state + (ngroups - 1), 24, hipMemcpyDeviceToHost, st));
-            SPAL_HIP_TRY(hipMemcpyAsync(gwin.data(), d_gwin, (size_t)ngroups * sizeof(uint2), hipMemcpyDeviceToHost, st));
+            SPAL_HIP_TRY(hipMemcpyAsync(tail, d_state + (ngroups - 1), 16, hipMemcpyDeviceToHost, st));
+            SPAL_HIP_TRY(hipMemcpyAsync(gwin, d_gwin, (size_t)ngroups * sizeof(uint2), hipMemcpyDeviceToHost, st));
             SPAL_HIP_TRY(hipStreamSynchronize(st));
-            const uint32_t flags = (uint32_t)tail[1], fullest = (uint32_t)tail[2];
+            const uint32_t flags = (uint32_t)tail[1], fullest = (uint32_t)(tail[1] >> 32);
             c->cap_hint[o] = std::max<uint32_t>(fullest, 1u);
+            c->last_ticket = ticket_mode;
+            c->last_packed = packed ? 1 : 0;
+            c->last_offsets = two_pass ? 1 : 0;
             if (getenv("SPAL_COO_DEBUG"))
-                fprintf(stderr, "[spal coo] %.2f entries/row -> groups of %u rows, guessed %u, fullest %u, capacity %d, flags %u\n",
-                        mean, 1u << gbits, guess, fullest, group_cap, flags);
+                fprintf(stderr, "[spal coo] %.2f entries/row -> groups of %u rows, guessed %u, fullest %u, capacity %d, flags %u, ticket mode %d, %s, %s\n",
+                        mean, 1u << gbits, guess, fullest, group_cap, flags, ticket_mode, packed ? "packed" : "key + column",
+                        two_pass ? "offsets from the counts" : "offsets from the sorted keys");
             if (!(flags & 2u)) break;              // every group fitted
             // the guess was too small: once more at the capacity the fullest group needs (the sorted triplets and
             // the groups' offsets stand), or the general route when no capacity holds it
             group_cap = (flags & 1u) ? 0 : cap_for(fullest);
             c->last_relaunches++;
-            if (group_cap) {
-                SPAL_HIP_TRY(hipMemsetAsync(d_state, 0, (size_t)ngroups * 8 + 8, st));   // states, flags, ticket (not the maximum)
+            if (group_cap) {   // states, flags, tickets (the fullest group stands: it is a property of the sorted triplets)
+                SPAL_HIP_TRY(hipMemsetAsync(d_state, 0, (size_t)ngroups * 8 + 4, st));
+                SPAL_HIP_TRY(hipMemsetAsync(d_err + 2, 0, (kTailWords - 2) * 4, st));
             }
         }
-        if (group_cap && (uint32_t)tail[1] == 0 && (tail[0] >> 32) == 2) {
+        if (group_cap && (uint32_t)tail[1] == 0 && (tail[0] >> 32) == 2) {   // no flag raised, the last group knows its inclusive count
             nnz = (uint32_t)tail[0];
             c->last_group_rows = (int)(1u << gbits);
             c->last_group_cap = group_cap;
@@ -1209,6 +1337,7 @@ int transpose_device(int device, int elem_size, uint64_t nmajor, uint64_t nminor
 
 static void coo_free(spal_coo *c) {
     if (!c) return;
+    if (c->h_back) (void)hipHostFree(c->h_back);
     (void)dev_free(c->d_work);
     (void)dev_free(c->d_rows);
     (void)dev_free(c->d_cols);
@@ -1311,10 +1440,10 @@ int spal_coo_describe(spal_coo_t c, char *buf, size_t buf_len) {
     snprintf(buf, buf_len,
              "{\"format\": \"coo\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"len\": %llu, "
              "\"last_route\": \"%s\", \"group_rows\": %d, \"group_cap\": %d, \"group_relaunches\": %d, "
-             "\"lookback_gave_up\": %d}",
+             "\"lookback_gave_up\": %d, \"ticket_mode\": %d, \"packed_payload\": %d, \"offsets_from_counts\": %d}",
              c->elem_size == 8 ? "f64" : "f32", (unsigned long long)c->nrows, (unsigned long long)c->ncols,
              (unsigned long long)c->len, c->last_group_rows ? "local_sort" : "general", c->last_group_rows,
-             c->last_group_cap, c->last_relaunches, c->last_lookback_gave_up);
+             c->last_group_cap, c->last_relaunches, c->last_lookback_gave_up, c->last_ticket, c->last_packed, c->last_offsets);
     return SPAL_OK;
 }
 int spal_coo_assemble_csr(spal_coo_t c, void *stream, spal_csr_t *out) {
@@ -1325,7 +1454,8 @@ int spal_coo_assemble_csr(spal_coo_t c, void *stream, spal_csr_t *out) {
     Assembled r;
     SPAL_TRY(coo_assemble(c, false, (hipStream_t)stream, r));
     int st = csr_adopt_device(c->device, c->elem_size, c->nrows, c->ncols, r.nnz, r.cap, r.ptr, r.ind,
-                              r.val, out, r.win256.empty() ? nullptr : &r.win256);
+                              r.val, out, r.win256.empty() ? nullptr : &r.win256, false,
+                              !(getenv("SPAL_COO_EAGER_PLAN") && getenv("SPAL_COO_EAGER_PLAN")[0] == '1'));
     if (st != SPAL_OK) { (void)dev_free(r.ptr); (void)dev_free(r.ind); (void)dev_free(r.val); }
     return st;
 }

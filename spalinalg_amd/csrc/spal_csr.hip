@@ -828,7 +828,28 @@ static hipError_t launch_lanes(const spal_csr *a, const void *x, void *y, hipStr
     }
 }
 
+// A handle assembled on the device (spal_coo_assemble_csr) is a complete CSR matrix the moment the assembly returns --
+// shape, download, conversions work on its arrays -- but the plan of the PRODUCT kernels (tile heights, x windows, 16-bit
+// columns, ...: csr_plan_build, a dozen small kernels and host round trips, ~0.3 ms at config 5) is not part of
+// `CsrMatrix::from(&coo)` and is built when something first needs it: the first product, spal_csr_plan, set_option,
+// autotune, alloc_vectors or describe.  Under mu_cb, pending until finished, like the column-blocked copy below.
+int csr_ensure_plan(spal_csr *a, hipStream_t launch_stream, bool from_launch) {
+    if (!__atomic_load_n(&a->plan_pending, __ATOMIC_ACQUIRE)) return SPAL_OK;
+    std::lock_guard<std::mutex> lock(a->mu_cb);
+    if (!a->plan_pending) return SPAL_OK;
+    if (from_launch) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(launch_stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+            return fail(SPAL_ERR_INVALID_ARGUMENT, "the first product of a device-assembled handle plans its kernels and cannot be "
+                                                   "captured into a graph: call spal_csr_plan (or run one product) before the capture");
+    }
+    SPAL_TRY(csr_plan_build(a));
+    __atomic_store_n(&a->plan_pending, 0, __ATOMIC_RELEASE);
+    return SPAL_OK;
+}
+
 int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream) {
+    SPAL_TRY(csr_ensure_plan(a, stream, true));
     if (!a->parts.empty()) {   // row blocks: each writes its own rows of y
         for (size_t b = 0; b < a->parts.size(); ++b)
             SPAL_TRY(csr_launch(a->parts[b], x_dev, (char *)y_dev + a->part_row0[b] * (uint64_t)a->elem_size, stream));
@@ -1366,7 +1387,7 @@ static void csr_free(spal_csr *a) {
 
 int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, uint64_t nnz,
                      uint64_t cap_entries, uint32_t *d_rowptr, uint32_t *d_colind, void *d_values,
-                     spal_csr **out, const std::vector<uint2> *win256, bool eager_copies) {
+                     spal_csr **out, const std::vector<uint2> *win256, bool eager_copies, bool lazy_plan) {
     spal_csr *a = new spal_csr;
     if (win256 && win256->size() == (nrows + kWinBase - 1) / kWinBase) a->win_base = *win256;
     a->device = device;
@@ -1404,7 +1425,9 @@ int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, 
         }
         a->d_colind = ci; a->d_values = va; a->cap_entries = need;
     }
-    int st = csr_plan_build(a);
+    int st = SPAL_OK;
+    if (lazy_plan && nnz != 0) a->plan_pending = 1;   // (csr_ensure_plan)
+    else st = csr_plan_build(a);
     if (st != SPAL_OK) {
         const bool swapped = a->d_colind != d_colind;
         if (swapped) { (void)dev_free(a->d_colind); (void)dev_free(a->d_values); a->d_colind = d_colind; a->d_values = d_values; }
@@ -1799,6 +1822,7 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
     }
     DeviceGuard guard(a->device);
     if (guard.status != SPAL_OK) return guard.status;
+    SPAL_TRY(csr_ensure_plan(a, nullptr, false));
     std::lock_guard<std::mutex> lock(a->mu);
     CsrPlan saved = a->plan;
     CsrPlan &p = a->plan;
@@ -1966,6 +1990,7 @@ int spal_csr_alloc_vectors(spal_csr_t a, void **x_dev, void **y_dev, void *strea
     if (!a || !x_dev || !y_dev) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_alloc_vectors: null argument");
     DeviceGuard guard(a->device);
     if (guard.status != SPAL_OK) return guard.status;
+    SPAL_TRY(csr_ensure_plan(a, nullptr, false));
     std::lock_guard<std::mutex> lock(a->mu);
     const size_t es = (size_t)a->elem_size;
     auto up = [](size_t v) { return (v + 4095) & ~(size_t)4095; };
@@ -2045,6 +2070,12 @@ int spal_csr_autotune_f32(spal_csr_t a, const float *x_dev, float *y_dev, void *
     return csr_autotune<float>(a, x_dev, y_dev, stream, iters);
 }
 
+int spal_csr_plan(spal_csr_t a) {
+    if (!a) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_plan: handle is NULL");
+    DeviceGuard guard(a->device);
+    if (guard.status != SPAL_OK) return guard.status;
+    return csr_ensure_plan(a, nullptr, false);
+}
 int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
     if (!a || !buf || !buf_len) return fail(SPAL_ERR_INVALID_ARGUMENT, "spal_csr_describe: null argument");
     if (!a->parts.empty()) {   // row blocks: the shape of the whole, the cuts, and the first block's plan
@@ -2059,6 +2090,11 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
                  a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows, (unsigned long long)a->ncols,
                  (unsigned long long)a->nnz, a->parts.size(), rows.c_str(), first.data());
         return SPAL_OK;
+    }
+    {   // (describing the plan of a device-assembled handle builds it: what is printed is what the products will run)
+        DeviceGuard guard(a->device);
+        if (guard.status != SPAL_OK) return guard.status;
+        SPAL_TRY(csr_ensure_plan(a, nullptr, false));
     }
     const CsrPlan &p = a->plan;
     snprintf(buf, buf_len,

@@ -200,6 +200,7 @@ struct spal_csr {
     uint8_t *d_cb_cnt = nullptr;   // entries per (tile, row): the builder's scratch
     uint16_t *d_cb_row = nullptr;  // row of every entry inside its row block
     float cblock_us[2] = {0.f, 0.f};   // autotune: per launch {stream kernels, column-blocked kernel}
+    int plan_pending = 0;          // a device-assembled handle: the product kernels' plan is built by whoever needs it first (csr_ensure_plan)
     int cblock_lazy = 0;           // build the tiled copy with the first product, not with the plan (csr_adopt_device)
     int cblock_failed = 0;         // building it failed (out of memory, ...): the stream kernels run instead
     // spal_csr_alloc_vectors: the block of 1 GiB (or more) that holds the caller's x and y, found by the placement walk
@@ -298,16 +299,20 @@ struct spal_coo {
     // is kept between assemblies.
     uint32_t cap_hint[2] = {0, 0};
     size_t work_bytes = 0;
+    void *h_back = nullptr;   // pinned host memory the assembly's few results come back into
+    size_t h_back_bytes = 0;
     std::mutex mu;            // serialises assemblies on one handle (shared workspace)
     int last_group_rows = 0, last_group_cap = 0;  // geometry of the last assembly's local sort (0 = general route)
     int last_relaunches = 0;        // group kernel launched again because the capacity hint was too small
     int last_lookback_gave_up = 0;  // assemblies of this handle whose look-back hit its spin bound (backstop taken)
+    int last_ticket = 0, last_packed = 0, last_offsets = 0;   // how ids were handed out (0 blockIdx, 1 one counter, 8 class counters); packed payload; offsets from the passes' counts
 };
 
 namespace spal {
 // implemented in spal_csr.hip
 int csr_plan_build(spal_csr *a);
 int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream);
+int csr_ensure_plan(spal_csr *a, hipStream_t launch_stream, bool from_launch);
 // implemented in spal_csr_slide.hip: the sliding-window kernel for a plan with plan.slide set
 hipError_t launch_slide(const spal_csr *a, const void *x, void *y, hipStream_t st);
 // ... and the column-panel kernel over a->d_ptiles
@@ -328,5 +333,5 @@ hipError_t launch_cblock(const spal_csr *a, const void *x, void *y, hipStream_t 
 int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols,
                      uint64_t nnz, uint64_t cap_entries, uint32_t *d_rowptr,
                      uint32_t *d_colind, void *d_values, spal_csr **out,
-                     const std::vector<uint2> *win256 = nullptr, bool eager_copies = false);
+                     const std::vector<uint2> *win256 = nullptr, bool eager_copies = false, bool lazy_plan = false);
 }  // namespace spal

@@ -177,6 +177,11 @@ class _DeviceMatrix:
 class DeviceCsr(_DeviceMatrix):
     _kind = "csr"
 
+    def plan(self) -> None:
+        """spal_csr_plan: builds the product kernels' plan of a device-assembled handle now (otherwise its first product,
+        set_option, autotune, alloc_vectors or describe does).  No-op on handles created from host arrays."""
+        check(_ffi.lib().spal_csr_plan(self._h))
+
     def download(self):
         nrows, _, nnz = self.shape()
         rp = np.empty(nrows + 1, dtype=np.uint64)

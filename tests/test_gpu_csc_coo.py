@@ -745,21 +745,47 @@ def test_coo_lookback_backstop_takes_the_general_route(oracle, monkeypatch):
     dev.close()
 
 
-@pytest.mark.parametrize("ticket", ["1", "0"])
+@pytest.mark.parametrize("ticket", ["8", "1", "0"])
 def test_coo_group_ids_by_ticket_or_by_block_index(oracle, monkeypatch, ticket):
-    """Groups are handed out by a device ticket (start order) by default; SPAL_COO_TICKET=0 takes blockIdx (the
-    dispatch-order assumption of round 2).  Both must give the oracle's arrays; 20 assemblies of one handle agree."""
+    """Groups are handed out by device tickets in start order: by default from 8 class counters (round 4), with
+    SPAL_COO_TICKET=1 from the single counter of round 3; SPAL_COO_TICKET=0 takes blockIdx (the dispatch-order assumption
+    of round 2).  All must give the oracle's arrays; 20 assemblies of one handle agree."""
     monkeypatch.setenv("SPAL_COO_TICKET", ticket)
     nr, nc, r, c, v = _coo_case(321, n=3_000_000, nr=400_000)
     p, i, w = oracle.coo_to_csr(nr, nc, r, c, v)
     dev = sp.CooMatrix.with_triplets(nr, nc, r, c, v).upload()
     for _ in range(20):
         got = dev.assemble_csr()
-        assert dev.describe()["last_route"] == "local_sort"
+        d = dev.describe()
+        assert d["last_route"] == "local_sort" and d["ticket_mode"] == int(ticket), d
         gp, gi, gw = got.download()
         assert np.array_equal(gp, p) and np.array_equal(gi, i) and np.array_equal(gw.view(np.uint64), w.view(np.uint64))
         got.close()
     dev.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"SPAL_COO_NO_PACK": "1"}, {"SPAL_COO_NO_OFFSETS": "1"}])
+@pytest.mark.parametrize("by_cols", [False, True])
+def test_coo_two_pass_forms_agree(oracle, monkeypatch, env, by_cols):
+    """Round 4: with exactly two radix passes the groups' offsets come from the passes' scanned counts (group_offsets) and
+    the second pass writes column | row-in-group in one word.  Both switched off one by one (the round-3 forms: offsets
+    from the sorted keys, key + column) must give the same bits, by rows and by columns."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    nr, nc, r, c, v = _coo_case(77, n=2_500_000, nr=300_000)
+    dev = sp.CooMatrix.with_triplets(nr, nc, r, c, v).upload()
+    if by_cols:
+        p, i, w = oracle.coo_to_csc(nr, nc, r, c, v)
+        got = dev.assemble_csc()
+    else:
+        p, i, w = oracle.coo_to_csr(nr, nc, r, c, v)
+        got = dev.assemble_csr()
+    d = dev.describe()
+    assert d["last_route"] == "local_sort", d
+    assert d["offsets_from_counts"] == (0 if "SPAL_COO_NO_OFFSETS" in env else 1), d
+    assert d["packed_payload"] == (0 if env else 1), d
+    gp, gi, gw = got.download()
+    assert np.array_equal(gp, p) and np.array_equal(gi, i) and np.array_equal(gw.view(np.uint64), w.view(np.uint64))
 
 
 def test_assembled_handle_plans_like_an_uploaded_one(oracle):
