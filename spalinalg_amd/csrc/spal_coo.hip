@@ -174,16 +174,25 @@ constexpr int kWaveChunk = 64 * kSortItems;               // consecutive entries
 constexpr int kHistThreads = 256;
 constexpr int kHistItems = kSortTile / kHistThreads;
 
-// counts[d * nblk + blk] = number of keys of tile blk with digit d
-// (the order inside the tile does not matter here: 16-byte loads, 4 keys per lane).  A workgroup counts kHistGroup
-// consecutive tiles and writes, per digit, their counts as ONE run of kHistGroup words: the digit-major layout the scan
-// wants puts the counts of one tile 4 * nblk bytes apart, and one tile per workgroup wrote 107 MB for 12.5 MB of counts
-// at config 5 (profiles/r03/pmc_traffic.txt).
+// The digit counts of a pass and what the scatter derives its offsets from (round 4: no scan over all 256 x tiles counts --
+// three launches and 24 us per pass at config 5 -- any more):
+//   raw[d * stride + t]   keys of tile t with digit d, as counted (stride = tiles rounded up to whole groups of 16);
+//   gt[d * groups + g]    the total of digit d over group g's 16 tiles; after digit_scan: the digit's keys in the groups
+//                         BEFORE g (exclusive, inside the digit);
+//   dt[d]                 all keys with digit d.
+// Where tile t's keys with digit d go:  (sum of dt over smaller digits: 256 values, scanned by the scatter workgroup itself)
+//   + gt[d][t / 16] + the raw counts of the tiles of t's group before t (at most 15 words of one 64-byte line).
+struct PassCounts {
+    uint32_t *raw = nullptr, *gt = nullptr, *dt = nullptr;
+};
+// radix_hist: the order inside a tile does not matter here: 16-byte loads, 4 keys per lane.  A workgroup counts kHistGroup
+// consecutive tiles and writes, per digit, their counts as ONE run of kHistGroup words (one tile per workgroup wrote 107 MB
+// for 12.5 MB of counts at config 5: profiles/r03/pmc_traffic.txt), and the run's total.
 constexpr int kHistGroup = 16;
 __global__ __launch_bounds__(kHistThreads) void radix_hist(const uint32_t *__restrict__ keys,
                                                            uint64_t len, uint32_t shift,
-                                                           uint32_t *__restrict__ counts,
-                                                           uint32_t nblk) {
+                                                           uint32_t *__restrict__ raw, uint32_t *__restrict__ gt,
+                                                           uint32_t nblk, uint32_t stride, uint32_t groups) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     __shared__ uint32_t h[kHistGroup][257];   // (257: the transposed read below walks a column)
     for (int j = 0; j < kHistGroup; ++j) h[j][threadIdx.x] = 0;
@@ -215,11 +224,33 @@ __global__ __launch_bounds__(kHistThreads) void radix_hist(const uint32_t *__res
         }
     }
     __syncthreads();
-    // sixteen lanes write one digit's run of sixteen counts (64 contiguous bytes), a wave four digits' runs
-    const uint32_t n = min((uint32_t)kHistGroup, nblk - blk0);
+    // sixteen lanes write one digit's run of sixteen counts (64 contiguous, aligned bytes; zeros for tiles beyond the last),
+    // a wave four digits' runs
     const uint32_t g = threadIdx.x % kHistGroup;
     for (uint32_t d = threadIdx.x / kHistGroup; d < 256; d += kHistThreads / kHistGroup)
-        if (g < n) counts[(uint64_t)d * nblk + blk0 + g] = h[g][d];
+        raw[(uint64_t)d * stride + blk0 + g] = h[g][d];
+    {   // thread d: the group's total of digit d
+        const uint32_t d = threadIdx.x;
+        uint32_t tot = 0;
+#pragma unroll
+        for (int j = 0; j < kHistGroup; ++j) tot += h[j][d];
+        gt[(uint64_t)d * groups + blockIdx.x] = tot;
+    }
+}
+
+// Workgroup d: gt[d][.] -> its exclusive prefix in place (the digit's keys in earlier groups), dt[d] = the digit's total.
+__global__ __launch_bounds__(256) void digit_scan(uint32_t *__restrict__ gt, uint32_t *__restrict__ dt, uint32_t groups) {
+    uint32_t *row = gt + (uint64_t)blockIdx.x * groups;
+    uint32_t carry = 0;
+    for (uint32_t b = 0; b < groups; b += 256) {
+        const uint32_t i = b + threadIdx.x;
+        const uint32_t v = i < groups ? row[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, &total);
+        if (i < groups) row[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) dt[blockIdx.x] = carry;
 }
 
 // Stable scatter of one tile.  Wave w owns the tile's entries [w*1024, (w+1)*1024)
@@ -239,7 +270,8 @@ template <typename T, bool PACK = false>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter(
     const uint32_t *__restrict__ kin, const uint32_t *__restrict__ ain, const T *__restrict__ vin,
     uint32_t *__restrict__ kout, uint32_t *__restrict__ aout, T *__restrict__ vout, uint64_t len,
-    uint32_t shift, const uint32_t *__restrict__ offs, uint32_t nblk, uint32_t per_xcd, uint32_t pack_bits = 0) {
+    uint32_t shift, const uint32_t *__restrict__ raw, const uint32_t *__restrict__ gt, const uint32_t *__restrict__ dt,
+    uint32_t nblk, uint32_t stride, uint32_t groups, uint32_t per_xcd, uint32_t pack_bits = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_sort_smem[];
     T *s_val = reinterpret_cast<T *>(spal_sort_smem);                       // kSortTile
     uint32_t *s_key = reinterpret_cast<uint32_t *>(s_val + kSortTile);      // kSortTile
@@ -248,7 +280,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(
     uint32_t *cnt = s_aux + kSortTile;                                       // [kSortWaves][256]
     uint32_t *s_start = cnt + kSortWaves * 256;                              // [256] tile-local digit start
     uint32_t *s_delta = s_start + 256;                                       // [256] global - local
-    uint32_t *s_wsum = s_delta + 256;                                        // [4] digit-scan wave sums
+    uint32_t *s_wsum = s_delta + 256;                                        // [4] + [4] digit-scan wave sums (tile-local starts, digit bases)
 
     // tiles that run side by side on one XCD are neighbours in tile order, so the
     // partial cache lines they leave at the end of each digit's run meet in one L2
@@ -275,6 +307,20 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(
         aux[j] = ok ? ain[i] : 0u;
         val[j] = ok ? vin[i] : T(0);
     }
+    // thread d: where this tile's keys with digit d go, apart from the digits' bases (PassCounts) -- requested behind the
+    // tile's entries, summed when the ranks are done (asked for first and summed at once they held the entries' loads back:
+    // 379 instead of 351 us for the first pass at config 5)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    uint32_t my_dt = 0, my_gt = 0;
+    u32x4 my_line[kHistGroup / 4];
+    if (threadIdx.x < 256) {
+        const uint32_t d = threadIdx.x, grp = tile / (uint32_t)kHistGroup;
+        my_dt = dt[d];
+        my_gt = gt[(uint64_t)d * groups + grp];
+        const u32x4 *line = reinterpret_cast<const u32x4 *>(raw + (uint64_t)d * stride + (uint64_t)grp * kHistGroup);
+#pragma unroll
+        for (int q = 0; q < kHistGroup / 4; ++q) my_line[q] = line[q];
+    }
 #pragma unroll
     for (int j = 0; j < kSortItems; ++j) {
         const uint64_t i = w0 + (uint64_t)j * 64 + lane;
@@ -297,7 +343,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(
     // distance between the digit's global run and its place in the tile
     {
         const uint32_t d = threadIdx.x;  // the first 256 threads (whole waves) take the 256 digits
-        uint32_t run = 0, inc = 0;
+        uint32_t run = 0, inc = 0, inc_dt = 0;
         if (d < 256) {
 #pragma unroll
             for (int ww = 0; ww < kSortWaves; ++ww) {
@@ -306,17 +352,24 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter(
                 run += c;
             }
             inc = wave_inclusive_scan(run);
-            if (lane == 63) s_wsum[w] = inc;
+            inc_dt = wave_inclusive_scan(my_dt);
+            if (lane == 63) { s_wsum[w] = inc; s_wsum[4 + w] = inc_dt; }
         }
         __syncthreads();
         if (d < 256) {
-            uint32_t base = 0;
+            uint32_t base = 0, base_dt = 0;
 #pragma unroll
             for (uint32_t i = 0; i < 4; ++i)
-                if (i < w) base += s_wsum[i];
+                if (i < w) { base += s_wsum[i]; base_dt += s_wsum[4 + i]; }
             const uint32_t start = base + inc - run;
             s_start[d] = start;
-            s_delta[d] = offs[(uint64_t)d * nblk + tile] - start;
+            uint32_t my_before = my_gt;
+            const uint32_t in_grp = tile % (uint32_t)kHistGroup;
+#pragma unroll
+            for (int q = 0; q < kHistGroup / 4; ++q)
+                my_before += ((uint32_t)(4 * q) < in_grp ? my_line[q].x : 0u) + ((uint32_t)(4 * q + 1) < in_grp ? my_line[q].y : 0u) +
+                             ((uint32_t)(4 * q + 2) < in_grp ? my_line[q].z : 0u) + ((uint32_t)(4 * q + 3) < in_grp ? my_line[q].w : 0u);
+            s_delta[d] = (base_dt + inc_dt - my_dt) + my_before - start;   // keys with smaller digits + digit d's keys in earlier tiles
         }
     }
     __syncthreads();
@@ -355,14 +408,17 @@ struct SortBuffers {
     uint32_t *key[2] = {nullptr, nullptr};
     uint32_t *aux[2] = {nullptr, nullptr};
     T *val[2] = {nullptr, nullptr};
-    uint32_t *counts = nullptr;  // 256 * nblk
-    uint32_t *counts2 = nullptr; // the same again: the second pass's, when the first pass's scanned counts must survive it
-    uint32_t *sums = nullptr;    // scan scratch
+    PassCounts counts;           // raw 256 * stride, gt 256 * groups, dt 256
+    PassCounts counts2;          // the same again: the second pass's, when the first pass's counts must survive it
+    uint32_t *sums = nullptr;    // scan scratch (general route)
 };
+static uint32_t sort_tiles(uint64_t len) { return (uint32_t)((len + kSortTile - 1) / kSortTile); }
+static uint32_t sort_groups(uint64_t len) { return (sort_tiles(len) + kHistGroup - 1) / kHistGroup; }
+static uint32_t sort_stride(uint64_t len) { return sort_groups(len) * kHistGroup; }
 
 template <typename T>
 static size_t sort_lds_bytes() {
-    return (size_t)kSortTile * (sizeof(T) + 8) + (size_t)(kSortWaves * 256 + 512 + 4) * 4;
+    return (size_t)kSortTile * (sizeof(T) + 8) + (size_t)(kSortWaves * 256 + 512 + 8) * 4;
 }
 
 // Sorts by bits [lo_bit, lo_bit + nbits) of key, stably.  The first pass reads
@@ -377,8 +433,7 @@ static hipError_t radix_sort_bits(SortBuffers<T> &b, uint64_t len, uint32_t lo_b
                                   const uint32_t *a_in = nullptr, const T *v_in = nullptr,
                                   bool two_counts = false, int pack_bits = -1) {
     if (len == 0) return hipSuccess;
-    const uint32_t nblk = (uint32_t)((len + kSortTile - 1) / kSortTile);
-    const uint64_t ncounts = 256ull * nblk;
+    const uint32_t nblk = sort_tiles(len), groups = sort_groups(len), stride = sort_stride(len);
     const size_t lds = sort_lds_bytes<T>();
     {  // > 64 KiB of dynamic LDS needs the cap raised (per device; cheap, so every call)
         hipError_t e = hipFuncSetAttribute((const void *)radix_scatter<T, false>,
@@ -394,51 +449,59 @@ static hipError_t radix_sort_bits(SortBuffers<T> &b, uint64_t len, uint32_t lo_b
         const uint32_t *ai = k_in ? a_in : b.aux[cur];
         const T *vi = k_in ? v_in : b.val[cur];
         const int dst = k_in ? cur : (cur ^ 1);
-        uint32_t *counts = (two_counts && pass == 1) ? b.counts2 : b.counts;
-        {
-            hipLaunchKernelGGL(radix_hist, dim3((nblk + kHistGroup - 1) / kHistGroup), dim3(kHistThreads), 0, st, ki, len, shift,
-                               counts, nblk);
-            hipError_t e = exclusive_scan_u32(counts, counts, ncounts, b.sums, nullptr, st);
-            if (e != hipSuccess) return e;
-        }
+        const PassCounts &pc = (two_counts && pass == 1) ? b.counts2 : b.counts;
+        hipLaunchKernelGGL(radix_hist, dim3(groups), dim3(kHistThreads), 0, st, ki, len, shift, pc.raw, pc.gt, nblk, stride, groups);
+        hipLaunchKernelGGL(digit_scan, dim3(256), dim3(256), 0, st, pc.gt, pc.dt, groups);
         const uint32_t per_xcd = (nblk + 7) / 8;
         const bool last = shift + 8 >= lo_bit + nbits;
         if (last && pack_bits >= 0)
             hipLaunchKernelGGL((radix_scatter<T, true>), dim3(SPAL_SORT_XCD ? per_xcd * 8 : nblk), dim3(kSortThreads),
-                               lds, st, ki, ai, vi, b.key[dst], b.aux[dst], b.val[dst], len, shift, counts,
-                               nblk, per_xcd, (uint32_t)pack_bits);
+                               lds, st, ki, ai, vi, b.key[dst], b.aux[dst], b.val[dst], len, shift, pc.raw, pc.gt, pc.dt,
+                               nblk, stride, groups, per_xcd, (uint32_t)pack_bits);
         else
             hipLaunchKernelGGL((radix_scatter<T, false>), dim3(SPAL_SORT_XCD ? per_xcd * 8 : nblk), dim3(kSortThreads),
-                               lds, st, ki, ai, vi, b.key[dst], b.aux[dst], b.val[dst], len, shift, counts,
-                               nblk, per_xcd, 0u);
+                               lds, st, ki, ai, vi, b.key[dst], b.aux[dst], b.val[dst], len, shift, pc.raw, pc.gt, pc.dt,
+                               nblk, stride, groups, per_xcd, 0u);
         cur = dst;
         k_in = nullptr;
     }
     return hipGetLastError();
 }
 
-// The groups' offsets after exactly TWO passes, from the passes' own scanned counts (round 4; round 3 read all sorted
-// keys once more for them, rows_boundaries: 206 MB and 45 us at config 5).  Group g = d2 << 8 | d1 (d1 = the first
-// pass's digit, d2 = the second's).  The second pass's input is ordered by d1: bucket d1 begins at B[d1] = offs1[d1][tile
-// 0], inside tile t* = B[d1] / tile.  Entries ordered before group g in the result: every entry with a smaller d2, and of
-// those with the same d2 the ones in buckets before d1 -- that is offs2[d2][t*] (same d2, tiles before t*) plus the
-// entries with digit d2 inside tile t* that lie before B[d1], which workgroup d1 counts here (at most one tile of keys).
-__global__ __launch_bounds__(256) void group_offsets(const uint32_t *__restrict__ offs1, const uint32_t *__restrict__ offs2,
+// The groups' offsets after exactly TWO passes, from the passes' own counts (round 4; round 3 read all sorted keys once
+// more for them, rows_boundaries: 206 MB and 45 us at config 5).  Group g = d2 << 8 | d1 (d1 = the first pass's digit, d2
+// = the second's).  The second pass's input is ordered by d1: bucket d1 begins at B[d1] = the keys with a smaller first
+// digit, inside tile t* = B[d1] / tile.  Entries ordered before group g in the result: every entry with a smaller d2, and
+// of those with the same d2 the ones in buckets before d1 -- that is what the second pass's counts say about (d2, tiles
+// before t*) (PassCounts) plus the entries with digit d2 inside tile t* that lie before B[d1], which workgroup d1 counts
+// here (at most one tile of keys).
+__global__ __launch_bounds__(256) void group_offsets(const uint32_t *__restrict__ dt1, const uint32_t *__restrict__ raw2,
+                                                     const uint32_t *__restrict__ gt2, const uint32_t *__restrict__ dt2,
                                                      const uint32_t *__restrict__ keys1, uint32_t len, uint32_t nblk,
-                                                     uint32_t shift2, uint32_t ngroups, uint32_t *__restrict__ gstart) {
-    __shared__ uint32_t h[256];
+                                                     uint32_t stride, uint32_t groups, uint32_t shift2, uint32_t ngroups,
+                                                     uint32_t *__restrict__ gstart) {
+    __shared__ uint32_t h[256], s_b;
     const uint32_t d1 = blockIdx.x, t = threadIdx.x;
     h[t] = 0;
-    __syncthreads();
-    const uint32_t b = offs1[(uint64_t)d1 * nblk];
+    uint32_t total;
+    const uint32_t b_mine = block_exclusive_scan(dt1[t], &total);      // B[t]
+    if (t == d1) s_b = b_mine;
+    const uint32_t my_dt2 = dt2[t];
+    const uint32_t base2 = block_exclusive_scan(my_dt2, &total);       // keys with a second digit below t (has barriers: s_b, h are set)
+    const uint32_t b = s_b;
     const uint32_t tstar = b / (uint32_t)kSortTile, t0 = tstar * (uint32_t)kSortTile;
     for (uint32_t i = t0 + t; i < b; i += 256) atomicAdd(&h[(keys1[i] >> shift2) & 0xffu], 1u);
     __syncthreads();
     const uint32_t d2 = t, g = d2 << 8 | d1;
     if (g < ngroups) {
-        uint32_t v;
-        if (tstar < nblk) v = offs2[(uint64_t)d2 * nblk + tstar] + h[d2];
-        else v = d2 == 255u ? len : offs2[(uint64_t)(d2 + 1) * nblk];   // (the bucket begins at the very end: nothing of it exists)
+        uint32_t v = base2;
+        if (tstar < nblk) {
+            const uint32_t grp = tstar / (uint32_t)kHistGroup, in_grp = tstar % (uint32_t)kHistGroup;
+            v += gt2[(uint64_t)d2 * groups + grp] + h[d2];
+            for (uint32_t j = 0; j < in_grp; ++j) v += raw2[(uint64_t)d2 * stride + (uint64_t)grp * kHistGroup + j];
+        } else {
+            v += my_dt2;   // (the bucket begins at the very end: nothing of it exists, every key with this second digit lies before)
+        }
         gstart[g] = v;
     }
     if (d1 == 0 && t == 0) gstart[ngroups] = len;
@@ -619,6 +682,41 @@ __device__ __forceinline__ uint32_t group_lookback(unsigned long long *state, ui
     return mine;
 }
 
+// Bitonic sorting network on N registers (N a power of two, fully unrolled: every compare-exchange is one v_min_u32 and
+// one v_max_u32 with compile-time directions) -- a row's columns, one row per thread (coo_group_sort, step 2).
+template <int N>
+__device__ __forceinline__ void bitonic_sort_regs(uint32_t (&k)[N]) {
+#pragma unroll
+    for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int j = i ^ stride;
+                if (j > i) {
+                    const bool up = (i & size) == 0;
+                    const uint32_t lo = min(k[i], k[j]), hi = max(k[i], k[j]);
+                    k[i] = up ? lo : hi;
+                    k[j] = up ? hi : lo;
+                }
+            }
+        }
+    }
+}
+// One thread sorts ONE row's columns: reads the row's L <= N columns out of c1[a ...) (row order = insertion order), sorts
+// the keys column << 5 | place-in-row (unique, so ties between equal columns fall in insertion order: stable), and writes
+// to every entry's slot its place in (row, col) order instead of its column (the entries keep their columns in registers).
+template <int N>
+__device__ __forceinline__ void sort_row_in_regs(uint32_t *c1, uint32_t a, uint32_t L) {
+    uint32_t key[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) key[u] = (uint32_t)u < L ? (c1[a + u] << 5 | (uint32_t)u) : 0xffffffffu;
+    bitonic_sort_regs<N>(key);
+#pragma unroll
+    for (int u = 0; u < N; ++u)
+        if ((uint32_t)u < L) c1[a + (key[u] & 31u)] = a + (uint32_t)u;
+}
+
 // ---- the group kernel (round 4) ------------------------------------------------------------------------------------
 // One workgroup per group, as in round 3; what changed:
 //  * ids come from kTicketClasses = 8 counters: workgroup b draws from counter b & 7 and takes id = 8 * ticket + (b & 7)
@@ -647,13 +745,28 @@ __device__ __forceinline__ uint32_t group_lookback(unsigned long long *state, ui
 // every other workgroup's look-back needs those ids' counts, and whoever falls behind by one iteration stalls everyone by
 // one iteration.  One group per workgroup lets the dispatcher start the next group the moment a slot is free; a waiting
 // workgroup holds nothing anybody needs.
+#ifndef SPAL_COO_LB_1536
+#define SPAL_COO_LB_1536 7
+#endif
 constexpr uint32_t kTicketClasses = 8;
+// -DSPAL_COO_STAMPS (lab builds): thread 0 of every workgroup of coo_group_sort records wall_clock64() (100 MHz) at its
+// phase boundaries into g_coo_stamps[group][8]; the host writes the phases' mean durations to stderr after the assembly
+#ifdef SPAL_COO_STAMPS
+__device__ unsigned long long *g_coo_stamps = nullptr;
+#define SPAL_STAMP(i) do { if (threadIdx.x == 0 && g_coo_stamps) g_coo_stamps[(size_t)stamp_slot * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define SPAL_STAMP(i) do { } while (0)
+#endif
 // state[] tail behind the groups' look-back words: {error flags, fullest group, single ticket, -, tickets[kTicketClasses]}
 constexpr uint32_t kTailWords = 4 + kTicketClasses;
 
-template <typename T, int CAP, bool PACKED>
-// (workgroups per CU the LDS footprint allows; eight at CAP = 1536 measured level with seven in round 3)
-__global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void coo_group_sort(const uint32_t *__restrict__ gstart,
+// ROWSORT: step 2 by the per-row network and the wave-per-long-row pass (columns below 2^27, rows of at most 256 entries: a
+// group with a longer row raises *err bit 2 and the host runs the kernel again with ROWSORT = false, where every entry
+// counts its place for itself as in rounds 1-3 -- two kernels rather than two paths in one: the unused path's registers
+// were spilled by the used one).
+template <typename T, int CAP, bool PACKED, bool ROWSORT>
+// (workgroups per CU the LDS footprint allows; eight at CAP = 1536 measured behind seven)
+__global__ __launch_bounds__(256, CAP == 1536 ? SPAL_COO_LB_1536 : CAP == 2048 ? 5 : 8) void coo_group_sort(const uint32_t *__restrict__ gstart,
                                                       const uint32_t *__restrict__ sorted_row,
                                                       const uint32_t *__restrict__ cols, const T *__restrict__ vals,
                                                       uint32_t nrows, uint32_t gbits, uint32_t ngroups,
@@ -675,14 +788,21 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
     __shared__ uint32_t s_c1[CAP];
     uint32_t *s_c2 = s_c1;   // (row, col) order replaces the row order in place (a barrier in between)
     uint32_t *s_rk = reinterpret_cast<uint32_t *>(s_region);   // survivors per row: counted when the sorted values are dead too
-    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_wsum[4], s_wlong[4];
     __shared__ uint32_t s_wc[K * 4];
     __shared__ uint32_t s_cmin, s_cmax;   // columns of the survivors (the CSR planner's window input)
     __shared__ uint32_t s_base, s_total;  // survivors of the groups before this one / of this one
     __shared__ uint8_t s_r2[CAP];
+    __shared__ uint32_t s_nlong;          // rows of more than 16 entries, listed for the wave-per-row pass of step 2
+    __shared__ uint8_t s_long[256];
 
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t row_len = 0, row_a = 0;      // thread t's row of the group: entries, first place in row order
+#ifdef SPAL_COO_STAMPS
+    const uint32_t stamp_slot = blockIdx.x;
+#endif
+    SPAL_STAMP(0);
     // The group this workgroup takes: its ticket (start order inside its class), not its blockIdx (see above).
     if (t == 0) {
         uint32_t id = blockIdx.x;
@@ -698,8 +818,10 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
     }
     __syncthreads();
     const uint32_t grp = s_base;                          // < ngroups (ngroups workgroups; every class has as many workgroups as ids)
+    SPAL_STAMP(1);
     const uint32_t e0 = gstart[grp], e1 = gstart[grp + 1];
     __syncthreads();                                      // (s_base is written again below)
+    SPAL_STAMP(2);
     const uint32_t r0 = grp << gbits;                     // < nrows (there are ceil(nrows / 2^gbits) groups)
     const uint32_t nr = min(1u << gbits, nrows - r0);     // rows of this group, <= 256
     uint32_t n = e1 - e0;
@@ -730,27 +852,31 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
     // 0. one batch of loads (clamped lanes re-read the last entry: every load is issued unconditionally, back to
     // back); wave w owns the entries [w * chunk, (w + 1) * chunk)
     const uint32_t chunk = ((n + 255) / 256) * 64;        // entries per wave, a multiple of 64, <= 64 K
+    // (the VALUES are requested later, behind step 2: nothing before the scatter into (row, col) order looks at them, and
+    //  their registers -- 12 of 72 for f64 -- are what the row-sorting network of step 2 needs; the kernel is bound by its
+    //  VALU instructions, so the other workgroups of the CU cover the wait)
     uint32_t rc[K], pr[K];   // column; (row inside the group) << 16 | position (step 1: among the row's entries, then in the group)
-    T rv[K];
+    // (lanes beyond the group's last entry read the next group's entries, or up to 255 entries past the end of the sorted
+    //  arrays, which lie inside the workspace -- never looked at: one base address and immediate offsets instead of a clamp
+    //  and an address per load)
+    const size_t my0 = (size_t)e0 + w * chunk + lane;
     {
         const uint32_t cmask = gbits ? (0xffffffffu >> gbits) : 0xffffffffu, rshift = 32u - gbits;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const uint32_t ic = min(w * chunk + 64u * k + lane, n - 1);
             if (PACKED) {
-                const uint32_t q = cols[e0 + ic];
+                const uint32_t q = cols[my0 + 64u * k];
                 rc[k] = q & cmask;
                 pr[k] = (gbits ? (q >> rshift) : 0u) << 16;
             } else {
-                rc[k] = cols[e0 + ic];
-                pr[k] = (sorted_row[e0 + ic] - r0) << 16;
+                rc[k] = cols[my0 + 64u * k];
+                pr[k] = (sorted_row[my0 + 64u * k] - r0) << 16;
             }
-            rv[k] = vals[e0 + ic];
         }
     }
     {
         for (uint32_t i = t; i < 4 * 256; i += 256) s_cnt[i >> 8][i & 255] = 0;
-        if (t == 0) { s_cmin = 0xffffffffu; s_cmax = 0u; }
+        if (t == 0) { s_cmin = 0xffffffffu; s_cmax = 0u; s_nlong = 0u; }
         __syncthreads();
         // 1. stable counting sort by row inside the group
 #pragma unroll
@@ -770,6 +896,7 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
             if (ok && (peers & lt) == 0) lds_poke(&s_cnt[w][d], before + (uint32_t)__popcll(peers));
         }
         __syncthreads();
+        SPAL_STAMP(3);
         {   // thread d: exclusive prefix of row d's counts over the waves, then the row starts
             uint32_t run = 0;
 #pragma unroll
@@ -779,7 +906,10 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
                 run += c;
             }
             const uint32_t inc = wave_inclusive_scan(run);
-            if (lane == 63) s_wsum[w] = inc;
+            uint32_t longest = run;                             // the longest row of this wave's 64 rows
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o, 64));
+            if (lane == 63) { s_wsum[w] = inc; s_wlong[w] = longest; }
             __syncthreads();
             uint32_t base = 0;
 #pragma unroll
@@ -787,8 +917,11 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
                 if (i < w) base += s_wsum[i];
             s_rs[t] = base + inc - run;
             if (t == 255) s_rs[256] = base + inc;  // = n
+            row_len = run;
+            row_a = base + inc - run;
         }
         __syncthreads();
+        SPAL_STAMP(12);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             if (64u * k >= chunk) break;
@@ -798,7 +931,46 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
             }
         }
         __syncthreads();
-        // 2. rank by column inside the row -> (row, col) order
+        SPAL_STAMP(13);
+        // 2. rank by column inside the row -> (row, col) order.  The kernel is bound by its VALU instructions (8 400 wave
+        // instructions per group of 1 280 entries, a wave instruction holds a SIMD for four cycles: profiles/r04/
+        // coo_assembly.txt), and the entry-parallel count -- every entry walks its row -- was a third of them.  Now:
+        //  * a row of at most kRowNet = 16 entries is sorted by ONE thread in registers (thread t: row t; 80 compare-exchanges
+        //    of two instructions) which leaves every entry's place in the entry's slot of c1;
+        //  * longer rows (up to 256 entries) are listed and taken by a whole wave each, a lane per entry (four at most), the row
+        //    read as broadcasts -- a wave that met one such entry used to walk the loop for all its lanes;
+        //  * the entries pick their places up.
+        // Rows beyond 256 entries, or columns that leave no 5 bits free: the kernel's other form (ROWSORT = false).
+        constexpr uint32_t kRowNet = 16;
+        if (ROWSORT) {
+            const uint32_t group_longest = max(max(s_wlong[0], s_wlong[1]), max(s_wlong[2], s_wlong[3]));
+            if (group_longest > 256u && t == 0) atomicOr(err, 4u);   // (the result is discarded: the host takes the other kernel)
+            if (row_len > kRowNet) s_long[atomicAdd(&s_nlong, 1u)] = (uint8_t)t;     // (order of the list does not matter)
+            else if (s_wlong[w] > 1u) sort_row_in_regs<16>(s_c1, row_a, row_len);    // (wave-uniform: some row of this wave holds two or more)
+            else if (row_len) s_c1[row_a] = row_a;
+            __syncthreads();
+            for (uint32_t li = w; li < s_nlong; li += 4) {   // wave-uniform
+                const uint32_t d = s_long[li], a = s_rs[d], L = min(s_rs[d + 1] - a, 256u);
+                uint32_t ci[4], rank[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ci[c] = s_c1[a + min(lane + 64u * c, L - 1)];
+                for (uint32_t j = 0; j < L; ++j) {
+                    const uint32_t q = s_c1[a + j];               // one address for the wave: a broadcast
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (64u * c < L) rank[c] += (uint32_t)((q < ci[c]) | ((q == ci[c]) & (j < lane + 64u * c)));   // (wave-uniform test)
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)                       // (after the wave's last read of the row: LDS keeps a wave's order)
+                    if (lane + 64u * c < L) s_c1[a + lane + 64u * c] = a + rank[c];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (64u * k >= chunk) break;
+                if (w * chunk + 64u * k + lane < n) pr[k] = (pr[k] & 0xffff0000u) | s_c1[pr[k] & 0xffffu];
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             if (64u * k >= chunk) break;
@@ -819,7 +991,12 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
                 pr[k] = (pr[k] & 0xffff0000u) | (a + rank);
             }
         }
-        __syncthreads();   // every rank is known: the row-ordered columns may be overwritten
+        }
+        T rv[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) rv[k] = vals[my0 + 64u * k];
+        __syncthreads();   // every rank is known (and picked up): the row-ordered columns may be overwritten
+        SPAL_STAMP(14);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             if (64u * k >= chunk) break;
@@ -830,6 +1007,7 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
             }
         }
         __syncthreads();
+        SPAL_STAMP(15);
         const uint32_t cur_n = n;
         // 3. heads and run sums; thread t takes the sorted positions t, t + 256, ...
         T acc[K];
@@ -859,6 +1037,7 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
             if (lane == 0) s_wc[k * 4 + w] = (uint32_t)__popcll(km);
         }
         __syncthreads();
+        SPAL_STAMP(4);
         // 4. numbering in sorted order = (round, wave, lane); the group's place in the result (look-back over the
         // groups before it); survivors written at their FINAL offsets; rowptr of the group's rows
         s_rk[t] = 0;   // (in the sorted values' space: the run sums above were their last readers)
@@ -872,6 +1051,7 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
             if (t == 0) { s_base = before; s_total = total; }
         }
         __syncthreads();
+        SPAL_STAMP(5);
         const uint32_t before = s_base;
         uint32_t cmin = 0xffffffffu, cmax = 0u;
 #pragma unroll
@@ -913,6 +1093,11 @@ __global__ __launch_bounds__(256, CAP == 1536 ? 7 : CAP == 2048 ? 5 : 8) void co
             out_col[nnz + t] = 0u;                            // the stream kernel's over-read margin (256 entries)
             out_val[nnz + t] = T(0);
         }
+        SPAL_STAMP(6);
+#ifdef SPAL_COO_STAMPS
+        __builtin_amdgcn_s_waitcnt(0);   // (the stores have drained)
+        SPAL_STAMP(7);
+#endif
     }
 }
 
@@ -964,7 +1149,7 @@ struct DevView {
 // when the COO matrix is uploaded (setup, not the timed path).
 struct CooWorkspace {
     size_t bytes = 0;
-    size_t off_key[2], off_aux[2], off_val[2], off_counts, off_counts2, off_sums, off_state, off_total, off_gwin, off_gstart;
+    size_t off_key[2], off_aux[2], off_val[2], off_raw[2], off_gt[2], off_dt[2], off_sums, off_state, off_total, off_gstart;
 };
 
 #ifndef SPAL_COO_GROUP_TARGET
@@ -988,22 +1173,23 @@ static CooWorkspace coo_workspace_layout(uint64_t len, uint64_t nrows, size_t el
     CooWorkspace w;
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 255) & ~(size_t)255; return r; };
-    const uint64_t nblk = (len + kSortTile - 1) / kSortTile;
-    const uint64_t ncounts = 256ull * std::max<uint64_t>(nblk, 1);
-    const uint64_t scan_n = std::max<uint64_t>(ncounts, len);
+    const uint64_t scan_n = std::max<uint64_t>(len, 1);   // (the general route scans one flag per entry)
     const uint64_t ngroups = len ? coo_group_count(len, nrows) : 1;
     for (int i = 0; i < 2; ++i) {
         w.off_key[i] = take(len * 4);
         w.off_aux[i] = take(len * 4);
         w.off_val[i] = take(len * elem);
     }
-    w.off_counts = take(ncounts * 4);
-    w.off_counts2 = take(ncounts * 4);
+    for (int i = 0; i < 2; ++i) {   // PassCounts of the two passes
+        w.off_raw[i] = take(256ull * std::max<uint32_t>(sort_stride(len), kHistGroup) * 4);
+        w.off_gt[i] = take(256ull * std::max<uint32_t>(sort_groups(len), 1) * 4);
+        w.off_dt[i] = take(256 * 4);
+    }
     w.off_sums = take(((scan_n + kScanTile - 1) / kScanTile) * 4);
     w.off_state = take(ngroups * 8 + kTailWords * 4);   // the look-back words of coo_group_sort, then {error flags, fullest group, -, -, tickets[8]}
     w.off_total = take(4);
-    w.off_gwin = take(ngroups * 8);         // one uint2 per group of rows
     w.off_gstart = take((ngroups + 1) * 4); // first sorted entry of every group
+    (void)take(4096);                       // (the group kernel's last lanes read up to 255 entries past the sorted arrays' end)
     w.bytes = o;
     return w;
 }
@@ -1019,6 +1205,9 @@ struct Assembled {
     // {first, one past last} minor index of every 256 majors of the result, when the local
     // sort produced it on the way (saves the CSR planner its own pass over the matrix)
     std::vector<uint2> win256;
+    // ... or, still on the device, per group of 2^gwin_bits majors (ownership passes to whoever takes the result)
+    uint2 *d_gwin = nullptr;
+    uint32_t gwin_n = 0, gwin_bits = 0;
 };
 
 template <typename T>
@@ -1057,8 +1246,8 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
         sb.aux[i] = (uint32_t *)(wb + ws.off_aux[i]);
         sb.val[i] = (T *)(wb + ws.off_val[i]);
     }
-    sb.counts = (uint32_t *)(wb + ws.off_counts);
-    sb.counts2 = (uint32_t *)(wb + ws.off_counts2);
+    sb.counts = PassCounts{(uint32_t *)(wb + ws.off_raw[0]), (uint32_t *)(wb + ws.off_gt[0]), (uint32_t *)(wb + ws.off_dt[0])};
+    sb.counts2 = PassCounts{(uint32_t *)(wb + ws.off_raw[1]), (uint32_t *)(wb + ws.off_gt[1]), (uint32_t *)(wb + ws.off_dt[1])};
     sb.sums = sums.as<uint32_t>();
 
     // The groups of 2^gbits rows (about a thousand entries on average) that are finished in LDS.  EVERYTHING that
@@ -1097,7 +1286,11 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
     int cur = 0;
     if (group_cap) {
         uint32_t *d_gstart = reinterpret_cast<uint32_t *>(wb + ws.off_gstart);
-        uint2 *d_gwin = reinterpret_cast<uint2 *>(wb + ws.off_gwin);
+        // (the groups' column spans stay on the device, in a block of their own that goes with the result: the CSR planner
+        //  fetches them when -- if -- a plan is built; round 3 copied 312 KB back inside every assembly)
+        DevBuf gwin_buf;
+        SPAL_HIP_TRY(gwin_buf.alloc((size_t)ngroups * sizeof(uint2)));
+        uint2 *d_gwin = gwin_buf.as<uint2>();
         unsigned long long *d_state = reinterpret_cast<unsigned long long *>(wb + ws.off_state);
         uint32_t *d_err = reinterpret_cast<uint32_t *>(d_state + ngroups);   // {flags, fullest, -, -, tickets[8]}
         SPAL_HIP_TRY(hipMemsetAsync(d_state, 0, (size_t)ngroups * 8 + kTailWords * 4, st));
@@ -1112,9 +1305,9 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
                                         two_pass, packed ? (int)gbits : -1));
         // ---- 2. the groups' offsets in the sorted triplets
         if (two_pass) {
-            const uint32_t nblk = (uint32_t)((len + kSortTile - 1) / kSortTile);
-            hipLaunchKernelGGL(group_offsets, dim3(256), dim3(256), 0, st, sb.counts, sb.counts2, sb.key[cur ^ 1], (uint32_t)len,
-                               nblk, gbits + 8, ngroups, d_gstart);
+            hipLaunchKernelGGL(group_offsets, dim3(256), dim3(256), 0, st, sb.counts.dt, sb.counts2.raw, sb.counts2.gt, sb.counts2.dt,
+                               sb.key[cur ^ 1], (uint32_t)len, sort_tiles(len), sort_stride(len), sort_groups(len), gbits + 8,
+                               ngroups, d_gstart);
         } else {
             launch_row_starts(sb.key[cur], (uint32_t)len, ngroups, d_gstart, st, gbits);   // (one streaming pass over the sorted keys)
         }
@@ -1126,28 +1319,29 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
         uint64_t cap = len + 256;  // + the stream kernel's over-read margin
         SPAL_HIP_TRY(ocol.alloc(cap * 4));
         SPAL_HIP_TRY(oval.alloc(cap * sizeof(T)));
-        // what comes back: the last group's state word (survivors of all groups), {flags, fullest}, the groups' column
-        // spans -- into PINNED host memory kept on the handle (two copies into pageable memory cost 0.12 ms of the call)
-        const size_t back_bytes = 16 + (size_t)ngroups * sizeof(uint2);
+        // what comes back: the last group's state word (survivors of all groups) and {flags, fullest} -- into PINNED host
+        // memory kept on the handle (copies into pageable memory cost 0.12 ms of the call)
+        const size_t back_bytes = 16;
         if (!c->h_back || c->h_back_bytes < back_bytes) {
             if (c->h_back) { (void)hipHostFree(c->h_back); c->h_back = nullptr; c->h_back_bytes = 0; }
             SPAL_HIP_TRY(hipHostMalloc(&c->h_back, back_bytes, hipHostMallocDefault));
             c->h_back_bytes = back_bytes;
         }
         unsigned long long *tail = reinterpret_cast<unsigned long long *>(c->h_back);
-        uint2 *gwin = reinterpret_cast<uint2 *>(tail + 2);
         tail[0] = tail[1] = 0;
-        for (int attempt = 0; attempt < 2 && group_cap; ++attempt) {
+        // step 2 of the group kernel by the per-row network (columns << 5 | place-in-row must fit a word; a row beyond 256
+        // entries sends the assembly to the kernel's other form: remembered on the handle like the capacity)
+        bool row_sort = cbits <= 27 && !c->loop_hint[o] && !getenv("SPAL_COO_LOOP_RANKS");
+        for (int attempt = 0; attempt < 3 && group_cap; ++attempt) {
             typedef void (*group_kernel_t)(const uint32_t *, const uint32_t *, const uint32_t *, const T *, uint32_t, uint32_t,
                                            uint32_t, unsigned long long *, uint32_t *, uint32_t *, uint32_t, uint32_t,
                                            uint32_t *, uint32_t *, T *, uint2 *);
             group_kernel_t k_sort;
-            if (packed)
-                k_sort = group_cap == 512 ? coo_group_sort<T, 512, true> : group_cap == 1024 ? coo_group_sort<T, 1024, true>
-                         : group_cap == 1536 ? coo_group_sort<T, 1536, true> : coo_group_sort<T, kGroupCap, true>;
-            else
-                k_sort = group_cap == 512 ? coo_group_sort<T, 512, false> : group_cap == 1024 ? coo_group_sort<T, 1024, false>
-                         : group_cap == 1536 ? coo_group_sort<T, 1536, false> : coo_group_sort<T, kGroupCap, false>;
+#define SPAL_GROUP_KERNEL(P, R) (group_cap == 512 ? coo_group_sort<T, 512, P, R> : group_cap == 1024 ? coo_group_sort<T, 1024, P, R> \
+                                 : group_cap == 1536 ? coo_group_sort<T, 1536, P, R> : coo_group_sort<T, kGroupCap, P, R>)
+            if (packed) k_sort = row_sort ? SPAL_GROUP_KERNEL(true, true) : SPAL_GROUP_KERNEL(true, false);
+            else k_sort = row_sort ? SPAL_GROUP_KERNEL(false, true) : SPAL_GROUP_KERNEL(false, false);
+#undef SPAL_GROUP_KERNEL
             // ids: 8 class counters (default), the single counter of round 3 (SPAL_COO_TICKET=1) or blockIdx (=0)
             uint32_t *d_tickets = ticket_mode == 0 ? nullptr : ticket_mode == 1 ? d_err + 2 : d_err + 4;
             hipLaunchKernelGGL(k_sort, dim3(ngroups), dim3(256), 0, st, d_gstart, sb.key[cur], sb.aux[cur],
@@ -1155,8 +1349,31 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
                                spin_bound, rowptr.as<uint32_t>(), ocol.as<uint32_t>(), oval.as<T>(), d_gwin);
             SPAL_HIP_TRY(hipGetLastError());
             SPAL_HIP_TRY(hipMemcpyAsync(tail, d_state + (ngroups - 1), 16, hipMemcpyDeviceToHost, st));
-            SPAL_HIP_TRY(hipMemcpyAsync(gwin, d_gwin, (size_t)ngroups * sizeof(uint2), hipMemcpyDeviceToHost, st));
             SPAL_HIP_TRY(hipStreamSynchronize(st));
+#ifdef SPAL_COO_STAMPS
+            {
+                std::vector<unsigned long long> hs((size_t)ngroups * 16);
+                SPAL_HIP_TRY(hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+                // order of the stamps in time
+                static const int order[12] = {0, 1, 2, 3, 12, 13, 14, 15, 4, 5, 6, 7};
+                static const char *name[12] = {"", "ticket", "bounds", "loads+rowsort", "row starts", "placed in row order", "ranks", "sorted arrays",
+                                               "heads+sums", "look-back", "stores issued", "stores drained"};
+                double sum[12] = {0};
+                unsigned long long first = ~0ull, lastt = 0, cnt = 0;
+                for (uint32_t g = 0; g < ngroups; ++g) {
+                    const unsigned long long *q = &hs[(size_t)g * 16];
+                    if (!q[7]) continue;
+                    for (int i = 1; i < 12; ++i) sum[i] += (double)(q[order[i]] - q[order[i - 1]]);
+                    first = std::min(first, q[0]); lastt = std::max(lastt, q[7]); ++cnt;
+                }
+                if (cnt) {
+                    fprintf(stderr, "[spal coo stamps] %llu workgroups, kernel %.1f us; mean us per phase:", cnt, (double)(lastt - first) / 100.0);
+                    double tot = 0;
+                    for (int i = 1; i < 12; ++i) { fprintf(stderr, " %s %.2f,", name[i], sum[i] / cnt / 100.0); tot += sum[i] / cnt / 100.0; }
+                    fprintf(stderr, " residence %.2f\n", tot);
+                }
+            }
+#endif
             const uint32_t flags = (uint32_t)tail[1], fullest = (uint32_t)(tail[1] >> 32);
             c->cap_hint[o] = std::max<uint32_t>(fullest, 1u);
             c->last_ticket = ticket_mode;
@@ -1166,10 +1383,13 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
                 fprintf(stderr, "[spal coo] %.2f entries/row -> groups of %u rows, guessed %u, fullest %u, capacity %d, flags %u, ticket mode %d, %s, %s\n",
                         mean, 1u << gbits, guess, fullest, group_cap, flags, ticket_mode, packed ? "packed" : "key + column",
                         two_pass ? "offsets from the counts" : "offsets from the sorted keys");
-            if (!(flags & 2u)) break;              // every group fitted
+            c->last_row_sort = row_sort ? 1 : 0;
+            if (!(flags & 6u)) break;              // every group fitted, no row too long for the kernel's form
             // the guess was too small: once more at the capacity the fullest group needs (the sorted triplets and
-            // the groups' offsets stand), or the general route when no capacity holds it
-            group_cap = (flags & 1u) ? 0 : cap_for(fullest);
+            // the groups' offsets stand), or the general route when no capacity holds it; a row beyond the network
+            // form's reach: once more with the other form
+            group_cap = (flags & 1u) ? 0 : (flags & 2u) ? cap_for(fullest) : group_cap;
+            if (flags & 4u) { row_sort = false; c->loop_hint[o] = 1; }
             c->last_relaunches++;
             if (group_cap) {   // states, flags, tickets (the fullest group stands: it is a property of the sorted triplets)
                 SPAL_HIP_TRY(hipMemsetAsync(d_state, 0, (size_t)ngroups * 8 + 4, st));
@@ -1180,15 +1400,7 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
             nnz = (uint32_t)tail[0];
             c->last_group_rows = (int)(1u << gbits);
             c->last_group_cap = group_cap;
-            {   // fold the groups (2^gbits <= 256 rows each) into windows of 256 rows
-                const uint32_t per = 256u >> gbits;
-                res.win256.assign(((size_t)nrows + 255) / 256, make_uint2(0xffffffffu, 0u));
-                for (uint32_t g = 0; g < ngroups; ++g) {
-                    uint2 &w = res.win256[g / per];
-                    w.x = std::min(w.x, gwin[g].x);
-                    w.y = std::max(w.y, gwin[g].y);
-                }
-            }
+            res.d_gwin = (uint2 *)gwin_buf.release(); res.gwin_n = ngroups; res.gwin_bits = gbits;
             if (((uint64_t)nnz + 256) * 4 <= cap * 3) {   // many duplicates summed: do not keep len-sized arrays
                 DevBuf tcol, tval;
                 const uint64_t tcap = (uint64_t)nnz + 256;
@@ -1297,7 +1509,7 @@ static int transpose_t(int device, uint64_t nmajor, uint64_t nminor, uint64_t nn
             sb.aux[i] = (uint32_t *)(wb + ws.off_aux[i]);
             sb.val[i] = (T *)(wb + ws.off_val[i]);
         }
-        sb.counts = (uint32_t *)(wb + ws.off_counts);
+        sb.counts = PassCounts{(uint32_t *)(wb + ws.off_raw[0]), (uint32_t *)(wb + ws.off_gt[0]), (uint32_t *)(wb + ws.off_dt[0])};
         sb.sums = (uint32_t *)(wb + ws.off_sums);
         hipLaunchKernelGGL(expand_major, dim3((uint32_t)((nmajor + 255) / 256)), dim3(256), 0, st, d_ptr,
                            (uint32_t)nmajor, major.as<uint32_t>());
@@ -1440,10 +1652,10 @@ int spal_coo_describe(spal_coo_t c, char *buf, size_t buf_len) {
     snprintf(buf, buf_len,
              "{\"format\": \"coo\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"len\": %llu, "
              "\"last_route\": \"%s\", \"group_rows\": %d, \"group_cap\": %d, \"group_relaunches\": %d, "
-             "\"lookback_gave_up\": %d, \"ticket_mode\": %d, \"packed_payload\": %d, \"offsets_from_counts\": %d}",
+             "\"lookback_gave_up\": %d, \"ticket_mode\": %d, \"packed_payload\": %d, \"offsets_from_counts\": %d, \"row_sort\": %d}",
              c->elem_size == 8 ? "f64" : "f32", (unsigned long long)c->nrows, (unsigned long long)c->ncols,
              (unsigned long long)c->len, c->last_group_rows ? "local_sort" : "general", c->last_group_rows,
-             c->last_group_cap, c->last_relaunches, c->last_lookback_gave_up, c->last_ticket, c->last_packed, c->last_offsets);
+             c->last_group_cap, c->last_relaunches, c->last_lookback_gave_up, c->last_ticket, c->last_packed, c->last_offsets, c->last_row_sort);
     return SPAL_OK;
 }
 int spal_coo_assemble_csr(spal_coo_t c, void *stream, spal_csr_t *out) {
@@ -1455,7 +1667,8 @@ int spal_coo_assemble_csr(spal_coo_t c, void *stream, spal_csr_t *out) {
     SPAL_TRY(coo_assemble(c, false, (hipStream_t)stream, r));
     int st = csr_adopt_device(c->device, c->elem_size, c->nrows, c->ncols, r.nnz, r.cap, r.ptr, r.ind,
                               r.val, out, r.win256.empty() ? nullptr : &r.win256, false,
-                              !(getenv("SPAL_COO_EAGER_PLAN") && getenv("SPAL_COO_EAGER_PLAN")[0] == '1'));
+                              !(getenv("SPAL_COO_EAGER_PLAN") && getenv("SPAL_COO_EAGER_PLAN")[0] == '1'),
+                              r.d_gwin, r.gwin_n, r.gwin_bits);   // (takes the spans' block, also when it fails)
     if (st != SPAL_OK) { (void)dev_free(r.ptr); (void)dev_free(r.ind); (void)dev_free(r.val); }
     return st;
 }
@@ -1466,6 +1679,8 @@ int spal_coo_assemble_csc(spal_coo_t c, void *stream, spal_csc_t *out) {
     if (guard.status != SPAL_OK) return guard.status;
     Assembled r;
     SPAL_TRY(coo_assemble(c, true, (hipStream_t)stream, r));
+    (void)dev_free(r.d_gwin);   // (the groups' ROW spans: the CSC planner has no use for them)
+    r.d_gwin = nullptr;
     if (r.cap < r.nnz + 256) {  // csc handles expect the over-read margin too
         uint32_t *ind = nullptr;
         void *val = nullptr;

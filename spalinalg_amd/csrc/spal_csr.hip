@@ -1071,7 +1071,26 @@ static int stream_plan(spal_csr *a, uint32_t R, uint32_t rpt, std::vector<uint4>
 }
 
 // Chooses the kernel and its parameters and builds the per-block tables.
+// the assembly's per-group column spans -> win_base (per 256 rows), once
+static int csr_fetch_group_windows(spal_csr *a) {
+    if (!a->d_win_groups) return SPAL_OK;
+    std::vector<uint2> g(a->win_groups);
+    hipError_t e = hipMemcpy(g.data(), a->d_win_groups, (size_t)a->win_groups * sizeof(uint2), hipMemcpyDeviceToHost);
+    (void)dev_free(a->d_win_groups);
+    a->d_win_groups = nullptr;
+    SPAL_HIP_TRY(e);
+    const uint32_t per = 256u >> a->win_group_bits;
+    a->win_base.assign(((size_t)a->nrows + 255) / 256, make_uint2(0xffffffffu, 0u));
+    for (uint32_t i = 0; i < a->win_groups; ++i) {
+        uint2 &w = a->win_base[i / per];
+        w.x = std::min(w.x, g[i].x);
+        w.y = std::max(w.y, g[i].y);
+    }
+    return SPAL_OK;
+}
+
 int csr_plan_build(spal_csr *a) {
+    SPAL_TRY(csr_fetch_group_windows(a));
     CsrPlan &p = a->plan;
     const double mean = a->nrows ? (double)a->nnz / (double)a->nrows : 0.0;
     // vector kernel geometry, from measurements (tools/lab.py ab): one lane per entry
@@ -1378,6 +1397,7 @@ static void csr_free(spal_csr *a) {
     (void)dev_free(a->d_ptiles);
     (void)dev_free(a->d_pwin);
     if (a->d_vec_block) (void)hipFree(a->d_vec_block);
+    (void)dev_free(a->d_win_groups);
     cblock_free(a);
     (void)dev_free(a->d_x);
     (void)dev_free(a->d_y);
@@ -1387,9 +1407,15 @@ static void csr_free(spal_csr *a) {
 
 int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols, uint64_t nnz,
                      uint64_t cap_entries, uint32_t *d_rowptr, uint32_t *d_colind, void *d_values,
-                     spal_csr **out, const std::vector<uint2> *win256, bool eager_copies, bool lazy_plan) {
+                     spal_csr **out, const std::vector<uint2> *win256, bool eager_copies, bool lazy_plan,
+                     uint2 *d_win_groups, uint32_t win_groups, uint32_t win_group_bits) {
     spal_csr *a = new spal_csr;
     if (win256 && win256->size() == (nrows + kWinBase - 1) / kWinBase) a->win_base = *win256;
+    if (d_win_groups && win_group_bits <= 8 && win_groups == (uint32_t)((nrows + (1ull << win_group_bits) - 1) >> win_group_bits)) {
+        a->d_win_groups = d_win_groups; a->win_groups = win_groups; a->win_group_bits = win_group_bits;
+    } else if (d_win_groups) {
+        (void)dev_free(d_win_groups);
+    }
     a->device = device;
     a->elem_size = elem_size;
     a->nrows = nrows; a->ncols = ncols; a->nnz = nnz;

@@ -216,6 +216,10 @@ struct spal_csr {
     int place_tried = 0;
     spal::CsrPlan plan;
     std::vector<uint2> win_base;   // host copy of the per-256-row column windows (planner cache)
+    // a device-assembled handle: {first column, one past the last} of every group of 2^win_group_bits rows as the assembly's
+    // group kernel saw them, still on the device -- fetched and folded into win_base when the plan is built (csr_plan_build)
+    uint2 *d_win_groups = nullptr;
+    uint32_t win_groups = 0, win_group_bits = 0;
     // host-convenience staging (spal_csr_spmv_*): guarded by mu
     std::mutex mu;
     void *d_x = nullptr, *d_y = nullptr;
@@ -298,6 +302,8 @@ struct spal_coo {
     // capacity without a host round trip; the kernel verifies it, see coo_assemble_t).  Nothing else about the triplets
     // is kept between assemblies.
     uint32_t cap_hint[2] = {0, 0};
+    int loop_hint[2] = {0, 0};   // the last assembly by rows [0] / columns [1] met a row beyond the network form's reach
+    int last_row_sort = 0;
     size_t work_bytes = 0;
     void *h_back = nullptr;   // pinned host memory the assembly's few results come back into
     size_t h_back_bytes = 0;
@@ -329,9 +335,11 @@ hipError_t launch_cblock(const spal_csr *a, const void *x, void *y, hipStream_t 
 // assembly, which produces CSR directly on the device)
 // (cap_entries = allocated entries of d_colind / d_values; re-allocated with
 // padding when smaller than nnz + the kernels' over-read margin)
-// (win256: optional {first column, one past the last} of every 256 rows, if the caller has it)
+// (win256: optional {first column, one past the last} of every 256 rows, if the caller has it; or d_win_groups: the same
+//  per group of 2^win_group_bits <= 256 rows, on the device, ownership passes to the handle)
 int csr_adopt_device(int device, int elem_size, uint64_t nrows, uint64_t ncols,
                      uint64_t nnz, uint64_t cap_entries, uint32_t *d_rowptr,
                      uint32_t *d_colind, void *d_values, spal_csr **out,
-                     const std::vector<uint2> *win256 = nullptr, bool eager_copies = false, bool lazy_plan = false);
+                     const std::vector<uint2> *win256 = nullptr, bool eager_copies = false, bool lazy_plan = false,
+                     uint2 *d_win_groups = nullptr, uint32_t win_groups = 0, uint32_t win_group_bits = 0);
 }  // namespace spal

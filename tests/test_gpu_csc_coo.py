@@ -788,6 +788,45 @@ def test_coo_two_pass_forms_agree(oracle, monkeypatch, env, by_cols):
     assert np.array_equal(gp, p) and np.array_equal(gi, i) and np.array_equal(gw.view(np.uint64), w.view(np.uint64))
 
 
+def test_coo_rows_beyond_the_network_form(oracle):
+    """Step 2 of the group kernel sorts rows of up to 16 entries in one thread's registers and takes rows of up to 256 by a
+    wave each; a group with a longer row raises a flag and the host runs the kernel's other form (every entry counts its
+    place for itself).  Rows of 17 ... 256 entries with duplicates inside them, then one row of 400: same bits as the
+    oracle, the relaunch happens once and is remembered on the handle."""
+    rng = np.random.default_rng(5)
+    nr, nc, r, c, v = _coo_case(31, n=2_000_000, nr=250_000)
+    extra_r, extra_c, extra_v = [], [], []
+    for row, cnt in ((7, 17), (100_000, 56), (100_001, 120), (200_000, 200), (249_999, 236)):   # (+ the ~8 entries each row holds anyway)
+        cols = rng.integers(0, nc, cnt)
+        cols[cnt // 2:cnt // 2 + 5] = cols[:5]                  # duplicates inside the long row (insertion-order sums)
+        extra_r.append(np.full(cnt, row)); extra_c.append(cols); extra_v.append(rng.integers(-3, 4, cnt) * 0.37)
+    r1 = np.concatenate([r] + [e.astype(np.uint64) for e in extra_r])
+    c1 = np.concatenate([c] + [e.astype(np.uint64) for e in extra_c])
+    v1 = np.concatenate([v] + extra_v)
+    perm = rng.permutation(r1.size)
+    r1, c1, v1 = r1[perm], c1[perm], v1[perm]
+    dev = sp.CooMatrix.with_triplets(nr, nc, r1, c1, v1).upload()
+    got = dev.assemble_csr()
+    d = dev.describe()
+    assert d["last_route"] == "local_sort" and d["row_sort"] == 1, d   # (the first capacity guess may cost a relaunch; not the form)
+    p, i, w = oracle.coo_to_csr(nr, nc, r1, c1, v1)
+    gp, gi, gw = got.download()
+    assert np.array_equal(gp, p) and np.array_equal(gi, i) and np.array_equal(gw.view(np.uint64), w.view(np.uint64))
+    # one row of 400 entries: beyond the wave pass
+    r2 = np.concatenate([r1, np.full(400, 123_456, dtype=np.uint64)])
+    c2 = np.concatenate([c1, rng.integers(0, nc, 400).astype(np.uint64)])
+    v2 = np.concatenate([v1, rng.integers(-3, 4, 400) * 0.37])
+    dev2 = sp.CooMatrix.with_triplets(nr, nc, r2, c2, v2).upload()
+    p, i, w = oracle.coo_to_csr(nr, nc, r2, c2, v2)
+    for attempt in range(2):
+        got = dev2.assemble_csr()
+        d = dev2.describe()
+        assert d["last_route"] == "local_sort" and d["row_sort"] == 0, d
+        assert d["group_relaunches"] >= 1 if attempt == 0 else d["group_relaunches"] == 0, d
+        gp, gi, gw = got.download()
+        assert np.array_equal(gp, p) and np.array_equal(gi, i) and np.array_equal(gw.view(np.uint64), w.view(np.uint64))
+
+
 def test_assembled_handle_plans_like_an_uploaded_one(oracle):
     """The assembly hands the CSR planner the column windows it saw on the way;
     the resulting plan (LDS windows, stream fractions) must be the plan the same

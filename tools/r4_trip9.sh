@@ -1,0 +1,21 @@
+#!/bin/bash
+set -u
+export TMPDIR=/tmp
+O=gpurun_out/r4; mkdir -p $O
+timeout -k 10 400 python -m pytest tests/test_gpu_csc_coo.py -x -q -k "coo" > $O/t9_coo.log 2>&1; rc=$?; tail -n 3 $O/t9_coo.log; [ $rc -ne 0 ] && exit $rc
+SPAL_HIP_LIB=$PWD/spalinalg_amd/lib_var/stamps/libspal_hip.so timeout -k 10 200 python bench.py --config 5 --steps 4 --warmup 1 --no-cpu-baseline > $O/t9_stamps.log 2>&1
+grep "spal coo stamps" $O/t9_stamps.log | tail -n 1
+for v in default lb6 loop; do
+  unset SPAL_HIP_LIB SPAL_COO_LOOP_RANKS
+  case $v in lb6) export SPAL_HIP_LIB=$PWD/spalinalg_amd/lib_var/$v/libspal_hip.so;; loop) export SPAL_COO_LOOP_RANKS=1;; esac
+  timeout -k 10 200 python bench.py --config 5 --steps 10 --warmup 2 --no-cpu-baseline > $O/t9_b5_$v.log 2>&1
+  python - <<PY
+import json
+l=[x for x in open("$O/t9_b5_$v.log") if x.startswith("{")]
+d=json.loads(l[-1]) if l else {}
+print("$v:", d.get("ms_per_step"), d.get("product_plan_ms"))
+PY
+done
+unset SPAL_HIP_LIB SPAL_COO_LOOP_RANKS
+bash tools/pmc_kernel.sh group_sort2 coo_group_sort "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" -- --config 5 --steps 4 --warmup 1 --no-cpu-baseline | tail -n 4
+exit 0
