@@ -452,6 +452,22 @@ def bench_mg(args):
         mg.spmv_local()
     mg.synchronize()
     compute["ms_per_step_back_to_back"] = round((time.perf_counter() - t0) * 1e3 / args.steps, 6)
+    # north_star's wording to the letter, measured the same way: the WHOLE vector broadcast once (ncclBroadcast), K local
+    # products, the slices all-gathered at the end (the K-th product is the one that all-gathers)
+    mg.set_x(xh)
+    mg.broadcast_x()
+    mg.spmv_resident()
+    mg.synchronize()
+    t0 = time.perf_counter()
+    mg.broadcast_x()
+    for _ in range(args.steps - 1):
+        mg.spmv_local()
+    mg.spmv_resident()
+    mg.synchronize()
+    bcast_total_ms = (time.perf_counter() - t0) * 1e3
+    y_all = mg.y_allgathered()
+    allgather_equals_gather = bool(np.array_equal(y_all.view(np.uint64 if esz == 8 else np.uint32),
+                                                  y.view(np.uint64 if esz == 8 else np.uint32)))
     halo = None
     if nrows == ncols:
         mg.set_x(xh)
@@ -499,6 +515,10 @@ def bench_mg(args):
                      "frac": round(whole_bytes / (kern_ms * 1e-3) / 8e12 / max(1, (len(set(devices)) if devices else G)), 4), "traffic": None,
                      "kernel": "csr_spmv_stream / csr_spmv_slide per shard", "kernel_ms": kern_ms,
                      "note": "per GPU: the whole matrix's algorithmic bytes / the shards' concurrent kernels / the GPUs"},
+        "end_to_end_windows_ms": round(total_ms, 4) if dist_x == mg.scatter_x else None,
+        "end_to_end_broadcast_allgather_ms": round(bcast_total_ms, 4),
+        "end_to_end_broadcast_allgather_value": round(synth.spmv_flops(nnz) * args.steps / (bcast_total_ms * 1e-3) / 1e9, 3),
+        "allgather_equals_gather_bit_for_bit": allgather_equals_gather,
         "compute_only": compute, "comm_ms": comm, "halo": halo,
         "efficiency_inputs": {"total_ms": round(total_ms, 4), "K": args.steps,
                               "note": "total = x_distribution + K * compute + y_collection: recompute for any K"},
@@ -997,6 +1017,7 @@ def main():
                               f"per rank), y slices all-gathered once at the end of the timed region")),
             "nrows": nrows, "ncols": ncols, "nnz": nnz, "algorithmic_index_bits": 32,
             "partition": "none" if world == 1 else f"rows/{world}",
+            "partition_rows": None if world == 1 else [int(b) for b in bounds],   # contiguous ranges balanced by stored entries
             "exchange": exchange,
             "x_distribution": x_mode if world > 1 else "none",
             "y_collection": y_mode if world > 1 else "none",

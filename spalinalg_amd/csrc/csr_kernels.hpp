@@ -142,6 +142,9 @@ constexpr uint32_t kPageShift = 8;
 constexpr uint32_t kPageCols = 1u << kPageShift;
 // ring > 0 (contiguous runs only): the window is a ring of `ring` pages, page p at slot p % ring -- the layout the
 // sliding kernel (csr_slide.hpp) keeps across steps; col16 is encoded for it (csr_encode_col16).
+#ifndef SPAL_STAGE_BATCH
+#define SPAL_STAGE_BATCH 12
+#endif
 template <typename T, int BLOCK>
 __device__ __forceinline__ void stage_pages(T *xw, const T *__restrict__ x,
                                             const uint32_t *__restrict__ pages, uint32_t first,
@@ -157,7 +160,9 @@ __device__ __forceinline__ void stage_pages(T *xw, const T *__restrict__ x,
         const uint32_t total = npages * VP;     // a multiple of 64: whole waves are in or out
         const uint32_t last_full = ((ncols - V) / V) * V;   // first column of the last whole vector of x
         vec_t *d4 = reinterpret_cast<vec_t *>(xw);
-        constexpr uint32_t K = 4;
+        // (K vectors per thread requested back to back: 12 bring the 24 pages of an f64 window in ONE round trip; with four
+        //  a super-tile's 20 pages took three -- round 4, profiles/r04/shard_sized_launches.txt)
+        constexpr uint32_t K = SPAL_STAGE_BATCH;
         for (uint32_t i0 = threadIdx.x; i0 < total; i0 += K * BLOCK) {
             vec_t t[K];
             uint32_t e[K];

@@ -31,6 +31,10 @@ namespace spal {
 constexpr uint32_t kSlideAsync = 1u << 16;   // the pages entering with this step fit beside the previous step's, are at most
                                              // kSlideAsyncVecs * 256 vectors and hold no partial vector of x: prefetched
 constexpr uint32_t kSlideAsyncVecs = 1;      // 16-byte vectors of entering pages a thread holds (2 pages of f64 per step)
+#ifndef SPAL_SLIDE_FIRST_BATCH
+#define SPAL_SLIDE_FIRST_BATCH 12
+#endif
+constexpr uint32_t kSlideFirstBatch = SPAL_SLIDE_FIRST_BATCH;   // vectors of the first window a thread requests at once
 
 template <typename T>
 struct SlideVec { using type = __attribute__((ext_vector_type(4))) uint32_t; };
@@ -126,21 +130,28 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_slide(
     // its first window whole.  (One run per workgroup = chunk >= steps per XCD / slots is the fully persistent form;
     // shorter runs keep the workgroups of an XCD on neighbouring memory -- one front instead of 64.)
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-    const uint32_t xbase = xcd * per_xcd;
+    const bool even = flags & 8u;
+    const uint32_t xbase = even ? xcd * (nsteps / 8u) + min(xcd, nsteps % 8u) : xcd * per_xcd;
     if (xbase >= nsteps) return;
-    const uint32_t nx = min(per_xcd, nsteps - xbase);                 // steps of this XCD
-    const uint32_t nruns = (nx + chunk - 1u) / chunk;
+    const uint32_t nx = even ? nsteps / 8u + (xcd < nsteps % 8u ? 1u : 0u) : min(per_xcd, nsteps - xbase);   // steps of this XCD
+    if (nx == 0u) return;
+    // (flags bit 3, one run per workgroup: the steps are split EVENLY over the XCDs and an XCD's over all its workgroups --
+    //  nx / slots steps each, the first nx % slots one more -- instead of runs of ceil(nx / slots): a 1M-row shard has 489
+    //  steps per XCD, which as runs of 8 kept 62 of the 64 workgroups of an XCD busy)
+    const uint32_t nruns = even ? min(slots, nx) : (nx + chunk - 1u) / chunk;
     if (slot >= nruns) return;
-    const uint32_t myruns = (nruns - slot + slots - 1u) / slots;
+    const uint32_t myruns = even ? 1u : (nruns - slot + slots - 1u) / slots;
     // steps of this workgroup: full runs, except that the XCD's last run may be short and is then this one's last
     const uint32_t lastrun = slot + (myruns - 1u) * slots;
-    const uint32_t nk = (myruns - 1u) * chunk + min(chunk, nx - lastrun * chunk);
+    const uint32_t even_lo = nx / slots, even_rem = nx % slots;
+    const uint32_t even_start = slot * even_lo + min(slot, even_rem);
+    const uint32_t nk = even ? even_lo + (slot < even_rem ? 1u : 0u) : (myruns - 1u) * chunk + min(chunk, nx - lastrun * chunk);
     // k-th step of this workgroup -> its global step index.  k past the end: the matrix's first step -- its tile is
     // what every workgroup's last PF load slots then read (the count of loads must not depend on the path), so it
     // stays in L2; re-reading the workgroup's own last tile cost 37 MB of HBM reads per launch (streaming loads
     // are not kept).
     auto gi = [&](uint32_t k) {
-        return k < nk ? xbase + (slot + (k / chunk) * slots) * chunk + k % chunk : 0u;
+        return k >= nk ? 0u : even ? xbase + even_start + k : xbase + (slot + (k / chunk) * slots) * chunk + k % chunk;
     };
 
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -152,8 +163,12 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_slide(
     // rows / entry range of this wave's tile at the workgroup's k-th step; steps past its last re-read that one's tile
     // (same count of loads on every path -- that is the point -- and nobody uses them)
     auto tile_row = [&](uint32_t k) { return (gi(k) * kStreamWaves + wave) * (uint32_t)RPT; };
-    auto tile_b = [&](uint32_t k) { return rowptr[min(tile_row(k), nrows)]; };
-    auto tile_e = [&](uint32_t k) { return rowptr[min(tile_row(k) + (uint32_t)RPT, nrows)]; };
+    // (flags bit 2, UNI plans only: EVERY row of the matrix holds ulen - 1 entries, so rowptr[r] = r * (ulen - 1) and a
+    //  workgroup's first tile loads do not wait for a round trip to rowptr -- at a shard's 7.6 steps per workgroup that is
+    //  a tenth of the launch, profiles/r04/shard_sized_launches.txt)
+    const bool arith = UNI && (flags & 4u);
+    auto tile_b = [&](uint32_t k) { const uint32_t r = min(tile_row(k), nrows); return arith ? r * (ulen - 1u) : rowptr[r]; };
+    auto tile_e = [&](uint32_t k) { const uint32_t r = min(tile_row(k) + (uint32_t)RPT, nrows); return arith ? r * (ulen - 1u) : rowptr[r]; };
 
     StreamTile<T> t[NB];
     uint32_t tb[NB], te[NB];     // entry ranges of the tiles whose loads go out next (asked for a step early, by s_load)
@@ -167,18 +182,19 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_slide(
 #pragma unroll
     for (int q = 0; q < PF; ++q)
         slide_tile_load<T, RPT, S, UNI>(t[q], rowptr, col16, vals, tile_row((uint32_t)q), nrows, tb[q], te[q], lane, ulen);
-    // the first window, whole
+    // the first window, whole: kSlideFirstBatch vectors per thread requested back to back (12: the 24 pages of an f64 window
+    // in ONE round trip; four at a time made it three, and a shard-sized launch is only 7.6 steps per workgroup long)
     {
         const uint32_t f = d.x, nv = (d.y & 0xffu) * VP;
-        for (uint32_t j0 = threadIdx.x; j0 < nv; j0 += 4u * kStreamBlock) {
-            vec_t r[4];
+        for (uint32_t j0 = threadIdx.x; j0 < nv; j0 += kSlideFirstBatch * kStreamBlock) {
+            vec_t r[kSlideFirstBatch];
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
+            for (uint32_t k = 0; k < kSlideFirstBatch; ++k) {
                 const uint32_t j = min(j0 + k * kStreamBlock, nv - 1u);
                 r[k] = slide_load_vec_tail<T>(x, f + j / VP, j % VP, ncols);
             }
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
+            for (uint32_t k = 0; k < kSlideFirstBatch; ++k) {
                 const uint32_t j = j0 + k * kStreamBlock;
                 if (j < nv) xw4[((f + j / VP) % NP) * VP + j % VP] = r[k];
             }
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(kStreamBlock, 2) void csr_spmv_slide(
         SlideNew nw = slide_new_pages(d.x, d.y & 0xffu, dn.x, dn.y & 0xffu);
         const uint32_t nlo = (nw.lo1 - nw.lo0) * VP;
         const uint32_t ntot = more ? nlo + (nw.hi1 - nw.hi0) * VP : 0u;
-        const bool async = more && (dn.y & kSlideAsync) && (i + 1u) % chunk != 0u;   // (a new run's window is staged whole)
+        const bool async = more && (dn.y & kSlideAsync) && (even || (i + 1u) % chunk != 0u);   // (a new run's window is staged whole)
         auto new_page = [&](uint32_t j) { return j < nlo ? nw.lo0 + j / VP : nw.hi0 + (j - nlo) / VP; };
         vec_t nv[kSlideAsyncVecs];
 #pragma unroll

@@ -613,6 +613,10 @@ static int slide_plan(spal_csr *a, uint32_t R, uint32_t rpt, const std::vector<u
     p.slide_steps = nsteps;
     p.slide_S = (int)S;
     p.slide_uniform = (uni && ulen != 0u) ? (int)ulen : 0;
+    // every row of the matrix that long: all steps stream (no tile left to the overflow kernel, none split) and the entries
+    // add up
+    p.all_rows_uniform = (p.slide_uniform && left_over.empty() && n_split == 0 &&
+                          (uint64_t)a->nrows * (uint64_t)(ulen - 1u) == a->nnz) ? 1 : 0;
     (void)R;
     return SPAL_OK;
 }
@@ -1949,6 +1953,14 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
     } else if (!strcmp(key, "slide_on")) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "slide_on must be 0 or 1");
         p.slide_on = (int)value;
+    } else if (!strcmp(key, "slide_even")) {
+        // sliding kernel, one run per workgroup: steps split evenly over all workgroups of an XCD (default 1) or runs of ceil(steps / workgroups)
+        if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "slide_even must be 0 or 1");
+        p.slide_even = (int)value;
+    } else if (!strcmp(key, "arith_bounds")) {
+        // sliding kernel, matrices whose rows ALL have one length: tile bounds computed (r * length) instead of loaded (default 1)
+        if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "arith_bounds must be 0 or 1");
+        p.arith_bounds = (int)value;
     } else if (!strcmp(key, "split_tiles")) {
         // sliding kernel: tiles above 1024 entries whose two halves fit the strip are computed in two passes (1,
         // default) or left to the overflow kernel like every other skipped tile (0)

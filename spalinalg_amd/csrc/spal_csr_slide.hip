@@ -20,7 +20,8 @@ static hipError_t launch_slide_inst(const spal_csr *a, const void *x, void *y, h
     // steps per run: one run per workgroup, or what the plan says ("slide_run": shorter runs dealt round-robin)
     const uint32_t one_run = (per_xcd + slots - 1u) / slots;
     const uint32_t chunk = p.slide_run > 0 ? std::min<uint32_t>((uint32_t)p.slide_run, one_run) : one_run;
-    const uint32_t used = std::min(slots, (per_xcd + chunk - 1u) / chunk);
+    const bool even = p.slide_run <= 0 && p.slide_even;        // one run per workgroup: the steps split evenly (csr_slide.hpp)
+    const uint32_t used = even ? std::min(slots, per_xcd) : std::min(slots, (per_xcd + chunk - 1u) / chunk);
     auto kern = csr_spmv_slide<T, RPT, S, UNI, PF>;
     static std::atomic<uint64_t> configured{0};
     const uint64_t bit = 1ull << (a->device & 63);
@@ -32,7 +33,7 @@ static hipError_t launch_slide_inst(const spal_csr *a, const void *x, void *y, h
     hipLaunchKernelGGL(kern, dim3(used * 8u), dim3(kStreamBlock), lds, st, a->d_rowptr, a->d_col16,
                        (const T *)a->d_values, (const T *)x, (T *)y, a->d_sdesc, (uint32_t)a->nrows, (uint32_t)a->ncols,
                        p.slide_steps, per_xcd, chunk, (uint32_t)p.ring_pages, (uint32_t)p.slide_uniform,
-                       (uint32_t)(p.nt_store ? 1 : 0) | (uint32_t)p.diag);
+                       (uint32_t)(p.nt_store ? 1 : 0) | (uint32_t)p.diag | ((UNI && p.all_rows_uniform && p.arith_bounds) ? 4u : 0u) | (even ? 8u : 0u));
     return hipGetLastError();
 }
 

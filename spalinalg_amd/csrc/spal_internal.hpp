@@ -146,6 +146,9 @@ struct CsrPlan {
     double nonlocal_row_fraction = 0.0;   // rows of super-tiles that gather x from global memory over a span no panel holds
     int slide_S = 0;         // 128-entry steps of the largest streamed tile: every tile issues that many loads
     int slide_uniform = 0;   // 1 + the length of every row when all streamed rows have one length (rowptr is not read), else 0
+    int all_rows_uniform = 0; // ... and EVERY row of the matrix has it (rowptr[r] = r * length): tile bounds are arithmetic
+    int arith_bounds = 1;    // option "arith_bounds": use that (0: load the tiles' bounds from rowptr as before)
+    int slide_even = 1;      // option "slide_even": one run per workgroup -> the XCD's steps split evenly over all its workgroups
     int place_tries = 8;     // autotune: blocks of 1 GiB the 16-bit columns are tried in, at most (see csr_autotune)
     int split_tiles_on = 1;  // sliding kernel: tiles above 1024 entries whose halves fit go through the strip twice
     int diag = 0;            // ablation builds (-DSPAL_DIAG) only: parts of the stream kernel switched off

@@ -66,7 +66,7 @@ def _worker(rank, world, port, equal, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,equal", [(2, True), (2, False), (3, False), (3, True), (4, True)])
+@pytest.mark.parametrize("world,equal", [(2, True), (2, False), (3, False), (3, True), (4, True), (8, False)])
 def test_row_partitioned_spmv_gloo(world, equal):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -97,7 +97,7 @@ def _halo_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        n, w = 6000, 512
+        n, w = 1500 * max(world, 4), 512      # (a slice stays several bands tall at every world size)
         rp, ci, va = synth.banded_csr(n, n, 14, w, 77)
         bounds = partition_rows(rp, world)
         a = sp.CsrMatrix(n, n, rp, ci, va)
@@ -128,7 +128,7 @@ def _halo_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_halo_exchange_gloo(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")

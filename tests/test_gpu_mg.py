@@ -212,3 +212,52 @@ def test_row_partitioned_spmv_over_nccl(ngpus):
     seen = [ln for ln in out.stdout.splitlines() if ln.startswith("[dist worker]")]
     print("\n".join(seen))                          # the RCCL world size and devices the ranks saw
     assert any(f"world {ngpus}" in ln for ln in seen), out.stdout[-2000:]
+
+
+def test_eight_shard_rehearsal_at_config3_size_through_the_c_abi():
+    """BASELINE config 3 at FULL size (10M x 10M, 140M entries) cut into the EIGHT shards an 8-GPU node
+    holds, driven by bench.py --host mg through spal_mg_* with all eight on GPU 0 (copy transport): the partition (eight
+    ranges balanced by stored entries), the x windows, the local kernels, the gather and the all-gather at their real sizes --
+    one GPU, so NOT a scaling measurement: what it pins is that the N = 8 line parses, carries both end-to-end totals and the
+    communication split, and that GPU 0's y carries the oracle's bits."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    out = subprocess.run([sys.executable, bench, "--host", "mg", "--gpus", "8", "--devices", "0,0,0,0,0,0,0,0", "--steps", "5",
+                          "--warmup", "2"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    print(lines[0][:1500])
+    assert d["config"]["shards"] == 8 and d["config"]["transport"] == "copy" and d["n_gpus"] == 1
+    part = d["config"]["partition"]
+    assert len(part) == 9 and part[0] == 0 and part[-1] == 10_000_000 and all(b > a for a, b in zip(part, part[1:]))
+    assert all(abs((b - a) * 14 - 140_000_000 / 8) <= 0.01 * 140_000_000 / 8 for a, b in zip(part, part[1:])), part   # 14 per row: balanced by entries
+    for key in ("end_to_end_windows_ms", "end_to_end_broadcast_allgather_ms", "comm_ms", "compute_only", "halo"):
+        assert d.get(key), key
+    assert set(d["comm_ms"]) == {"x_distribution", "y_collection"}
+    assert d["allgather_equals_gather_bit_for_bit"] is True
+    assert d["cpu_baseline"]["gpu_equals_cpu_bit_for_bit"] is True        # GPU 0's gathered y against the oracle, all 10M rows
+    # every shard reads its own slice of x +- half the band: 7 windows of ~1.25M + 4096 columns leave GPU 0
+    assert d["config"]["exchange_bytes"]["x_scatter"] < 0.2 * 8 * 10_000_000 * 7
+
+
+def test_dist_host_rehearsal_four_ranks_on_one_gpu_config2():
+    """the driver's launch contract (torch.distributed.run, one process per rank) with FOUR ranks sharing GPU 0 over gloo at
+    config 2's size: the N > 1 line of bench.py parses and carries what the scaling table will be built from.  (The pool allows
+    six processes on a card, this test's parent is one of them: the 6-rank run at config 3's size is tools/rehearse_n8.sh.)"""
+    import json
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4",
+                          "--master-addr", "127.0.0.1", "--master-port", "29733", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "4", "--config", "2", "--steps", "5", "--warmup", "2", "--backend", "gloo", "--same-device",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["value"] > 0
+    for key in ("end_to_end_windows_ms", "end_to_end_broadcast_allgather_ms", "comm_ms", "compute_only"):
+        assert d.get(key) is not None, key
+    part = d["config"]["partition_rows"]
+    assert d["config"]["partition"] == "rows/4" and len(part) == 5 and part[0] == 0 and part[-1] == 1_000_000
+    assert all(abs((b - a) - 250_000) <= 2_500 for a, b in zip(part, part[1:])), part

@@ -1363,6 +1363,68 @@ def small():
 
 
 @lab
+def shard():
+    """Shard-sized launches: BASELINE config 2 (1M x 1M, 14 per row inside 4096 columns; what one GPU
+    of eight holds of config 3), launches rotating over THREE handles that own their arrays (the Infinity Cache), every
+    variant's options re-applied before its rounds, rounds interleaved.
+        python tools/lab.py shard ["opt=val,opt=val" ...] [@rows=N] [f32] [csc]
+    Without variants: the forms the autotune chooses between."""
+    import statistics
+    import sys
+
+    import numpy as np
+    import torch
+    import spalinalg_amd as sp
+    import spal_synth as synth
+
+    variants = [a for a in sys.argv[1:] if "=" in a and not a.startswith("@")]
+    shape = dict(kv[1:].split("=") for kv in sys.argv[1:] if kv.startswith("@"))
+    flags = [a for a in sys.argv[1:] if "=" not in a]
+    n = int(shape.get("rows", 1_000_000))
+    dtype = np.float32 if "f32" in flags else np.float64
+    if not variants:
+        variants = ["slide_on=1,nt_store=0", "slide_on=1,nt_store=1", "slide_on=0,nt_store=0", "slide_on=0,nt_store=1",
+                    "slide_on=1,nt_store=0,arith_bounds=0"]
+    rp, ci, va = synth.banded_csr(n, n, 14, 4096, synth.matrix_seed(2), dtype=dtype)
+    copies = 3
+    m = sp.CsrMatrix._trusted(n, n, rp, ci, va)
+    devs = [m.device_copy() for _ in range(copies)]
+    xs = [torch.from_numpy(synth.vector(n, dtype=dtype)).cuda() for _ in range(copies)]
+    ys = [torch.empty_like(xs[0]) for _ in range(copies)]
+    yref = devs[0].spmv_torch(xs[0]).clone()
+    B = synth.spmv_bytes(int(rp[-1]), n, n, n, np.dtype(dtype).itemsize)
+    defaults = {"slide_on": 1, "nt_store": 0, "arith_bounds": 1, "slide_run": 0, "persistent_blocks": 0, "persistent": 0, "prefetch": 1,
+                "xcd_chunk": 32}
+    named = {kv.split("=")[0] for v in variants for kv in v.split(",")}
+    times = [[] for _ in variants]
+    ok = [True] * len(variants)
+    for rnd in range(int(shape.get("rounds", 5))):
+        for i, v in enumerate(variants):
+            opts = {k: defaults[k] for k in named if k in defaults}
+            opts.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in v.split(",")})
+            for d in devs:
+                for k, val in opts.items():
+                    d.set_option(k, val)
+            for j in range(6):
+                devs[j % copies].spmv_torch(xs[j % copies], out=ys[j % copies])
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            iters = 150
+            e0.record()
+            for j in range(iters):
+                devs[j % copies].spmv_torch(xs[j % copies], out=ys[j % copies])
+            e1.record()
+            torch.cuda.synchronize()
+            times[i].append(e0.elapsed_time(e1) / iters * 1e3)
+            ok[i] = ok[i] and bool(torch.equal(ys[0], yref))
+    for v, t, good in zip(variants, times, ok):
+        med = statistics.median(t)
+        print(f"{v:48s} median {med:6.2f} us  min {min(t):6.2f} us  frac {B / med / 1e3 / 8000:5.3f}  bit-identical={good}  "
+              f"rounds={[round(q, 1) for q in t]}", flush=True)
+    print("plan:", {k: devs[0].describe().get(k) for k in ("kernel", "slide", "blocks", "ring_pages", "tile_steps", "uniform_row_fraction")}, flush=True)
+
+
+@lab
 def zoo():
     """A small zoo of sparsity patterns through the automatic plan (development tool): where are the cliffs?
     (was tools/lab_zoo.py)"""
