@@ -163,12 +163,17 @@ int spal_csr_autotune_f32(spal_csr_t a, const float *x_dev, float *y_dev,
  * of y do not collide with the matrix stream.  Why: on MI355X the time of a product depends on where y lies in the
  * device's memory RELATIVE to the matrix arrays (streams out of one class of region disturb each other: +-5 % at
  * config 3) -- a property of the pair that neither side can fix alone, and `hipMalloc` gives no say.
- * The call walks the device's memory in blocks of 1 GiB ("walk_blocks", default 12, up to three times as many while all
- * candidates so far ran alike; ~3 ms each), times the
- * handle's kernel into a candidate y in every block, keeps the block of the fastest and frees the rest.  The vectors
- * belong to the handle (freed by spal_csr_destroy; a second call returns the same pointers); any other device memory
- * works as x / y too, only possibly slower.  Not for handles above 2^32 - 65537 entries (row blocks): plain
- * allocations there.  Synchronises `stream`.
+ * The FIRST such call in a process (per device) walks the device's memory in blocks of 1 GiB ("walk_blocks", default 8 =
+ * at most 8 GiB held during the walk; ~3 ms each), times the handle's kernel into a candidate y in every block, KEEPS the
+ * block where it ran fastest and -- when the walk met a second class of region -- the one where it ran slowest, as the
+ * process's placement blocks, and frees the rest.  Every later call (any handle) only times the handle in the kept blocks
+ * (two probes, no hipMalloc) and takes its vectors as a PIECE of the better one; spal_csr_autotune_* takes the 16-bit
+ * columns from the same blocks.  Memory: at most two blocks of 1 GiB per process and device, shared by all handles
+ * (spal_csr_describe: "placement_blocks", "placement_free_bytes"; a handle reports the new blocks its call took in
+ * "vectors_walk_blocks" -- 0 once the process has its blocks -- and the places it timed in "vectors_probes").  The
+ * vectors belong to the handle (their piece returns to the block with spal_csr_destroy; a second call returns the same
+ * pointers); any other device memory works as x / y too, only possibly slower.  Matrices below 256 MB and handles above
+ * 2^32 - 65537 entries (row blocks): a plain allocation of exactly the vectors' size.  Synchronises `stream`.
  * Replaces nothing in the reference: its `Vec<T>` has no placement.  Rust shim: `DeviceCsr::vectors()`. */
 int spal_csr_alloc_vectors(spal_csr_t a, void **x_dev, void **y_dev, void *stream);
 /* Writes a one-line JSON description of the active plan into buf: "kernel"

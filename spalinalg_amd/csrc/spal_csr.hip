@@ -71,6 +71,92 @@ StreamPool &stream_pool() { static StreamPool p; return p; }
 
 // Non-blocking streams are pooled: creating one costs ~100 us, and every handle
 // (including each assembled CSR result) owns one.
+// ---- placement blocks ------------------------------------------------------------------------------------------------
+namespace {
+struct PlaceArenaBlock {
+    void *base = nullptr;
+    size_t size = 0;
+    std::vector<std::pair<size_t, size_t>> used;   // {offset, bytes}, sorted by offset
+};
+struct PlaceArena {
+    std::mutex mu;
+    std::vector<PlaceArenaBlock> blocks[64];        // per device
+    bool walked[64] = {};
+};
+PlaceArena &place_arena() {
+    static PlaceArena *a = new PlaceArena;          // (never destroyed: handles may outlive static destructors)
+    return *a;
+}
+}  // namespace
+int place_block_count(int device) {
+    PlaceArena &a = place_arena();
+    std::lock_guard<std::mutex> lock(a.mu);
+    return (int)a.blocks[device & 63].size();
+}
+PlaceBlock place_block(int device, int index) {
+    PlaceArena &a = place_arena();
+    std::lock_guard<std::mutex> lock(a.mu);
+    const auto &v = a.blocks[device & 63];
+    if (index < 0 || index >= (int)v.size()) return PlaceBlock{nullptr, 0};
+    return PlaceBlock{v[(size_t)index].base, v[(size_t)index].size};
+}
+void *place_alloc(int device, int index, size_t bytes) {
+    PlaceArena &a = place_arena();
+    std::lock_guard<std::mutex> lock(a.mu);
+    auto &v = a.blocks[device & 63];
+    if (index < 0 || index >= (int)v.size() || bytes == 0) return nullptr;
+    PlaceArenaBlock &b = v[(size_t)index];
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    size_t at = 0;
+    size_t pos = 0;
+    for (; pos < b.used.size(); ++pos) {            // first fit
+        if (b.used[pos].first - at >= bytes) break;
+        at = b.used[pos].first + b.used[pos].second;
+    }
+    if (pos == b.used.size() && b.size - at < bytes) return nullptr;
+    b.used.insert(b.used.begin() + (long)pos, std::make_pair(at, bytes));
+    return (char *)b.base + at;
+}
+void place_free(int device, void *ptr) {
+    if (!ptr) return;
+    PlaceArena &a = place_arena();
+    std::lock_guard<std::mutex> lock(a.mu);
+    for (PlaceArenaBlock &b : a.blocks[device & 63]) {
+        if ((char *)ptr < (char *)b.base || (char *)ptr >= (char *)b.base + b.size) continue;
+        const size_t off = (size_t)((char *)ptr - (char *)b.base);
+        for (size_t i = 0; i < b.used.size(); ++i)
+            if (b.used[i].first == off) { b.used.erase(b.used.begin() + (long)i); return; }
+    }
+}
+void place_adopt(int device, void *base, size_t size) {
+    PlaceArena &a = place_arena();
+    std::lock_guard<std::mutex> lock(a.mu);
+    PlaceArenaBlock b;
+    b.base = base; b.size = size;
+    a.blocks[device & 63].push_back(b);
+}
+size_t place_free_bytes(int device) {
+    PlaceArena &a = place_arena();
+    std::lock_guard<std::mutex> lock(a.mu);
+    size_t n = 0;
+    for (const PlaceArenaBlock &b : a.blocks[device & 63]) {
+        size_t u = 0;
+        for (const auto &r : b.used) u += r.second;
+        n += b.size - u;
+    }
+    return n;
+}
+bool place_walked(int device) {
+    PlaceArena &a = place_arena();
+    std::lock_guard<std::mutex> lock(a.mu);
+    return a.walked[device & 63];
+}
+void place_set_walked(int device) {
+    PlaceArena &a = place_arena();
+    std::lock_guard<std::mutex> lock(a.mu);
+    a.walked[device & 63] = true;
+}
+
 hipError_t stream_acquire(hipStream_t *out) {
     int device = 0;
     hipError_t e = hipGetDevice(&device);
@@ -1393,14 +1479,16 @@ static void csr_free(spal_csr *a) {
     (void)dev_free(a->d_colind);
     (void)dev_free(a->d_values);
     (void)dev_free(a->d_desc);
-    (void)dev_free(a->d_col16);
+    if (a->col16_placed) place_free(a->device, a->d_col16);
+    else (void)dev_free(a->d_col16);
     (void)dev_free(a->d_pages);
     (void)dev_free(a->d_ovtiles);
     (void)dev_free(a->d_sdesc);
     (void)dev_free(a->d_ovtiles_slide);
     (void)dev_free(a->d_ptiles);
     (void)dev_free(a->d_pwin);
-    if (a->d_vec_block) (void)hipFree(a->d_vec_block);
+    if (a->d_vec_block && a->vec_block_owned) (void)hipFree(a->d_vec_block);
+    else place_free(a->device, a->d_vec_block);
     (void)dev_free(a->d_win_groups);
     cblock_free(a);
     (void)dev_free(a->d_x);
@@ -1738,42 +1826,39 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
     // 1 GiB taken one after the other from the device's memory, the kernel is timed on each, the fastest place is kept
     // (round 2 re-allocated the 1.1 GB values array up to 12 times and, the candidates lying side by side in one
     // region, often found nothing).  `place_tries` blocks (default 8: ~25 ms), up to three times as many while nothing better turns up.
+    // Round 4: the candidates are the process's placement blocks (spal_csr_alloc_vectors' walk found and kept them: at most
+    // two, no hipMalloc here), the columns become a PIECE of the one that wins by 1 % and more.
     int tries = p.place_tries;
     if (const char *e = getenv("SPAL_PLACE_TRIES")) tries = atoi(e);
     const size_t cbytes = a->d_col16 ? (size_t)a->cap_entries * sizeof(uint16_t) : 0;
-    if (rc == SPAL_OK && tries > 0 && cbytes >= ((size_t)64 << 20)) {
-        const size_t block = std::max<size_t>((size_t)1 << 30, (cbytes + 4095) & ~(size_t)4095);
+    if (rc == SPAL_OK && tries > 0 && cbytes >= ((size_t)64 << 20) && !a->col16_placed) {
         const int n = std::max(4, iters / 4);
         float cur_ms = 0.f;
         timed(n, &cur_ms);
         a->place_us[0] = cur_ms * 1e3f;
         uint16_t *const original = a->d_col16;
-        std::vector<void *> blocks;
+        std::vector<void *> cand;
         std::vector<float> ms_of;
-        // (no place 3 % better among the first `tries` blocks -- they may all lie in the class of region the walk started
-        //  in, the classes come in runs of GiBs --: it goes on, up to three times as far)
-        float best_seen = cur_ms;
-        for (int k = 0; rc == SPAL_OK && (k < tries || (k < 3 * tries && best_seen > 0.97f * cur_ms)); ++k) {
-            void *b = nullptr;
-            if (hipMalloc(&b, block) != hipSuccess) { (void)hipGetLastError(); break; }   // the device is full: what we have
-            blocks.push_back(b);
+        const int kept = place_block_count(a->device);
+        for (int k = 0; k < kept && k < tries && rc == SPAL_OK; ++k) {
+            void *b = place_alloc(a->device, k, cbytes);
+            if (!b) continue;
             hipError_t e = hipMemcpyAsync(b, original, cbytes, hipMemcpyDeviceToDevice, st);
-            if (e != hipSuccess) { rc = fail(SPAL_ERR_HIP, "spal_csr_autotune: %s", hipGetErrorString(e)); break; }
+            if (e != hipSuccess) { place_free(a->device, b); rc = fail(SPAL_ERR_HIP, "spal_csr_autotune: %s", hipGetErrorString(e)); break; }
             a->d_col16 = (uint16_t *)b;
             float ms = 0.f;
             timed(n, &ms);
-            ms_of.push_back(ms);
-            best_seen = std::min(best_seen, ms);
+            cand.push_back(b); ms_of.push_back(ms);
             ++a->place_tried;
         }
         int best = -1;
         for (size_t k = 0; k < ms_of.size(); ++k)
             if (ms_of[k] < 0.99f * cur_ms && (best < 0 || ms_of[k] < ms_of[(size_t)best])) best = (int)k;
         (void)hipStreamSynchronize(st);
-        a->d_col16 = best >= 0 ? (uint16_t *)blocks[(size_t)best] : original;
-        for (size_t k = 0; k < blocks.size(); ++k)
-            if ((int)k != best) (void)hipFree(blocks[k]);
-        if (best >= 0) (void)dev_free(original);
+        a->d_col16 = best >= 0 ? (uint16_t *)cand[(size_t)best] : original;
+        for (size_t k = 0; k < cand.size(); ++k)
+            if ((int)k != best) place_free(a->device, cand[k]);
+        if (best >= 0) { (void)dev_free(original); a->col16_placed = 1; }
         a->place_us[1] = (best >= 0 ? ms_of[(size_t)best] : cur_ms) * 1e3f;
     }
     (void)hipEventDestroy(e0);
@@ -2039,31 +2124,38 @@ int spal_csr_alloc_vectors(spal_csr_t a, void **x_dev, void **y_dev, void *strea
         return SPAL_OK;
     }
     hipStream_t st = (hipStream_t)stream;
-    // small products, empty matrices, row-block handles: nothing to place
+    // small products, empty matrices, row-block handles: nothing to place -- a block of their own, exactly as large as needed
     size_t walk_min = (size_t)256 << 20;    // matrices the caches do not hold
     if (const char *e = getenv("SPAL_WALK_MIN_BYTES")) walk_min = (size_t)strtoull(e, nullptr, 10);
-    const bool walk = a->parts.empty() && a->nnz != 0 && (size_t)a->nnz * (es + 2) >= walk_min && a->walk_max > 1;
-    const size_t block = walk ? std::max<size_t>((size_t)1 << 30, up(xb + yb)) : up(xb + yb);   // (1 GiB: the stride of the walk)
-    std::vector<void *> blocks;
-    std::vector<float> us;
+    const bool walk = a->parts.empty() && a->nnz != 0 && (size_t)a->nnz * (es + 2) >= walk_min && a->walk_max > 1 &&
+                      xb + yb <= ((size_t)1 << 30);
+    if (!walk) {
+        void *b = nullptr;
+        hipError_t e = hipMalloc(&b, up(xb + yb));
+        if (e == hipSuccess) e = hipMemsetAsync(b, 0, xb + yb, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            if (b) (void)hipFree(b);
+            return fail(e == hipErrorOutOfMemory ? SPAL_ERR_OUT_OF_MEMORY : SPAL_ERR_HIP, "spal_csr_alloc_vectors: %s", hipGetErrorString(e));
+        }
+        a->d_vec_block = b; a->vec_block_owned = 1; a->vec_x_off = 0; a->vec_y_off = xb;
+        a->walk_blocks = 1; a->walk_probes = 0;
+        *x_dev = (char *)b; *y_dev = (char *)b + xb;
+        return SPAL_OK;
+    }
+    // Where x and y lie relative to the matrix stream decides +-5 - 12 % of a product.  The process keeps a few
+    // PLACEMENT BLOCKS of 1 GiB per device (place_*): the FIRST handle that asks walks the device's memory -- blocks taken
+    // one after the other, its kernel timed into a candidate y in each, at most `walk_blocks` (8 GiB) held at once -- and
+    // keeps the block where it ran fastest and, when a second class of region showed (3 % apart), the one where it ran
+    // slowest; the others go back.  Every LATER handle times itself in the kept blocks only (no hipMalloc, two probes) and
+    // takes its vectors -- and, in the autotune, its 16-bit columns -- as PIECES of them: no handle keeps a GiB for 160 MB.
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = SPAL_OK;
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
-    // "walk_blocks" blocks at least; up to three times as many while every candidate so far ran alike (within 3 %:
-    // the walk has not left the class of region it started in)
-    const int nmax = walk ? 3 * a->walk_max : 1;
-    for (int k = 0; k < nmax && e == hipSuccess && rc == SPAL_OK; ++k) {
-        if (walk && k >= a->walk_max) {
-            const float lo = *std::min_element(us.begin(), us.end()), hi = *std::max_element(us.begin(), us.end());
-            if (hi > 1.03f * lo) break;
-        }
-        void *b = nullptr;
-        if (hipMalloc(&b, block) != hipSuccess) { (void)hipGetLastError(); break; }   // the device is full: what we have
-        blocks.push_back(b);
-        e = hipMemsetAsync(b, 0, xb + yb, st);      // x = 0 for the probes: the time of a product does not depend on the values
-        if (!walk) { us.push_back(0.f); break; }
-        void *xc = b, *yc = (char *)b + xb;
+    auto probe = [&](void *xc, float *us_out) {           // the handle's kernel, x and y at xc
+        void *yc = (char *)xc + xb;
+        if (e == hipSuccess) e = hipMemsetAsync(xc, 0, xb + yb, st);   // x = 0: the time of a product does not depend on the values
         for (int i = 0; i < 3 && rc == SPAL_OK; ++i) rc = csr_launch(a, xc, yc, st);
         if (e == hipSuccess) e = hipEventRecord(e0, st);
         const int n = 8;
@@ -2072,29 +2164,82 @@ int spal_csr_alloc_vectors(spal_csr_t a, void **x_dev, void **y_dev, void *strea
         if (e == hipSuccess) e = hipEventSynchronize(e1);
         float ms = 0.f;
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-        us.push_back(ms * 1e3f / (float)n);
+        *us_out = ms * 1e3f / (float)n;
+    };
+    std::vector<float> us;          // per candidate
+    std::vector<void *> piece;      // its x (a piece of a placement block)
+    a->walk_blocks = 0;
+    a->walk_probes = 0;
+    // (i) the process's blocks
+    const int kept = place_block_count(a->device);
+    for (int k = 0; k < kept && e == hipSuccess && rc == SPAL_OK; ++k) {
+        void *pc = place_alloc(a->device, k, xb + yb);
+        if (!pc) continue;
+        float t = 0.f;
+        probe(pc, &t);
+        piece.push_back(pc); us.push_back(t);
+        ++a->walk_probes;
+    }
+    // (ii) the walk, once per process and device (or when the kept blocks are full)
+    if ((!place_walked(a->device) || piece.empty()) && e == hipSuccess && rc == SPAL_OK) {
+        const size_t block = (size_t)1 << 30;
+        std::vector<void *> fresh;
+        std::vector<float> fresh_us;
+        for (int k = 0; k < a->walk_max && e == hipSuccess && rc == SPAL_OK; ++k) {
+            void *b = nullptr;
+            if (hipMalloc(&b, block) != hipSuccess) { (void)hipGetLastError(); break; }   // the device is full: what we have
+            float t = 0.f;
+            probe(b, &t);
+            fresh.push_back(b); fresh_us.push_back(t);
+            ++a->walk_blocks; ++a->walk_probes;
+        }
+        if (e == hipSuccess && rc == SPAL_OK && !fresh.empty()) {
+            size_t lo = 0, hi = 0;
+            for (size_t k = 1; k < fresh.size(); ++k) {
+                if (fresh_us[k] < fresh_us[lo]) lo = k;
+                if (fresh_us[k] > fresh_us[hi]) hi = k;
+            }
+            const bool two = fresh_us[hi] > 1.03f * fresh_us[lo];
+            for (size_t k = 0; k < fresh.size(); ++k) {
+                if (k == lo || (two && k == hi)) {
+                    place_adopt(a->device, fresh[k], block);
+                    void *pc = place_alloc(a->device, place_block_count(a->device) - 1, xb + yb);   // (its start: where it was timed)
+                    piece.push_back(pc); us.push_back(fresh_us[k]);
+                } else {
+                    (void)hipFree(fresh[k]);
+                }
+            }
+            place_set_walked(a->device);
+            if (getenv("SPAL_WALK_DEBUG")) {
+                fprintf(stderr, "[spal walk] us per product by new block:");
+                for (float t : fresh_us) fprintf(stderr, " %.1f", t);
+                fprintf(stderr, "  -> kept %zu%s\n", lo, two ? " and the slowest" : "");
+            }
+        } else {
+            for (void *b : fresh) (void)hipFree(b);
+        }
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     size_t best = 0;
     for (size_t k = 1; k < us.size(); ++k) if (us[k] < us[best]) best = k;
-    const bool ok = e == hipSuccess && rc == SPAL_OK && !blocks.empty() && us.size() == blocks.size();
-    for (size_t k = 0; k < blocks.size(); ++k)
-        if (!ok || k != best) (void)hipFree(blocks[k]);
+    const bool ok = e == hipSuccess && rc == SPAL_OK && !piece.empty() && piece[best] != nullptr;
+    for (size_t k = 0; k < piece.size(); ++k)
+        if (!ok || k != best) place_free(a->device, piece[k]);
     if (rc != SPAL_OK) return rc;
     if (!ok) return fail(e == hipSuccess ? SPAL_ERR_OUT_OF_MEMORY : SPAL_ERR_HIP, "spal_csr_alloc_vectors: %s",
                          e == hipSuccess ? "no device memory for the vectors" : hipGetErrorString(e));
-    a->d_vec_block = blocks[best];
+    a->d_vec_block = piece[best];
+    a->vec_block_owned = 0;
     a->vec_x_off = 0;
     a->vec_y_off = xb;
-    a->walk_blocks = (int)blocks.size();
     a->walk_us[0] = us[best];
     a->walk_us[1] = *std::max_element(us.begin(), us.end());
     if (getenv("SPAL_WALK_DEBUG")) {
-        fprintf(stderr, "[spal walk] us per product by block:");
+        fprintf(stderr, "[spal walk] us per product by candidate:");
         for (float t : us) fprintf(stderr, " %.1f", t);
-        fprintf(stderr, "  -> block %zu\n", best);
+        fprintf(stderr, "  -> %zu (%d new blocks, %d probes)\n", best, a->walk_blocks, a->walk_probes);
     }
     *x_dev = (char *)a->d_vec_block + a->vec_x_off;
     *y_dev = (char *)a->d_vec_block + a->vec_y_off;
@@ -2142,7 +2287,7 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              "\"lds_window_bytes\": %llu, \"lds_row_fraction\": %.4f, \"stream_row_fraction\": %.4f, "
              "\"overflow_tiles\": %u, \"skew\": %d, \"persistent\": %d, \"nt_store\": %d, \"uniform_row_fraction\": %.4f, "
              "\"prefetch\": %d, \"slide\": %d, \"ring_pages\": %d, \"tile_steps\": %d, \"split_tiles\": %u, \"panel_tiles\": %u, \"autotune_us\": [%.1f, %.1f, %.1f, %.1f], \"placement_us\": [%.1f, %.1f], \"placement_tries\": %d, \"addr\": [\"%llx\", \"%llx\", \"%llx\"], "
-             "\"vectors_walk_us\": [%.1f, %.1f], \"vectors_walk_blocks\": %d, "
+             "\"vectors_walk_us\": [%.1f, %.1f], \"vectors_walk_blocks\": %d, \"vectors_probes\": %d, \"placement_blocks\": %d, \"placement_free_bytes\": %llu, "
              "\"nonlocal_row_fraction\": %.4f, \"cblock\": %d, \"cblock_pending\": %d, \"cblock_rows\": %d, \"cblock_form\": \"%s\", \"cblock_run\": %.2f, \"cblock_cols\": %llu, \"cblock_col_blocks\": %d, \"cblock_row_blocks\": %u, \"cblock_us\": [%.1f, %.1f], \"cblock_failed\": %d}",
              a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows,
              (unsigned long long)a->ncols, (unsigned long long)a->nnz, (p.kernel == 2 || p.vec_col16) ? 16 : 32,
@@ -2162,7 +2307,8 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              (double)a->tuned_us[2], (double)a->tuned_us[3], (double)a->place_us[0], (double)a->place_us[1],
              a->place_tried, (unsigned long long)(uintptr_t)a->d_values,
              (unsigned long long)(uintptr_t)a->d_col16, (unsigned long long)(uintptr_t)a->d_rowptr,
-             (double)a->walk_us[0], (double)a->walk_us[1], a->walk_blocks,
+             (double)a->walk_us[0], (double)a->walk_us[1], a->walk_blocks, a->walk_probes, place_block_count(a->device),
+             (unsigned long long)place_free_bytes(a->device),
              p.kernel == 2 ? p.nonlocal_row_fraction : 0.0, (p.cblock && p.cblock_on) ? 1 : 0, p.cblock_pending, p.cblock ? p.cblock_rows : 0, !p.cblock ? "" : p.cblock_form ? "rows" : "entry", p.cblock ? (double)p.cblock_run : 0.0,
              p.cblock ? (1ull << p.cblock_shift) : 0ull, p.cblock ? p.cblock_nbc : 0, p.cblock ? p.cblock_nrb : 0u,
              (double)a->cblock_us[0], (double)a->cblock_us[1], a->cblock_failed);

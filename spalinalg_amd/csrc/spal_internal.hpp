@@ -62,6 +62,19 @@ struct DeviceGuard {
 // `offset + a batch` (at most a few thousand entries past the end, clamped afterwards) in 32 bits.
 constexpr uint64_t kMaxEntries = 0xffffffffull - 65536ull;
 
+// ---- placement blocks: blocks of 1 GiB found by ONE walk per process and device, kept, and shared by every
+// handle's vectors and 16-bit columns as pieces (first fit, 4 KB granules).  Two are kept when the walk met two classes of
+// region: the place where the first handle ran fastest and the one where it ran slowest -- a later handle, whose values lie
+// wherever they lie, times itself in each (no hipMalloc) and takes the better.
+struct PlaceBlock { void *base; size_t size; };
+int place_block_count(int device);
+PlaceBlock place_block(int device, int index);
+void *place_alloc(int device, int index, size_t bytes);        // a piece of block `index`, or nullptr
+void place_free(int device, void *ptr);                        // a piece (nullptr is fine)
+void place_adopt(int device, void *base, size_t size);         // a hipMalloc'ed block becomes a placement block
+size_t place_free_bytes(int device);                           // what the retained blocks still have to give
+bool place_walked(int device);
+void place_set_walked(int device);
 hipError_t dev_alloc(void **ptr, size_t bytes);   // on the current device
 hipError_t dev_free(void *ptr);                   // on the current device; NULL is fine
 // a device block that returns to the allocator when it goes out of scope (early returns included)
@@ -207,11 +220,14 @@ struct spal_csr {
     int cblock_lazy = 0;           // build the tiled copy with the first product, not with the plan (csr_adopt_device)
     int cblock_failed = 0;         // building it failed (out of memory, ...): the stream kernels run instead
     // spal_csr_alloc_vectors: the block of 1 GiB (or more) that holds the caller's x and y, found by the placement walk
-    void *d_vec_block = nullptr;
+    void *d_vec_block = nullptr;       // x and y: a piece of one of the process's placement blocks (place_*), or a block of its own
+    int vec_block_owned = 0;           // 1: hipMalloc'ed for this handle alone (small matrices: nothing to place)
     size_t vec_x_off = 0, vec_y_off = 0;
     float walk_us[2] = {0.f, 0.f};     // fastest / slowest candidate of the walk (per product)
-    int walk_blocks = 0;               // blocks probed
-    int walk_max = 12;                 // option "walk_blocks"
+    int walk_blocks = 0;               // NEW blocks of 1 GiB this handle's call took from the device (0 once the process has its blocks)
+    int walk_probes = 0;               // places timed (new blocks + the process's retained ones)
+    int walk_max = 8;                  // option "walk_blocks": blocks of 1 GiB a walk may hold at once = how far it reaches
+    int col16_placed = 0;              // d_col16 is a piece of a placement block (place_free, not dev_free)
     std::mutex mu_cb;
     // autotune: microseconds per launch of {plain, persistent} x {plain, non-temporal y stores}
     float tuned_us[4] = {0.f, 0.f, 0.f, 0.f};
