@@ -1084,6 +1084,40 @@ __global__ __launch_bounds__(kStreamBlock) void csr_spmv_overflow(
     }
 }
 
+// ---- the LONG rows of a row-split plan (spal_csr.hip: csr_try_row_split) -----------------------------------------
+// rows[i], i < nlong: rows of more than the split's threshold.  A wave per row: consecutive lanes read consecutive entries
+// (coalesced, non-temporal), x gathered through L2, lane-partial sums folded by a shuffle tree -- rounded like every row the
+// vector kernels compute (1e-10 parity, not bit-identical).  Rows of a power-law tail, a few thousand entries at most:
+// the wave loops; four rows in flight per workgroup.
+template <typename T>
+__global__ __launch_bounds__(kStreamBlock) void csr_spmv_row_list(
+    const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind, const T *__restrict__ vals,
+    const T *__restrict__ x, T *__restrict__ y, const uint32_t *__restrict__ rows, uint32_t nlong) {
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t i = blockIdx.x * kStreamWaves + wave;
+    if (i >= nlong) return;   // wave-uniform
+    const uint32_t r = rows[i];
+    const uint32_t b = rowptr[r], e = rowptr[r + 1];
+    T acc = strided_row_sum<T, kWave>(colind, vals, x, b, e, lane);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) y[r] = acc;
+}
+
+// setup: the short rows' entries copied into the compacted arrays of the split's short part (a thread per row: setup time)
+template <typename T>
+__global__ __launch_bounds__(256) void csr_split_copy(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ rowptr_s,
+                                                      const uint32_t *__restrict__ colind, const T *__restrict__ vals,
+                                                      uint32_t *__restrict__ colind_s, T *__restrict__ vals_s, uint32_t nrows) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nrows) return;
+    const uint32_t b = rowptr[r], bs = rowptr_s[r], n = rowptr_s[r + 1] - bs;   // n = the row's length, or 0 for a long row
+    for (uint32_t k = 0; k < n; ++k) {
+        colind_s[bs + k] = colind[b + k];
+        vals_s[bs + k] = vals[b + k];
+    }
+}
+
 // y[i] = 0 for an all-empty matrix slice (nnz == 0): nothing to stream.
 template <typename T>
 __global__ void fill_zero(T *y, uint64_t n) {

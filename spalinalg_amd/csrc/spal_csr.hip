@@ -945,6 +945,18 @@ int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream) 
             SPAL_TRY(csr_launch(a->parts[b], x_dev, (char *)y_dev + a->part_row0[b] * (uint64_t)a->elem_size, stream));
         return SPAL_OK;
     }
+    if (a->split_short) {   // row split: the short rows' handle writes every row of y, the long rows are then overwritten
+        SPAL_TRY(csr_launch(a->split_short, x_dev, y_dev, stream));
+        const uint32_t grid = (a->split_nlong + kStreamWaves - 1) / kStreamWaves;
+        if (a->elem_size == 8)
+            hipLaunchKernelGGL(csr_spmv_row_list<double>, dim3(grid), dim3(kStreamBlock), 0, stream, a->d_rowptr, a->d_colind,
+                               (const double *)a->d_values, (const double *)x_dev, (double *)y_dev, a->d_split_rows, a->split_nlong);
+        else
+            hipLaunchKernelGGL(csr_spmv_row_list<float>, dim3(grid), dim3(kStreamBlock), 0, stream, a->d_rowptr, a->d_colind,
+                               (const float *)a->d_values, (const float *)x_dev, (float *)y_dev, a->d_split_rows, a->split_nlong);
+        SPAL_HIP_TRY(hipGetLastError());
+        return SPAL_OK;
+    }
     if (a->nnz == 0) {
         const uint64_t n = a->nrows;
         if (a->elem_size == 8)
@@ -1179,8 +1191,105 @@ static int csr_fetch_group_windows(spal_csr *a) {
     return SPAL_OK;
 }
 
+static void csr_free(spal_csr *a);
+
+// ROW SPLIT (round 4).  Power-law row lengths: 0.7 % of the rows are longer than the 128 entries a lane
+// may sum, but a 64-row tile holds such a row with probability 36 % -- a third of the ROWS went to the overflow kernel, tile
+// by tile, for the sake of those few (2M rows, 20M entries, columns within +-5000: 196 us = 0.18).  When long rows keep a
+// tenth of the tiles and more from streaming, the handle multiplies as A = A_short + A_long instead: A_short is a compacted
+// copy WITHOUT the long rows' entries (they are empty rows in it) with a complete plan of its own -- stream kernels, sliding
+// window, column blocks, whatever its structure asks for --, the long rows are listed and taken a wave each out of the
+// original arrays (csr_spmv_row_list).  Short rows stay bit-identical to the reference's order; long rows are tree sums, as
+// they were in the overflow kernel (1e-10).  Built on the host side from a copy of rowptr (setup time).
+static int csr_try_row_split(spal_csr *a, bool *did) {
+    CsrPlan &p = a->plan;
+    *did = false;
+    if (a->split_short) { csr_free(a->split_short); a->split_short = nullptr; }
+    (void)dev_free(a->d_split_rows); a->d_split_rows = nullptr;
+    a->split_nlong = 0; a->split_long_entries = 0;
+    if (p.row_split == 0 || a->split_child || !a->parts.empty() || a->nnz == 0 || a->nrows < 2) return SPAL_OK;
+    const uint32_t T = (uint32_t)std::max(1, p.split_threshold);
+    std::vector<uint32_t> rp((size_t)a->nrows + 1);
+    SPAL_HIP_TRY(hipMemcpy(rp.data(), a->d_rowptr, rp.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> rows_long;
+    uint64_t tiles_hit = 0, long_entries = 0, ntiles = (a->nrows + 63) / 64;
+    for (uint64_t t = 0; t < ntiles; ++t) {
+        bool hit = false;
+        const uint64_t r1 = std::min<uint64_t>(a->nrows, (t + 1) * 64);
+        for (uint64_t r = t * 64; r < r1; ++r) {
+            const uint32_t len = rp[r + 1] - rp[r];
+            if (len > T) { hit = true; rows_long.push_back((uint32_t)r); long_entries += len; }
+        }
+        tiles_hit += hit ? 1 : 0;
+    }
+    const uint64_t nnz_s = a->nnz - long_entries;
+    const bool wanted = p.row_split == 1 ? !rows_long.empty()
+                                         : (tiles_hit * 10 >= ntiles && nnz_s >= a->nnz / 4 &&       // a tenth of the tiles poisoned; the short part is worth a plan
+                                            (double)nnz_s / (double)a->nrows <= 64.0);              // ... and streams
+    if (!wanted || rows_long.empty() || nnz_s == 0) return SPAL_OK;
+    // the short part's arrays
+    std::vector<uint32_t> rps((size_t)a->nrows + 1);
+    uint32_t run = 0;
+    for (uint64_t r = 0; r < a->nrows; ++r) {
+        rps[r] = run;
+        const uint32_t len = rp[r + 1] - rp[r];
+        if (len <= T) run += len;
+    }
+    rps[a->nrows] = run;
+    const uint64_t cap = (uint64_t)nnz_s + kStreamPad;
+    uint32_t *d_rps = nullptr, *d_cis = nullptr;
+    void *d_vas = nullptr;
+    hipError_t e = dev_alloc((void **)&d_rps, rps.size() * 4);
+    if (e == hipSuccess) e = dev_alloc((void **)&d_cis, cap * 4);
+    if (e == hipSuccess) e = dev_alloc(&d_vas, cap * (size_t)a->elem_size);
+    if (e == hipSuccess) e = dev_alloc((void **)&a->d_split_rows, rows_long.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_rps, rps.data(), rps.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(a->d_split_rows, rows_long.data(), rows_long.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset((char *)d_cis + (size_t)nnz_s * 4, 0, kStreamPad * 4);
+    if (e == hipSuccess) e = hipMemset((char *)d_vas + (size_t)nnz_s * a->elem_size, 0, kStreamPad * (size_t)a->elem_size);
+    if (e == hipSuccess) {
+        const uint32_t grid = (uint32_t)((a->nrows + 255) / 256);
+        if (a->elem_size == 8)
+            hipLaunchKernelGGL(csr_split_copy<double>, dim3(grid), dim3(256), 0, a->stream, a->d_rowptr, d_rps, a->d_colind,
+                               (const double *)a->d_values, d_cis, (double *)d_vas, (uint32_t)a->nrows);
+        else
+            hipLaunchKernelGGL(csr_split_copy<float>, dim3(grid), dim3(256), 0, a->stream, a->d_rowptr, d_rps, a->d_colind,
+                               (const float *)a->d_values, d_cis, (float *)d_vas, (uint32_t)a->nrows);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
+    spal_csr *child = nullptr;
+    int st = e == hipSuccess ? SPAL_OK : SPAL_ERR_HIP;
+    if (st == SPAL_OK) {
+        // (a handle of its own: its plan is built here, eagerly, with this handle's user options that concern the stream kernels)
+        st = csr_adopt_device(a->device, a->elem_size, a->nrows, a->ncols, nnz_s, cap, d_rps, d_cis, d_vas, &child, nullptr, true, true);
+        if (st == SPAL_OK) {
+            child->split_child = 1;
+            child->plan.row_split = 0;
+            st = csr_ensure_plan(child, nullptr, false);
+            if (st != SPAL_OK) { csr_free(child); child = nullptr; d_rps = nullptr; d_cis = nullptr; d_vas = nullptr; }
+        }
+    }
+    if (st != SPAL_OK) {   // an optional form: without it the handle runs the kernels it always ran
+        (void)dev_free(d_rps); (void)dev_free(d_cis); (void)dev_free(d_vas);
+        (void)dev_free(a->d_split_rows); a->d_split_rows = nullptr;
+        (void)hipGetLastError();
+        return SPAL_OK;
+    }
+    a->split_short = child;
+    a->split_nlong = (uint32_t)rows_long.size();
+    a->split_long_entries = long_entries;
+    *did = true;
+    return SPAL_OK;
+}
+
 int csr_plan_build(spal_csr *a) {
     SPAL_TRY(csr_fetch_group_windows(a));
+    {
+        bool did = false;
+        SPAL_TRY(csr_try_row_split(a, &did));
+        if (did) { a->plan.kernel = 3; return SPAL_OK; }   // ("split": the products run through the short part's handle)
+    }
     CsrPlan &p = a->plan;
     const double mean = a->nrows ? (double)a->nnz / (double)a->nrows : 0.0;
     // vector kernel geometry, from measurements (tools/lab.py ab): one lane per entry
@@ -1487,6 +1596,8 @@ static void csr_free(spal_csr *a) {
     (void)dev_free(a->d_ovtiles_slide);
     (void)dev_free(a->d_ptiles);
     (void)dev_free(a->d_pwin);
+    if (a->split_short) csr_free(a->split_short);
+    (void)dev_free(a->d_split_rows);
     if (a->d_vec_block && a->vec_block_owned) (void)hipFree(a->d_vec_block);
     else place_free(a->device, a->d_vec_block);
     (void)dev_free(a->d_win_groups);
@@ -1748,6 +1859,8 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
     if (iters < 1) iters = 1;
     DeviceGuard guard(a->device);
     if (guard.status != SPAL_OK) return guard.status;
+    SPAL_TRY(csr_ensure_plan(a, nullptr, false));
+    if (a->split_short) return csr_autotune<T>(a->split_short, x_dev, y_dev, stream, iters);   // (the short part's kernels; y is scratch here)
     std::lock_guard<std::mutex> lock(a->mu);
     CsrPlan &p = a->plan;
     for (float &t : a->tuned_us) t = 0.f;
@@ -1938,6 +2051,20 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
     DeviceGuard guard(a->device);
     if (guard.status != SPAL_OK) return guard.status;
     SPAL_TRY(csr_ensure_plan(a, nullptr, false));
+    if (!strcmp(key, "row_split") || !strcmp(key, "row_split_threshold")) {
+        // skewed row lengths: rows above the threshold multiplied apart from the rest (csr_try_row_split): -1 = when they keep
+        // a tenth of the 64-row tiles from streaming, 0 = never, 1 = whenever there is such a row
+        std::lock_guard<std::mutex> lock(a->mu);
+        if (!strcmp(key, "row_split")) {
+            if (value < -1 || value > 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "row_split must be -1 (auto), 0 or 1");
+            a->plan.row_split = (int)value;
+        } else {
+            if (value < 1 || value > 4096) return fail(SPAL_ERR_INVALID_ARGUMENT, "row_split_threshold must be in [1, 4096]");
+            a->plan.split_threshold = (int)value;
+        }
+        return a->split_child ? SPAL_OK : csr_plan_build(a);
+    }
+    if (a->split_short) return spal_csr_set_option(a->split_short, key, value);   // every other option concerns the short part's kernels
     std::lock_guard<std::mutex> lock(a->mu);
     CsrPlan saved = a->plan;
     CsrPlan &p = a->plan;
@@ -2278,6 +2405,16 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
         DeviceGuard guard(a->device);
         if (guard.status != SPAL_OK) return guard.status;
         SPAL_TRY(csr_ensure_plan(a, nullptr, false));
+    }
+    if (a->split_short) {   // row split: the whole, what was split off, and the short part's plan
+        std::vector<char> part(buf_len);
+        SPAL_TRY(spal_csr_describe(a->split_short, part.data(), part.size()));
+        snprintf(buf, buf_len,
+                 "{\"format\": \"csr\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"nnz\": %llu, \"kernel\": \"split\", "
+                 "\"split_threshold\": %d, \"split_long_rows\": %u, \"split_long_entries\": %llu, \"short_part\": %s}",
+                 a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows, (unsigned long long)a->ncols,
+                 (unsigned long long)a->nnz, a->plan.split_threshold, a->split_nlong, (unsigned long long)a->split_long_entries, part.data());
+        return SPAL_OK;
     }
     const CsrPlan &p = a->plan;
     snprintf(buf, buf_len,

@@ -162,6 +162,8 @@ struct CsrPlan {
     int all_rows_uniform = 0; // ... and EVERY row of the matrix has it (rowptr[r] = r * length): tile bounds are arithmetic
     int arith_bounds = 1;    // option "arith_bounds": use that (0: load the tiles' bounds from rowptr as before)
     int slide_even = 1;      // option "slide_even": one run per workgroup -> the XCD's steps split evenly over all its workgroups
+    int row_split = -1;      // option "row_split": -1 = when long rows keep a tenth of the 64-row tiles from streaming, 0 never, 1 always (tests)
+    int split_threshold = 128;   // option "row_split_threshold": rows above it are "long"
     int place_tries = 8;     // autotune: blocks of 1 GiB the 16-bit columns are tried in, at most (see csr_autotune)
     int split_tiles_on = 1;  // sliding kernel: tiles above 1024 entries whose halves fit go through the strip twice
     int diag = 0;            // ablation builds (-DSPAL_DIAG) only: parts of the stream kernel switched off
@@ -216,6 +218,15 @@ struct spal_csr {
     uint8_t *d_cb_cnt = nullptr;   // entries per (tile, row): the builder's scratch
     uint16_t *d_cb_row = nullptr;  // row of every entry inside its row block
     float cblock_us[2] = {0.f, 0.f};   // autotune: per launch {stream kernels, column-blocked kernel}
+    // ROW SPLIT (skewed row lengths: a few long rows poison the 64-row tiles of the stream kernel): the matrix is multiplied as
+    // A = A_short + A_long -- `split_short` is a complete handle of its own over a compacted copy of the rows of at most
+    // `split_threshold` entries (the long rows are empty rows in it: it writes every row of y), `d_split_rows` lists the
+    // long rows, which csr_spmv_row_list then overwrites out of THIS handle's arrays.  No temporaries: concurrent products stay safe.
+    spal_csr *split_short = nullptr;
+    uint32_t *d_split_rows = nullptr;
+    uint32_t split_nlong = 0;
+    uint64_t split_long_entries = 0;
+    int split_child = 0;           // this handle IS the short part of a split (never splits again)
     int plan_pending = 0;          // a device-assembled handle: the product kernels' plan is built by whoever needs it first (csr_ensure_plan)
     int cblock_lazy = 0;           // build the tiled copy with the first product, not with the plan (csr_adopt_device)
     int cblock_failed = 0;         // building it failed (out of memory, ...): the stream kernels run instead

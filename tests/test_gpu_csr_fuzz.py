@@ -76,6 +76,12 @@ def test_random_matrices_all_planner_paths(oracle, seed):
     dev = sp.CsrMatrix(n, ncols, rp, ci, va).device()
     d = dev.describe()
     assert_spmv_close(dev.spmv(x), y_ref, bound, TOL[va.dtype])
+    if d["kernel"] == "split":          # skewed rows: the planner split the long rows off (round 4); the rest of this test
+        assert d["split_long_rows"] > 0 and d["short_part"]["nnz"] + d["split_long_entries"] == int(rp[-1]), d
+        dev.set_option("row_split", 0)  # drives the one-handle paths
+        d = dev.describe()
+        assert d["kernel"] != "split"
+        assert_spmv_close(dev.spmv(x), y_ref, bound, TOL[va.dtype])
     if d["kernel"] == "stream":
         for key, value in (("persistent", 1), ("skew", 1 - d["skew"]), ("rows_per_tile", 8), ("rows_per_tile", 128), ("rows_per_tile", 256), ("rows_per_tile", 12), ("stream_row_max", 16),
                            ("window_pages", 4)):
@@ -99,3 +105,12 @@ def test_random_matrices_all_planner_paths(oracle, seed):
             assert np.array_equal(dev.spmv(x).view(bits), y_ref.view(bits)), dev.describe()
         else:
             assert_spmv_close(dev.spmv(x), y_ref, bound, TOL[va.dtype])
+        # ... and the row split forced at a random threshold: rows above it by csr_spmv_row_list, the rest by a handle of their own
+        dev.set_option("cblock", -1)
+        dev.set_option("row_split_threshold", int(rng.choice([1, 4, 16, 128, 1000])))
+        dev.set_option("row_split", 1)
+        d = dev.describe()
+        lens = np.diff(rp.astype(np.int64))
+        if (lens > d.get("split_threshold", 1 << 30)).any() and d["kernel"] == "split":
+            assert d["split_long_rows"] == int((lens > d["split_threshold"]).sum()), d
+        assert_spmv_close(dev.spmv(x), y_ref, bound, TOL[va.dtype])

@@ -1136,3 +1136,54 @@ def test_device_copy_is_a_handle_of_its_own(oracle):
     assert np.array_equal(d0.spmv(x), y_ref) and np.array_equal(d2.spmv(x), y_ref)
     d2.close()
     assert np.array_equal(a.device().spmv(x), y_ref)               # the cached handle is untouched
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_row_split_on_power_law_rows(oracle, dtype):
+    """Skewed row lengths (round 4): 0.7 % of the rows are longer than a lane may sum, and a third of the
+    64-row tiles hold one -- the planner multiplies the long rows apart from the rest (A = A_short + A_long).  The short rows
+    go through a plan of their own and keep the reference's bits; the long rows are tree sums (1e-10 / 1e-4).  Switched off
+    the handle runs as rounds 1-3 did, and agrees."""
+    rng = np.random.default_rng(11)
+    n = 400_000
+    lens = np.minimum((rng.pareto(1.6, n) * 6 + 1).astype(np.int64), 5000)
+    lens[:3] = (0, 5000, 129)
+    rows = np.repeat(np.arange(n, dtype=np.int64), lens)
+    cols = np.clip(rows - 5000 + rng.integers(0, 10000, rows.size), 0, n - 1)
+    key = np.unique(rows * n + cols)
+    r2, c2 = key // n, key % n
+    rp = np.concatenate([[0], np.cumsum(np.bincount(r2, minlength=n))]).astype(np.uint64)
+    ci, va = c2.astype(np.uint64), rng.uniform(-1, 1, c2.size).astype(dtype)
+    x = rng.uniform(-1, 1, n).astype(dtype)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    bound = oracle.csr_abs_bound(rp, ci, va.astype(np.float64), x.astype(np.float64))
+    tol = 1e-10 if dtype == np.float64 else 1e-4
+    dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    d = dev.describe()
+    rl = np.diff(rp.astype(np.int64))
+    assert d["kernel"] == "split" and d["split_threshold"] == 128 and d["split_long_rows"] == int((rl > 128).sum()), d
+    assert d["split_long_entries"] == int(rl[rl > 128].sum()) and d["short_part"]["kernel"] == "stream", d
+    y = dev.spmv(x)
+    assert_spmv_close(y, y_ref, bound, tol)
+    short = rl <= 128
+    bits = np.uint64 if dtype == np.float64 else np.uint32
+    if d["short_part"]["stream_row_fraction"] == 1.0 and d["short_part"]["overflow_tiles"] == 0:
+        assert np.array_equal(y[short].view(bits), y_ref[short].view(bits))       # every short row: the reference's order
+    # the device entry point on two streams at once (no temporaries in the split: concurrent products stay safe)
+    import torch
+    xt = torch.from_numpy(x).cuda()
+    ys = [torch.full((n,), float("nan"), dtype=xt.dtype, device="cuda") for _ in range(2)]
+    st = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    for _ in range(3):
+        for k in range(2):
+            dev.spmv_dev(xt.data_ptr(), ys[k].data_ptr(), st[k])
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert np.array_equal(ys[k].cpu().numpy().view(bits), y.view(bits))
+    dev.set_option("row_split", 0)
+    d0 = dev.describe()
+    assert d0["kernel"] == "stream" and d0["overflow_tiles"] > 0, d0
+    assert_spmv_close(dev.spmv(x), y_ref, bound, tol)
+    dev.set_option("row_split", -1)
+    assert dev.describe()["kernel"] == "split"

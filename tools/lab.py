@@ -786,7 +786,28 @@ def longrows():
     import torch  # noqa: E402
     import spalinalg_amd as sp  # noqa: E402
     import spal_synth as synth  # noqa: E402
-    from tools.lab_zoo import from_lens, timeit  # noqa: E402
+
+    def timeit(fn, iters=20, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    def from_lens(lens, col_fn, rng):
+        n = lens.size
+        rows = np.repeat(np.arange(n, dtype=np.int64), lens)
+        pos = np.arange(rows.size, dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens)
+        cols = col_fn(rows, pos, rng)
+        key = np.unique(rows * (int(cols.max()) + 1) + cols)
+        rows2, cols2 = key // (int(cols.max()) + 1), key % (int(cols.max()) + 1)
+        rp = np.concatenate([[0], np.cumsum(np.bincount(rows2, minlength=n))]).astype(np.uint64)
+        return rp, cols2.astype(np.uint64), rng.uniform(-1, 1, cols2.size)
 
     def main():
         rng = np.random.default_rng(5)
@@ -1145,7 +1166,28 @@ def powerlaw():
     import torch  # noqa: E402
     import spalinalg_amd as sp  # noqa: E402
     import spal_synth as synth  # noqa: E402
-    from tools.lab_zoo import from_lens, timeit  # noqa: E402
+
+    def timeit(fn, iters=20, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    def from_lens(lens, col_fn, rng):
+        n = lens.size
+        rows = np.repeat(np.arange(n, dtype=np.int64), lens)
+        pos = np.arange(rows.size, dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens)
+        cols = col_fn(rows, pos, rng)
+        key = np.unique(rows * (int(cols.max()) + 1) + cols)
+        rows2, cols2 = key // (int(cols.max()) + 1), key % (int(cols.max()) + 1)
+        rp = np.concatenate([[0], np.cumsum(np.bincount(rows2, minlength=n))]).astype(np.uint64)
+        return rp, cols2.astype(np.uint64), rng.uniform(-1, 1, cols2.size)
 
     def main():
         rng = np.random.default_rng(5)
@@ -1165,8 +1207,8 @@ def powerlaw():
             x = torch.from_numpy(synth.vector(n)).cuda()
             y = torch.empty(n, dtype=torch.float64, device="cuda")
             print(f"power-law rows (mean {pl.mean():.1f}, max {pl.max()}), columns {name}: nnz {nnz}, floor {B/8e12*1e6:.1f} us", flush=True)
-            variants = ([("kernel", 0)], [("stream_row_max", 128), ("rows_per_tile", 64)], [("rows_per_tile", 64), ("window_pages", 24)],
-                        [("rows_per_tile", 16), ("window_pages", 24)]) if quick else None
+            variants = ([("row_split", -1)], [("row_split", 0)], [("row_split", -1), ("row_split_threshold", 64)],
+                        [("row_split", -1), ("row_split_threshold", 256)]) if quick else None
             for opts in variants or ([("kernel", 0)], [("stream_row_max", 1024)], [("stream_row_max", 256)], [("stream_row_max", 128)],
                          [("stream_row_max", 64)], [("stream_row_max", 32)],
                          [("stream_row_max", 128), ("rows_per_tile", 64)], [("stream_row_max", 128), ("rows_per_tile", 16)],
@@ -1176,12 +1218,18 @@ def powerlaw():
                     dev.set_option(k, v)
                 for pers in (0, 1):
                     d = dev.describe()
+                    split = d["kernel"] == "split"
+                    if split:
+                        d = d["short_part"]
                     if d["kernel"] != "stream" and pers:
                         continue
                     if d["kernel"] == "stream":
                         dev.set_option("persistent", pers)
                     t = timeit(lambda: dev.spmv_torch(x, out=y))
                     d = dev.describe()
+                    if split:
+                        print(f"  (split: {d['split_long_rows']} long rows, {d['split_long_entries']} entries)", end="")
+                        d = d["short_part"]
                     print(f"  {str(dict(opts)):70s} pers={pers}: {t*1e3:8.1f} us = {100*B/(t*1e-3)/8e12:5.1f} %  "
                           f"[{d['kernel']} rpt={d['rows_per_tile']} stream={d['stream_row_fraction']:.3f} "
                           f"overflow_tiles={d.get('overflow_tiles')} win={d['lds_window_bytes']//1024}K]", flush=True)
@@ -1256,7 +1304,28 @@ def shortrows():
     import torch  # noqa: E402
     import spalinalg_amd as sp  # noqa: E402
     import spal_synth as synth  # noqa: E402
-    from tools.lab_zoo import from_lens, timeit  # noqa: E402
+
+    def timeit(fn, iters=20, warm=3):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    def from_lens(lens, col_fn, rng):
+        n = lens.size
+        rows = np.repeat(np.arange(n, dtype=np.int64), lens)
+        pos = np.arange(rows.size, dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens)
+        cols = col_fn(rows, pos, rng)
+        key = np.unique(rows * (int(cols.max()) + 1) + cols)
+        rows2, cols2 = key // (int(cols.max()) + 1), key % (int(cols.max()) + 1)
+        rp = np.concatenate([[0], np.cumsum(np.bincount(rows2, minlength=n))]).astype(np.uint64)
+        return rp, cols2.astype(np.uint64), rng.uniform(-1, 1, cols2.size)
 
     def main():
         rng = np.random.default_rng(5)
