@@ -1085,20 +1085,58 @@ __global__ __launch_bounds__(kStreamBlock) void csr_spmv_overflow(
 }
 
 // ---- the LONG rows of a row-split plan (spal_csr.hip: csr_try_row_split) -----------------------------------------
-// rows[i], i < nlong: rows of more than the split's threshold.  A wave per row: consecutive lanes read consecutive entries
+// rows[i], i < nlong: rows of more than the split's threshold, longest first; the first nheavy (more than 1024 entries) take a
+// whole workgroup each and start first.  Otherwise a wave per row: consecutive lanes read consecutive entries
 // (coalesced, non-temporal), x gathered through L2, lane-partial sums folded by a shuffle tree -- rounded like every row the
 // vector kernels compute (1e-10 parity, not bit-identical).  Rows of a power-law tail, a few thousand entries at most:
 // the wave loops; four rows in flight per workgroup.
+// partial sum of entries b + s, b + s + S, ... < e with EIGHT entries per lane in flight: all eight (column, value) pairs are
+// requested before the first x is gathered (clamped, masked: no branch between the loads), so a row of up to 8 S entries costs
+// two dependent round trips, not four
+template <typename T, uint32_t S>
+__device__ __forceinline__ T strided_row_sum8(const uint32_t *__restrict__ colind, const T *__restrict__ vals,
+                                              const T *__restrict__ x, uint32_t b, uint32_t e, uint32_t s) {
+    T acc = T(0);
+    for (uint32_t k0 = b + s; k0 < e; k0 += 8 * S) {   // (lanes past the row's end skip the trip; e > b here)
+        uint32_t c[8];
+        T v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t k = min(k0 + u * S, e - 1u);
+            c[u] = __builtin_nontemporal_load(colind + k);
+            v[u] = __builtin_nontemporal_load(vals + k);
+        }
+        T xv[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) xv[u] = x[c[u]];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u)
+            if (k0 + u * S < e) acc += v[u] * xv[u];
+    }
+    return acc;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kStreamBlock) void csr_spmv_row_list(
     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind, const T *__restrict__ vals,
-    const T *__restrict__ x, T *__restrict__ y, const uint32_t *__restrict__ rows, uint32_t nlong) {
+    const T *__restrict__ x, T *__restrict__ y, const uint32_t *__restrict__ rows, uint32_t nlong, uint32_t nheavy) {
+    // rows[3 i ...] = {row, its first entry, one past its last}: the bounds come with the list, not by a second round trip
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const uint32_t i = blockIdx.x * kStreamWaves + wave;
+    if (blockIdx.x < nheavy) {   // block-uniform: one of the longest rows (listed first), the whole workgroup on it
+        __shared__ T part[kStreamWaves];
+        const uint32_t r = rows[3u * blockIdx.x], b = rows[3u * blockIdx.x + 1u], e = rows[3u * blockIdx.x + 2u];
+        T acc = strided_row_sum8<T, kStreamBlock>(colind, vals, x, b, e, threadIdx.x);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) part[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) y[r] = (part[0] + part[1]) + (part[2] + part[3]);
+        return;
+    }
+    const uint32_t i = nheavy + (blockIdx.x - nheavy) * kStreamWaves + wave;
     if (i >= nlong) return;   // wave-uniform
-    const uint32_t r = rows[i];
-    const uint32_t b = rowptr[r], e = rowptr[r + 1];
-    T acc = strided_row_sum<T, kWave>(colind, vals, x, b, e, lane);
+    const uint32_t r = rows[3u * i], b = rows[3u * i + 1u], e = rows[3u * i + 2u];
+    T acc = strided_row_sum8<T, kWave>(colind, vals, x, b, e, lane);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
     if (lane == 0) y[r] = acc;

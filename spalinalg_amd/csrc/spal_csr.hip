@@ -699,6 +699,15 @@ static int slide_plan(spal_csr *a, uint32_t R, uint32_t rpt, const std::vector<u
     p.slide_steps = nsteps;
     p.slide_S = (int)S;
     p.slide_uniform = (uni && ulen != 0u) ? (int)ulen : 0;
+    // every tile of the sliding kernel issues S loads per array (counted waits): where the tiles are on average less than
+    // 60 % of the largest one -- ragged short rows, the short part of a row split: 4 of 8 steps -- half its loads are
+    // re-reads, and the one-super-tile-per-workgroup kernel, which issues what a tile holds, is faster (power-law short
+    // part: 104 -> 68 us); the autotune still times both
+    {
+        const double tiles = (double)nsteps * kStreamWaves;
+        const double avg_steps = tiles > 0 ? (double)a->nnz / tiles / 128.0 : 0.0;
+        p.slide_fill_ok = (p.slide_fill_user >= 0) ? p.slide_fill_user : (avg_steps >= 0.6 * (double)std::max(4u, S) ? 1 : 0);
+    }
     // every row of the matrix that long: all steps stream (no tile left to the overflow kernel, none split) and the entries
     // add up
     p.all_rows_uniform = (p.slide_uniform && left_over.empty() && n_split == 0 &&
@@ -859,7 +868,7 @@ template <typename T>
 static hipError_t launch_stream_main(const spal_csr *a, const void *x, void *y, hipStream_t st);
 
 static bool slide_runs(const spal_csr *a, const void *x) {   // (its page loads are 16-byte vectors of x)
-    return a->plan.slide && a->plan.slide_on && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+    return a->plan.slide && a->plan.slide_on && a->plan.slide_fill_ok && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
 }
 
 template <typename T>
@@ -947,13 +956,15 @@ int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream) 
     }
     if (a->split_short) {   // row split: the short rows' handle writes every row of y, the long rows are then overwritten
         SPAL_TRY(csr_launch(a->split_short, x_dev, y_dev, stream));
-        const uint32_t grid = (a->split_nlong + kStreamWaves - 1) / kStreamWaves;
+        const uint32_t grid = a->split_nheavy + (a->split_nlong - a->split_nheavy + kStreamWaves - 1) / kStreamWaves;
         if (a->elem_size == 8)
             hipLaunchKernelGGL(csr_spmv_row_list<double>, dim3(grid), dim3(kStreamBlock), 0, stream, a->d_rowptr, a->d_colind,
-                               (const double *)a->d_values, (const double *)x_dev, (double *)y_dev, a->d_split_rows, a->split_nlong);
+                               (const double *)a->d_values, (const double *)x_dev, (double *)y_dev, a->d_split_rows, a->split_nlong,
+                               a->split_nheavy);
         else
             hipLaunchKernelGGL(csr_spmv_row_list<float>, dim3(grid), dim3(kStreamBlock), 0, stream, a->d_rowptr, a->d_colind,
-                               (const float *)a->d_values, (const float *)x_dev, (float *)y_dev, a->d_split_rows, a->split_nlong);
+                               (const float *)a->d_values, (const float *)x_dev, (float *)y_dev, a->d_split_rows, a->split_nlong,
+                               a->split_nheavy);
         SPAL_HIP_TRY(hipGetLastError());
         return SPAL_OK;
     }
@@ -1222,6 +1233,11 @@ static int csr_try_row_split(spal_csr *a, bool *did) {
         }
         tiles_hit += hit ? 1 : 0;
     }
+    // longest first: the rows of more than 1024 entries get a workgroup each and start first (a row of 5000 entries by one
+    // wave is 20 dependent trips, 80 us -- the launch's tail)
+    std::stable_sort(rows_long.begin(), rows_long.end(), [&](uint32_t x, uint32_t y) { return rp[x + 1] - rp[x] > rp[y + 1] - rp[y]; });
+    uint32_t n_heavy = 0;
+    while (n_heavy < rows_long.size() && rp[rows_long[n_heavy] + 1] - rp[rows_long[n_heavy]] > 1024u) ++n_heavy;
     const uint64_t nnz_s = a->nnz - long_entries;
     const bool wanted = p.row_split == 1 ? !rows_long.empty()
                                          : (tiles_hit * 10 >= ntiles && nnz_s >= a->nnz / 4 &&       // a tenth of the tiles poisoned; the short part is worth a plan
@@ -1242,9 +1258,13 @@ static int csr_try_row_split(spal_csr *a, bool *did) {
     hipError_t e = dev_alloc((void **)&d_rps, rps.size() * 4);
     if (e == hipSuccess) e = dev_alloc((void **)&d_cis, cap * 4);
     if (e == hipSuccess) e = dev_alloc(&d_vas, cap * (size_t)a->elem_size);
-    if (e == hipSuccess) e = dev_alloc((void **)&a->d_split_rows, rows_long.size() * 4);
+    std::vector<uint32_t> list(rows_long.size() * 3);   // {row, first entry, one past the last}
+    for (size_t i = 0; i < rows_long.size(); ++i) {
+        list[3 * i] = rows_long[i]; list[3 * i + 1] = rp[rows_long[i]]; list[3 * i + 2] = rp[rows_long[i] + 1];
+    }
+    if (e == hipSuccess) e = dev_alloc((void **)&a->d_split_rows, list.size() * 4);
     if (e == hipSuccess) e = hipMemcpy(d_rps, rps.data(), rps.size() * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(a->d_split_rows, rows_long.data(), rows_long.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(a->d_split_rows, list.data(), list.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset((char *)d_cis + (size_t)nnz_s * 4, 0, kStreamPad * 4);
     if (e == hipSuccess) e = hipMemset((char *)d_vas + (size_t)nnz_s * a->elem_size, 0, kStreamPad * (size_t)a->elem_size);
     if (e == hipSuccess) {
@@ -1277,6 +1297,7 @@ static int csr_try_row_split(spal_csr *a, bool *did) {
         return SPAL_OK;
     }
     a->split_short = child;
+    a->split_nheavy = n_heavy;
     a->split_nlong = (uint32_t)rows_long.size();
     a->split_long_entries = long_entries;
     *did = true;
@@ -1919,7 +1940,7 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
     float best_ms = 1e30f;
     for (int round = 0; round < 2 && rc == SPAL_OK; ++round) {      // round 0 also settles the clocks
         for (int cand = 0; cand < 4 && rc == SPAL_OK; ++cand) {
-            if (walking_is_slide) { p.slide_on = cand & 1; p.persistent = 0; }
+            if (walking_is_slide) { p.slide_on = cand & 1; p.slide_fill_ok = 1; p.persistent = 0; }
             else p.persistent = cand & 1;
             p.nt_store = (cand >> 1) & 1;
             float ms = 0.f;
@@ -1930,7 +1951,7 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
             }
         }
     }
-    if (walking_is_slide) { p.slide_on = best & 1; p.persistent = 0; }
+    if (walking_is_slide) { p.slide_on = best & 1; p.slide_fill_ok = 1; p.persistent = 0; }
     else p.persistent = best & 1;
     p.user_persistent = true;   // measured: a later re-plan keeps it
     p.nt_store = (best >> 1) & 1;
@@ -2165,6 +2186,8 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
     } else if (!strcmp(key, "slide_on")) {
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "slide_on must be 0 or 1");
         p.slide_on = (int)value;
+        p.slide_fill_user = value ? 1 : -1;   // (asked for by name: also where the tiles are ragged)
+        p.slide_fill_ok = value ? 1 : p.slide_fill_ok;
     } else if (!strcmp(key, "slide_even")) {
         // sliding kernel, one run per workgroup: steps split evenly over all workgroups of an XCD (default 1) or runs of ceil(steps / workgroups)
         if (value != 0 && value != 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "slide_even must be 0 or 1");
@@ -2436,7 +2459,7 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
              (p.kernel == 2 && p.skew) ? 1 : 0,
              (p.kernel == 2 && p.persistent && p.tiles_per_wave == 4) ? 1 : 0,
              p.kernel == 2 ? p.nt_store : 0, p.kernel == 2 ? p.uniform_row_fraction : 0.0,
-             p.kernel == 2 ? p.prefetch : 0, (p.kernel == 2 && p.slide && p.slide_on) ? 1 : 0,
+             p.kernel == 2 ? p.prefetch : 0, (p.kernel == 2 && p.slide && p.slide_on && p.slide_fill_ok) ? 1 : 0,
              p.kernel == 2 ? p.ring_pages : 0, (p.kernel == 2 && p.slide) ? p.slide_S : 0,
              (p.kernel == 2 && p.slide && p.slide_on) ? a->n_split_tiles : 0u,
              (p.kernel == 2 && p.panel_on) ? a->n_ptiles : 0u,

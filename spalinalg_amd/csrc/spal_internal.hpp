@@ -161,6 +161,8 @@ struct CsrPlan {
     int slide_uniform = 0;   // 1 + the length of every row when all streamed rows have one length (rowptr is not read), else 0
     int all_rows_uniform = 0; // ... and EVERY row of the matrix has it (rowptr[r] = r * length): tile bounds are arithmetic
     int arith_bounds = 1;    // option "arith_bounds": use that (0: load the tiles' bounds from rowptr as before)
+    int slide_fill_ok = 1;   // the sliding kernel's tiles are full enough for its fixed count of loads per tile (csr_slide plan)
+    int slide_fill_user = -1; // -1 = by the tiles' average fill, 1 = "slide_on" was asked for by name
     int slide_even = 1;      // option "slide_even": one run per workgroup -> the XCD's steps split evenly over all its workgroups
     int row_split = -1;      // option "row_split": -1 = when long rows keep a tenth of the 64-row tiles from streaming, 0 never, 1 always (tests)
     int split_threshold = 128;   // option "row_split_threshold": rows above it are "long"
@@ -224,7 +226,7 @@ struct spal_csr {
     // long rows, which csr_spmv_row_list then overwrites out of THIS handle's arrays.  No temporaries: concurrent products stay safe.
     spal_csr *split_short = nullptr;
     uint32_t *d_split_rows = nullptr;
-    uint32_t split_nlong = 0;
+    uint32_t split_nlong = 0, split_nheavy = 0;   // listed rows (longest first); the first split_nheavy hold more than 1024 entries
     uint64_t split_long_entries = 0;
     int split_child = 0;           // this handle IS the short part of a split (never splits again)
     int plan_pending = 0;          // a device-assembled handle: the product kernels' plan is built by whoever needs it first (csr_ensure_plan)

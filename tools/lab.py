@@ -1566,6 +1566,9 @@ def zoo():
             nnz = int(rp[-1])
             B = synth.spmv_bytes(nnz, nrows, nrows, ncols, 8)
             d = dev.describe()
+            if d["kernel"] == "split":
+                name = name + f" [split: {d['split_long_rows']} long rows]"
+                d = d["short_part"]
             print(f"{name:52s} nnz {nnz:>10d}  {t*1e3:8.1f} us -> autotuned {t2*1e3:8.1f} us = {100*B/(t2*1e-3)/8e12:5.1f} % of 8 TB/s  "
                   f"[{d['kernel']} rpt={d['rows_per_tile']} stream={d['stream_row_fraction']:.2f} lds={d['lds_row_fraction']:.2f} "
                   f"win={d['lds_window_bytes']//1024}K pers={d['persistent']}]  (host {time.time()-t0:.0f} s)", flush=True)
