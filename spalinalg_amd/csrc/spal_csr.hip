@@ -1204,6 +1204,24 @@ static int csr_fetch_group_windows(spal_csr *a) {
 
 static void csr_free(spal_csr *a);
 
+// setup: out = {rows longer than T, 64-row tiles that hold one, their entries (low, high word)} -- what decides whether the
+// row split is worth building, before anything is copied to the host
+__global__ __launch_bounds__(256) void csr_long_rows_scan(const uint32_t *__restrict__ rowptr, uint32_t nrows, uint32_t T,
+                                                          unsigned long long *__restrict__ out) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t len = r < nrows ? rowptr[r + 1] - rowptr[r] : 0u;
+    const bool lng = len > T;
+    const uint64_t m = __ballot(lng);          // a wave = a 64-row tile
+    unsigned long long entries = lng ? len : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) entries += __shfl_xor(entries, o);
+    if ((threadIdx.x & 63) == 0 && m) {
+        atomicAdd(&out[0], (unsigned long long)__popcll(m));
+        atomicAdd(&out[1], 1ull);
+        atomicAdd(&out[2], entries);
+    }
+}
+
 // ROW SPLIT (round 4).  Power-law row lengths: 0.7 % of the rows are longer than the 128 entries a lane
 // may sum, but a 64-row tile holds such a row with probability 36 % -- a third of the ROWS went to the overflow kernel, tile
 // by tile, for the sake of those few (2M rows, 20M entries, columns within +-5000: 196 us = 0.18).  When long rows keep a
@@ -1220,6 +1238,24 @@ static int csr_try_row_split(spal_csr *a, bool *did) {
     a->split_nlong = 0; a->split_long_entries = 0;
     if (p.row_split == 0 || a->split_child || !a->parts.empty() || a->nnz == 0 || a->nrows < 2) return SPAL_OK;
     const uint32_t T = (uint32_t)std::max(1, p.split_threshold);
+    {   // on the device first (one pass over rowptr, 24 bytes back): most matrices have no such rows, or too few
+        unsigned long long *d_cnt = nullptr, cnt[3] = {0, 0, 0};
+        SPAL_HIP_TRY(dev_alloc((void **)&d_cnt, 24));
+        hipError_t e = hipMemsetAsync(d_cnt, 0, 24, a->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(csr_long_rows_scan, dim3((uint32_t)((a->nrows + 255) / 256)), dim3(256), 0, a->stream, a->d_rowptr,
+                               (uint32_t)a->nrows, T, d_cnt);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(cnt, d_cnt, 24, hipMemcpyDeviceToHost, a->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(a->stream);
+        (void)dev_free(d_cnt);
+        SPAL_HIP_TRY(e);
+        const uint64_t ntiles0 = (a->nrows + 63) / 64, nnz_s0 = a->nnz - cnt[2];
+        const bool wanted0 = p.row_split == 1 ? cnt[0] != 0
+                                              : (cnt[1] * 10 >= ntiles0 && nnz_s0 >= a->nnz / 4 && (double)nnz_s0 / (double)a->nrows <= 64.0);
+        if (!wanted0 || cnt[0] == 0 || nnz_s0 == 0) return SPAL_OK;
+    }
     std::vector<uint32_t> rp((size_t)a->nrows + 1);
     SPAL_HIP_TRY(hipMemcpy(rp.data(), a->d_rowptr, rp.size() * 4, hipMemcpyDeviceToHost));
     std::vector<uint32_t> rows_long;
