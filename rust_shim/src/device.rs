@@ -97,6 +97,12 @@ impl<T: HipScalar> DeviceCsr<T> {
         (x as *mut T, y as *mut T)
     }
 
+    /// Builds the product kernels' plan of a device-assembled handle now (include/spal.h: spal_csr_plan); otherwise its first
+    /// product, `set_option`, `autotune` or `vectors` does.  No-op on handles created from host arrays.
+    pub fn plan(&self) {
+        unsafe { ffi::check(ffi::spal_csr_plan(self.h)); }
+    }
+
     /// Kernel plan knob (include/spal.h: spal_csr_set_option).
     pub fn set_option(&self, key: &str, value: i64) {
         let k = std::ffi::CString::new(key).expect("option key");
@@ -134,6 +140,14 @@ impl<T: HipScalar> DeviceCsc<T> {
         let (mut nr, mut nc, mut nz, mut es) = (0u64, 0u64, 0u64, 0 as c_int);
         unsafe { ffi::check(ffi::spal_csc_shape(self.h, &mut nr, &mut nc, &mut nz, &mut es)); }
         (nr as usize, nc as usize, nz as usize)
+    }
+
+    /// Device-pointer products of this handle whose neighbour hand-off hit its spin bound (their y was not valid):
+    /// include/spal.h: spal_csc_status; call after synchronising the stream.  0 on every other route.
+    pub fn invalid_products(&self) -> i32 {
+        let mut n: c_int = 0;
+        unsafe { ffi::check(ffi::spal_csc_status(self.h, &mut n)); }
+        n as i32
     }
 
     pub fn mul_vec(&self, x: &[T]) -> Vec<T> {
