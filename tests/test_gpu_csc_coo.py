@@ -637,6 +637,26 @@ def test_coo_assembly_randomised(oracle, seed):
     assert_spmv_close(csr * x, oracle.csr_spmv(rp, ci, va, x), bound, 1e-10 if dtype == np.float64 else 1e-4)
 
 
+def test_coo_wide_columns_take_the_unpacked_forms(oracle):
+    """2^28 columns: column | row-in-group does not fit one word and column << 5 leaves no room for the place in the row, so
+    the second pass writes key + column and the group kernel runs its loop form (rounds 1-3) -- offsets still from the two
+    passes' counts.  Same bits as the oracle."""
+    rng = np.random.default_rng(41)
+    nr, nc, n = 300_000, (1 << 28) + 5, 2_500_000
+    r = rng.integers(0, nr, n).astype(np.uint64)
+    c = rng.integers(0, nc, n).astype(np.uint64)
+    c[: n // 50] = c[n // 50: 2 * (n // 50)]            # duplicates (insertion-order sums) ...
+    r[: n // 50] = r[n // 50: 2 * (n // 50)]
+    v = rng.integers(-3, 4, n).astype(np.float64) * 0.37  # ... some cancelling
+    dev = sp.CooMatrix.with_triplets(nr, nc, r, c, v).upload()
+    got = dev.assemble_csr()
+    d = dev.describe()
+    assert d["last_route"] == "local_sort" and d["packed_payload"] == 0 and d["row_sort"] == 0 and d["offsets_from_counts"] == 1, d
+    p, i, w = oracle.coo_to_csr(nr, nc, r, c, v)
+    gp, gi, gw = got.download()
+    assert np.array_equal(gp, p) and np.array_equal(gi, i) and np.array_equal(gw.view(np.uint64), w.view(np.uint64))
+
+
 def test_coo_out_of_bounds_panics():
     with pytest.raises(sp.Panic):
         sp.CooMatrix.with_triplets(2, 2, [0, 2], [0, 0], np.array([1.0, 2.0]))
