@@ -858,7 +858,8 @@ __global__ __launch_bounds__(256, CAP == 1536 ? SPAL_COO_LB_1536 : CAP == 2048 ?
     uint32_t rc[K], pr[K];   // column; (row inside the group) << 16 | position (step 1: among the row's entries, then in the group)
     // (lanes beyond the group's last entry read the next group's entries, or up to 255 entries past the end of the sorted
     //  arrays, which lie inside the workspace -- never looked at: one base address and immediate offsets instead of a clamp
-    //  and an address per load)
+    //  and an address per load.  Price: 3 KB per group that its neighbour fetches again, 0.12 of the 4.85 GB per assembly at
+    //  config 5; clamped, the network form spills 37 - 66 registers at seven workgroups per CU.)
     const size_t my0 = (size_t)e0 + w * chunk + lane;
     {
         const uint32_t cmask = gbits ? (0xffffffffu >> gbits) : 0xffffffffu, rshift = 32u - gbits;
