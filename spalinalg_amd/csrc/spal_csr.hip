@@ -1332,6 +1332,41 @@ static int csr_try_row_split(spal_csr *a, bool *did) {
         (void)hipGetLastError();
         return SPAL_OK;
     }
+    // The short part of a skewed matrix is ragged short rows; where its super-tiles are too wide for an LDS window (they went
+    // to the column panels) the column-blocked kernels may be the faster family (power-law rows, columns within +-5000: 93 us
+    // in panels, 73 - 82 us column-blocked) -- or not (uniform rows in a band of 16 384: panels).  Setup time: both are timed
+    // on scratch vectors, the faster stays.
+    if (child->plan.kernel == 2 && child->n_ptiles * 2u > child->plan.nblocks && !child->plan.cblock && child->plan.cblock_user < 0) {
+        (void)cblock_plan(child, true);
+        if (child->plan.cblock) {
+            void *sx = nullptr, *sy = nullptr;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            hipError_t te = dev_alloc(&sx, std::max<uint64_t>(a->ncols, 1) * (size_t)a->elem_size);
+            if (te == hipSuccess) te = dev_alloc(&sy, std::max<uint64_t>(a->nrows, 1) * (size_t)a->elem_size);
+            if (te == hipSuccess) te = hipMemsetAsync(sx, 0, a->ncols * (size_t)a->elem_size, child->stream);
+            if (te == hipSuccess) te = hipEventCreate(&e0);
+            if (te == hipSuccess) te = hipEventCreate(&e1);
+            float ms[2] = {0.f, 0.f};
+            int trc = SPAL_OK;
+            for (int on = 0; on < 2 && te == hipSuccess && trc == SPAL_OK; ++on) {
+                child->plan.cblock_on = on;
+                for (int i = 0; i < 2 && trc == SPAL_OK; ++i) trc = csr_launch(child, sx, sy, child->stream);
+                te = hipEventRecord(e0, child->stream);
+                for (int i = 0; i < 5 && trc == SPAL_OK; ++i) trc = csr_launch(child, sx, sy, child->stream);
+                if (te == hipSuccess) te = hipEventRecord(e1, child->stream);
+                if (te == hipSuccess) te = hipEventSynchronize(e1);
+                if (te == hipSuccess) te = hipEventElapsedTime(&ms[on], e0, e1);
+            }
+            const bool keep = te == hipSuccess && trc == SPAL_OK && ms[1] < ms[0];
+            child->plan.cblock_on = 1;
+            if (!keep) cblock_free(child);
+            child->cblock_us[0] = ms[0] * 200.f; child->cblock_us[1] = ms[1] * 200.f;   // (us per launch: 5 launches)
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            (void)dev_free(sx); (void)dev_free(sy);
+            (void)hipGetLastError();
+        }
+    }
     a->split_short = child;
     a->split_nheavy = n_heavy;
     a->split_nlong = (uint32_t)rows_long.size();
