@@ -652,6 +652,10 @@ __device__ __forceinline__ uint32_t group_lookback(unsigned long long *state, ui
         __hip_atomic_store(&state[grp], (grp ? kGroupOwn : kGroupUpTo) | total, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     if (grp == 0) return 0;
+#ifdef SPAL_COO_FAKE_LOOKBACK   // lab builds: what the kernel costs WITHOUT the wait (wrong offsets, results discarded)
+    if (lane == 0) __hip_atomic_store(&state[grp], kGroupUpTo | (unsigned long long)(grp * 1264u + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return grp * 1264u;
+#endif
     uint32_t mine = 0, spins = 0;                         // lane-local part of the sum
     int64_t base = (int64_t)grp - 1;                      // lane 0 looks at the nearest predecessor
     for (;;) {
@@ -745,6 +749,9 @@ __device__ __forceinline__ void sort_row_in_regs(uint32_t *c1, uint32_t a, uint3
 // every other workgroup's look-back needs those ids' counts, and whoever falls behind by one iteration stalls everyone by
 // one iteration.  One group per workgroup lets the dispatcher start the next group the moment a slot is free; a waiting
 // workgroup holds nothing anybody needs.
+#ifndef SPAL_COO_PRIO
+#define SPAL_COO_PRIO 3   // wave priority of the group kernel's phases before its count is published (0: none); -15 us per assembly
+#endif
 #ifndef SPAL_COO_LB_1536
 #define SPAL_COO_LB_1536 7
 #endif
@@ -798,6 +805,11 @@ __global__ __launch_bounds__(256, CAP == 1536 ? SPAL_COO_LB_1536 : CAP == 2048 ?
 
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
+#if SPAL_COO_PRIO
+    // everything up to the group's published count is what OTHER workgroups wait for in their look-back: those phases run at a
+    // raised wave priority, the stores behind the look-back at the normal one
+    __builtin_amdgcn_s_setprio(SPAL_COO_PRIO);
+#endif
     uint32_t row_len = 0, row_a = 0;      // thread t's row of the group: entries, first place in row order
 #ifdef SPAL_COO_STAMPS
     const uint32_t stamp_slot = blockIdx.x;
@@ -1051,6 +1063,9 @@ __global__ __launch_bounds__(256, CAP == 1536 ? SPAL_COO_LB_1536 : CAP == 2048 ?
             const uint32_t before = group_lookback(state, grp, total, lane, err, spin_bound);
             if (t == 0) { s_base = before; s_total = total; }
         }
+#if SPAL_COO_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();
         SPAL_STAMP(5);
         const uint32_t before = s_base;
