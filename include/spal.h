@@ -387,7 +387,8 @@ int spal_device_synchronize(int device);
  * cache for reuse (bounded by the environment variable SPAL_CACHE_BYTES; default:
  * a quarter of the device's memory, at most half of what was free at first use).
  * spal_cache_trim hands every cached block back to the driver, e.g. before
- * another allocator in the process (torch) needs the memory. */
+ * another allocator in the process (torch) needs the memory -- and the placement
+ * blocks of spal_csr_alloc_vectors that no live handle holds a piece of. */
 int spal_cache_trim(void);
 
 #ifdef __cplusplus

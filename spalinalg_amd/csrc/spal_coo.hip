@@ -29,6 +29,8 @@
 // lane-sequential run summation, which is correct for any input, only slower.
 #include "spal_internal.hpp"
 
+#include <numeric>
+
 namespace spal {
 
 // --------------------------------------------------------------------------
@@ -624,6 +626,9 @@ __global__ __launch_bounds__(256) void groups_check(const uint32_t *__restrict__
 // state[g] of the look-back below: (status << 32) | count, status 0 = nothing yet, 1 = the group's own number of
 // survivors, 2 = survivors of groups 0 ... g inclusive.
 constexpr unsigned long long kGroupOwn = 1ull << 32, kGroupUpTo = 2ull << 32;
+#ifndef SPAL_COO_LBW
+#define SPAL_COO_LBW 1
+#endif
 constexpr uint32_t kLookbackSpins = 1u << 21;   // (seconds: a bound, so that every wave reaches its exit; SPAL_COO_LOOKBACK_SPINS overrides)
 
 // Survivors in all groups before `grp`, for the group that holds `total` of its own: decoupled look-back over the
@@ -647,7 +652,9 @@ constexpr uint32_t kLookbackSpins = 1u << 21;   // (seconds: a bound, so that ev
 // kernel and row scan it replaces, and 1.2 GB less traffic.  Polling 128 or 512 predecessors per round trip is slower
 // (1.86 / 1.98 vs 1.75 ms per assembly), the sleep between polls does not matter (1 ... 64: 1.75 - 1.79 ms).
 __device__ __forceinline__ uint32_t group_lookback(unsigned long long *state, uint32_t grp, uint32_t total,
-                                                   uint32_t lane, uint32_t *err, uint32_t spin_bound) {
+                                                   uint32_t lane, uint32_t *err, uint32_t spin_bound,
+                                                   uint32_t *dbg = nullptr) {
+    constexpr int W = SPAL_COO_LBW;
     if (lane == 0)
         __hip_atomic_store(&state[grp], (grp ? kGroupOwn : kGroupUpTo) | total, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
@@ -659,14 +666,28 @@ __device__ __forceinline__ uint32_t group_lookback(unsigned long long *state, ui
     uint32_t mine = 0, spins = 0;                         // lane-local part of the sum
     int64_t base = (int64_t)grp - 1;                      // lane 0 looks at the nearest predecessor
     for (;;) {
-        const int64_t idx = base - (int64_t)lane;
-        const unsigned long long sv = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                               : kGroupUpTo;   // before group 0: nothing
-        const uint32_t status = (uint32_t)(sv >> 32);
-        const uint64_t missing = __ballot(status == 0), upto = __ballot(status == 2);
-        // the nearest predecessor that knows its inclusive count ends the walk; everyone nearer must have reported
-        const uint64_t need = upto ? ((2ull << __builtin_ctzll(upto)) - 1ull) : ~0ull;
-        if (missing & need) {
+        // one round trip covers W windows of 64 predecessors (nearest first): W loads per lane issued back to back
+        unsigned long long sv[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const int64_t idx = base - (int64_t)lane - 64 * j;
+            sv[j] = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                             : kGroupUpTo;                // before group 0: nothing
+        }
+        uint32_t part = 0;
+        bool wait = false, done = false;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {                     // (all tests wave-uniform)
+            if (wait || done) continue;
+            const uint32_t status = (uint32_t)(sv[j] >> 32);
+            const uint64_t missing = __ballot(status == 0), upto = __ballot(status == 2);
+            // the nearest predecessor that knows its inclusive count ends the walk; everyone nearer must have reported
+            const uint64_t need = upto ? ((2ull << __builtin_ctzll(upto)) - 1ull) : ~0ull;
+            if (missing & need) { wait = true; continue; }
+            if ((need >> lane) & 1ull) part += (uint32_t)sv[j];
+            if (upto) done = true;
+        }
+        if (wait) {
             if (++spins > spin_bound) {
                 if (lane == 0) atomicOr(err, 1u);
                 break;
@@ -674,10 +695,11 @@ __device__ __forceinline__ uint32_t group_lookback(unsigned long long *state, ui
             __builtin_amdgcn_s_sleep(4);
             continue;
         }
-        if ((need >> lane) & 1ull) mine += (uint32_t)sv;
-        if (upto) break;
-        base -= 64;
+        mine += part;
+        if (done) break;
+        base -= 64 * W;
     }
+    if (dbg) { dbg[0] = spins; dbg[1] = (uint32_t)(((int64_t)grp - 1 - base) / (64 * W)) + 1u; }   // (lab builds: polls that waited, windows walked)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mine += (uint32_t)__shfl_xor((int)mine, o, 64);
     if (lane == 0)
@@ -765,7 +787,14 @@ __device__ unsigned long long *g_coo_stamps = nullptr;
 #define SPAL_STAMP(i) do { } while (0)
 #endif
 // state[] tail behind the groups' look-back words: {error flags, fullest group, single ticket, -, tickets[kTicketClasses]}
-constexpr uint32_t kTailWords = 4 + kTicketClasses;
+// The class counters lie kTicketStride words apart: atomics on ONE line are served one after the other whatever their address in
+// the line (87 M/s; eight counters in consecutive words were one hot line -- the 1 792 workgroups of the launch's first round waited
+// 18 us for their ids, and the steady 62 M tickets/s kept that line 70 % busy), counters 256 bytes apart are served side by side.
+#ifndef SPAL_COO_TICKET_STRIDE
+#define SPAL_COO_TICKET_STRIDE 64
+#endif
+constexpr uint32_t kTicketStride = SPAL_COO_TICKET_STRIDE;
+constexpr uint32_t kTailWords = 4 + kTicketClasses * kTicketStride;
 
 // ROWSORT: step 2 by the per-row network and the wave-per-long-row pass (columns below 2^27, rows of at most 256 entries: a
 // group with a longer row raises *err bit 2 and the host runs the kernel again with ROWSORT = false, where every entry
@@ -821,7 +850,7 @@ __global__ __launch_bounds__(256, CAP == 1536 ? SPAL_COO_LB_1536 : CAP == 2048 ?
         if (tickets) {
             if (ticket_classes > 1) {
                 const uint32_t cls = blockIdx.x & (kTicketClasses - 1);
-                id = atomicInc(&tickets[cls], 0xffffffffu) * kTicketClasses + cls;
+                id = atomicInc(&tickets[cls * kTicketStride], 0xffffffffu) * kTicketClasses + cls;
             } else {
                 id = atomicInc(tickets, 0xffffffffu);
             }
@@ -1060,7 +1089,17 @@ __global__ __launch_bounds__(256, CAP == 1536 ? SPAL_COO_LB_1536 : CAP == 2048 ?
             const uint32_t inc = wave_inclusive_scan(c);
             if (t < (uint32_t)(K * 4)) s_wc[t] = inc - c;
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+#ifdef SPAL_COO_STAMPS
+            uint32_t dbg[2] = {0, 0};
+            const uint32_t before = group_lookback(state, grp, total, lane, err, spin_bound, dbg);
+            if (t == 0 && g_coo_stamps) {
+                g_coo_stamps[(size_t)stamp_slot * 16 + 8] = grp;
+                g_coo_stamps[(size_t)stamp_slot * 16 + 9] = dbg[0];
+                g_coo_stamps[(size_t)stamp_slot * 16 + 10] = dbg[1];
+            }
+#else
             const uint32_t before = group_lookback(state, grp, total, lane, err, spin_bound);
+#endif
             if (t == 0) { s_base = before; s_total = total; }
         }
 #if SPAL_COO_PRIO
@@ -1360,6 +1399,17 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
 #undef SPAL_GROUP_KERNEL
             // ids: 8 class counters (default), the single counter of round 3 (SPAL_COO_TICKET=1) or blockIdx (=0)
             uint32_t *d_tickets = ticket_mode == 0 ? nullptr : ticket_mode == 1 ? d_err + 2 : d_err + 4;
+#ifdef SPAL_COO_STAMPS
+            static unsigned long long *d_stamps = nullptr;   // (lab builds: one buffer per process, never freed)
+            static uint32_t stamps_for = 0;
+            if (stamps_for < ngroups) {
+                if (d_stamps) (void)hipFree(d_stamps);
+                SPAL_HIP_TRY(hipMalloc((void **)&d_stamps, (size_t)ngroups * 16 * 8));
+                stamps_for = ngroups;
+                SPAL_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_coo_stamps), &d_stamps, sizeof(d_stamps)));
+            }
+            SPAL_HIP_TRY(hipMemsetAsync(d_stamps, 0, (size_t)ngroups * 16 * 8, st));
+#endif
             hipLaunchKernelGGL(k_sort, dim3(ngroups), dim3(256), 0, st, d_gstart, sb.key[cur], sb.aux[cur],
                                sb.val[cur], nrows, gbits, ngroups, d_state, d_err, d_tickets, ticket_mode == 1 ? 1u : kTicketClasses,
                                spin_bound, rowptr.as<uint32_t>(), ocol.as<uint32_t>(), oval.as<T>(), d_gwin);
@@ -1386,7 +1436,72 @@ static int coo_assemble_t(spal_coo *c, bool by_cols, hipStream_t st, Assembled &
                     fprintf(stderr, "[spal coo stamps] %llu workgroups, kernel %.1f us; mean us per phase:", cnt, (double)(lastt - first) / 100.0);
                     double tot = 0;
                     for (int i = 1; i < 12; ++i) { fprintf(stderr, " %s %.2f,", name[i], sum[i] / cnt / 100.0); tot += sum[i] / cnt / 100.0; }
-                    fprintf(stderr, " residence %.2f\n", tot);
+                    fprintf(stderr, " residence %.2f (= %.0f workgroups in flight on average)\n", tot, tot * (double)cnt / ((double)(lastt - first) / 100.0));
+                    // who waits for whom: time from start to the published count and the wait behind it, by percentile; the wait
+                    // a group cannot avoid is the time until the LAST of its predecessors (by id) has published its count
+                    std::vector<double> pub, wait, spins, wins;
+                    std::vector<unsigned long long> pub_at(ngroups, 0), ready_at(ngroups, 0);
+                    for (uint32_t g = 0; g < ngroups; ++g) {
+                        const unsigned long long *q = &hs[(size_t)g * 16];
+                        if (!q[7] || q[8] >= ngroups) continue;
+                        pub.push_back((double)(q[4] - q[0]) / 100.0);
+                        wait.push_back((double)(q[5] - q[4]) / 100.0);
+                        spins.push_back((double)q[9]);
+                        wins.push_back((double)q[10]);
+                        pub_at[q[8]] = q[4];
+                        ready_at[q[8]] = q[5];
+                    }
+                    double natural = 0, measured = 0;
+                    unsigned long long latest = 0;
+                    for (uint32_t id = 0; id < ngroups; ++id) {
+                        if (!pub_at[id]) continue;
+                        if (latest > pub_at[id]) natural += (double)(latest - pub_at[id]) / 100.0;
+                        measured += (double)(ready_at[id] - pub_at[id]) / 100.0;
+                        latest = std::max(latest, pub_at[id]);
+                    }
+                    {   // which phase the slow groups are slow in: per phase p50 / p99, and the phases' means over the slowest 1 % to publish
+                        std::vector<std::vector<double>> ph(12);
+                        std::vector<std::pair<double, uint32_t>> by_pub;
+                        for (uint32_t g = 0; g < ngroups; ++g) {
+                            const unsigned long long *q = &hs[(size_t)g * 16];
+                            if (!q[7]) continue;
+                            for (int i = 1; i < 12; ++i) ph[i].push_back((double)(q[order[i]] - q[order[i - 1]]) / 100.0);
+                            by_pub.push_back({(double)(q[4] - q[0]) / 100.0, g});
+                        }
+                        fprintf(stderr, "[spal coo stamps] p50 / p99 per phase:");
+                        for (int i = 1; i < 12; ++i) {
+                            std::sort(ph[i].begin(), ph[i].end());
+                            fprintf(stderr, " %s %.1f / %.1f,", name[i], ph[i][ph[i].size() / 2], ph[i][(size_t)(0.99 * (ph[i].size() - 1))]);
+                        }
+                        std::sort(by_pub.begin(), by_pub.end());
+                        const size_t n1 = std::max<size_t>(by_pub.size() / 100, 1);
+                        double slow[12] = {0};
+                        unsigned long long t_lo = ~0ull, t_hi = 0;
+                        for (size_t k = by_pub.size() - n1; k < by_pub.size(); ++k) {
+                            const unsigned long long *q = &hs[(size_t)by_pub[k].second * 16];
+                            for (int i = 1; i < 12; ++i) slow[i] += (double)(q[order[i]] - q[order[i - 1]]) / 100.0 / (double)n1;
+                            t_lo = std::min(t_lo, q[0]); t_hi = std::max(t_hi, q[0]);
+                        }
+                        fprintf(stderr, "\n[spal coo stamps] the slowest 1 %% to publish (started between %.1f and %.1f us of the kernel), mean us per phase:",
+                                (double)(t_lo - first) / 100.0, (double)(t_hi - first) / 100.0);
+                        for (int i = 1; i < 12; ++i) fprintf(stderr, " %s %.1f,", name[i], slow[i]);
+                        // start times of the slowest 1 % by decile of the kernel
+                        int dec[10] = {0};
+                        for (size_t k = by_pub.size() - n1; k < by_pub.size(); ++k) {
+                            const unsigned long long *q = &hs[(size_t)by_pub[k].second * 16];
+                            dec[std::min<int>(9, (int)(10.0 * (double)(q[0] - first) / (double)(lastt - first)))]++;
+                        }
+                        fprintf(stderr, "\n[spal coo stamps] their starts by tenth of the kernel:");
+                        for (int i = 0; i < 10; ++i) fprintf(stderr, " %d", dec[i]);
+                        fprintf(stderr, "\n");
+                    }
+                    auto pct = [](std::vector<double> &v, double p) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[(size_t)(p * (v.size() - 1))]; };
+                    fprintf(stderr, "[spal coo stamps] start -> count published us: p50 %.1f p90 %.1f p99 %.1f max %.1f; look-back us: p50 %.1f p90 %.1f p99 %.1f max %.1f; "
+                            "polls that waited: mean %.1f p99 %.0f; windows walked: mean %.2f p99 %.0f max %.0f; mean wait %.2f us of which until the last predecessor had published %.2f us\n",
+                            pct(pub, 0.5), pct(pub, 0.9), pct(pub, 0.99), pct(pub, 1.0), pct(wait, 0.5), pct(wait, 0.9), pct(wait, 0.99), pct(wait, 1.0),
+                            std::accumulate(spins.begin(), spins.end(), 0.0) / std::max<size_t>(spins.size(), 1), pct(spins, 0.99),
+                            std::accumulate(wins.begin(), wins.end(), 0.0) / std::max<size_t>(wins.size(), 1), pct(wins, 0.99), pct(wins, 1.0),
+                            measured / cnt, natural / cnt);
                 }
             }
 #endif

@@ -146,6 +146,28 @@ size_t place_free_bytes(int device) {
     }
     return n;
 }
+// placement blocks nobody holds a piece of go back to the driver (spal_cache_trim); a device left without any walks again
+void place_trim() {
+    PlaceArena &a = place_arena();
+    std::lock_guard<std::mutex> lock(a.mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < 64; ++d) {
+        auto &v = a.blocks[d];
+        bool any = false;
+        for (size_t i = 0; i < v.size();) {
+            if (v[i].used.empty()) {
+                if (!any) { (void)hipSetDevice(d); any = true; }
+                (void)hipFree(v[i].base);
+                v.erase(v.begin() + (long)i);
+            } else {
+                ++i;
+            }
+        }
+        if (v.empty()) a.walked[d] = false;
+    }
+    (void)hipSetDevice(cur);
+}
 bool place_walked(int device) {
     PlaceArena &a = place_arena();
     std::lock_guard<std::mutex> lock(a.mu);
@@ -2578,6 +2600,7 @@ int spal_memcpy_d2h(int device, void *dst_host, const void *src_dev, size_t byte
 }
 int spal_cache_trim(void) {
     dev_cache_trim();
+    place_trim();
     return SPAL_OK;
 }
 int spal_device_synchronize(int device) {

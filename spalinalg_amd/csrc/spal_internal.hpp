@@ -73,6 +73,7 @@ void *place_alloc(int device, int index, size_t bytes);        // a piece of blo
 void place_free(int device, void *ptr);                        // a piece (nullptr is fine)
 void place_adopt(int device, void *base, size_t size);         // a hipMalloc'ed block becomes a placement block
 size_t place_free_bytes(int device);                           // what the retained blocks still have to give
+void place_trim();                                             // blocks without pieces back to the driver
 bool place_walked(int device);
 void place_set_walked(int device);
 hipError_t dev_alloc(void **ptr, size_t bytes);   // on the current device

@@ -1121,6 +1121,13 @@ def test_handle_owned_vectors(oracle):
     del x2, y2
     dev2.close()
     assert dev.describe()["placement_free_bytes"] >= free_with_both + 2 * n * 8
+    # cache_trim gives back the kept blocks nobody holds a piece of; the block under this handle's vectors stays
+    sp.cache_trim()
+    assert dev.describe()["placement_blocks"] == 1
+    y.fill_(float("nan"))
+    dev.spmv_torch(x, out=y)
+    torch.cuda.synchronize()
+    assert np.array_equal(y.cpu().numpy(), oracle.csr_spmv(rp, ci, va, xh))
 
 
 def test_device_copy_is_a_handle_of_its_own(oracle):
