@@ -12,6 +12,8 @@
 //   direct : every lane stores its entry straight to its destination (what a wide digit amounts to anyway);
 //   staged : the tile is first permuted in LDS into digit order and copied out linearly, so a digit's run leaves the
 //            workgroup as consecutive lanes (radix_scatter's form; runs of TILE >> BITS entries).
+//   staged2: the same in two rounds through HALF the LDS -- keys and aux words first, the values behind them in the same space --
+//            so that a tile of 8192 entries (runs twice as long) still leaves room for two workgroups per CU.
 // Build: hipcc -O3 --offload-arch=gfx950 tools/micro/wide_scatter.hip -o tools/micro/wide_scatter
 // Run:   tools/micro/wide_scatter [entries]        (prints one line per (BITS, TILE, form): us per pass, GB/s of 32 B/entry)
 //        rocprofv3 --pmc WRITE_SIZE FETCH_SIZE ... -- tools/micro/wide_scatter   (kernel names carry BITS / TILE / form)
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(kThreads) void make_keys(uint32_t *key, uint32_t *a
     }
 }
 
-template <int BITS, int TILE, bool STAGED>
+template <int BITS, int TILE, int STAGED>
 __global__ __launch_bounds__(kThreads) void wide_scatter(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ ain,
                                                           const double *__restrict__ vin, uint32_t *__restrict__ kout,
                                                           uint32_t *__restrict__ aout, double *__restrict__ vout,
@@ -72,7 +74,29 @@ __global__ __launch_bounds__(kThreads) void wide_scatter(const uint32_t *__restr
         const uint64_t i = t0 + (uint64_t)j * kThreads + threadIdx.x;
         k[j] = kin[i]; a[j] = ain[i]; v[j] = vin[i];
     }
-    if (STAGED) {
+    if (STAGED == 2) {
+        uint32_t *s_key = reinterpret_cast<uint32_t *>(smem), *s_aux = s_key + TILE;
+        double *s_val = reinterpret_cast<double *>(smem);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) { s_key[k[j]] = k[j]; s_aux[k[j]] = a[j]; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint32_t lp = j * kThreads + threadIdx.x;
+            const uint64_t gp = (uint64_t)(lp / PER) * bucket + (uint64_t)tile * PER + (lp % PER);
+            kout[gp] = s_key[lp]; aout[gp] = s_aux[lp];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) s_val[k[j]] = v[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint32_t lp = j * kThreads + threadIdx.x;
+            const uint64_t gp = (uint64_t)(lp / PER) * bucket + (uint64_t)tile * PER + (lp % PER);
+            vout[gp] = s_val[lp];
+        }
+    } else if (STAGED) {
         double *s_val = reinterpret_cast<double *>(smem);
         uint32_t *s_key = reinterpret_cast<uint32_t *>(s_val + TILE), *s_aux = s_key + TILE;
 #pragma unroll
@@ -98,10 +122,10 @@ struct Buffers {
     double *vin, *vout;
 };
 
-template <int BITS, int TILE, bool STAGED>
+template <int BITS, int TILE, int STAGED>
 static void run(const Buffers &b, uint64_t n, int reps) {
     const uint32_t ntiles = (uint32_t)(n / TILE), per_xcd = (ntiles + 7) / 8;
-    const size_t lds = STAGED ? (size_t)TILE * 16 : 0;
+    const size_t lds = STAGED == 2 ? (size_t)TILE * 8 : STAGED ? (size_t)TILE * 16 : 0;
     auto kern = wide_scatter<BITS, TILE, STAGED>;
     if (lds > 48 * 1024) CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((make_keys<TILE>), dim3(ntiles), dim3(kThreads), 0, 0, b.kin, b.ain, b.vin, ntiles);
@@ -130,8 +154,8 @@ static void run(const Buffers &b, uint64_t n, int reps) {
         ok = ko[i] / PER == digit && ao[i] / TILE == tile;
     }
     const double us = ms * 1e3 / reps, gb = (double)used * 32.0 / 1e9;
-    printf("bits %2d  tile %5d  %-6s  runs of %4u entries  %8.1f us per pass  %7.1f GB/s (16 B read + 16 B written per entry)  %s\n", BITS,
-           TILE, STAGED ? "staged" : "direct", PER, us, gb / (us * 1e-6) , ok ? "ok" : "WRONG ORDER");
+    printf("bits %2d  tile %5d  %-7s  runs of %4u entries  %8.1f us per pass  %7.1f GB/s (16 B read + 16 B written per entry)  %s\n", BITS,
+           TILE, STAGED == 2 ? "staged2" : STAGED ? "staged" : "direct", PER, us, gb / (us * 1e-6) , ok ? "ok" : "WRONG ORDER");
     fflush(stdout);
     CHECK(hipEventDestroy(e0));
     CHECK(hipEventDestroy(e1));
@@ -145,18 +169,25 @@ int main(int argc, char **argv) {
     CHECK(hipMalloc((void **)&b.kin, n * 4)); CHECK(hipMalloc((void **)&b.ain, n * 4)); CHECK(hipMalloc((void **)&b.vin, n * 8));
     CHECK(hipMalloc((void **)&b.kout, n * 4)); CHECK(hipMalloc((void **)&b.aout, n * 4)); CHECK(hipMalloc((void **)&b.vout, n * 8));
     printf("# %llu entries, %d timed passes each; XCD-contiguous tiles\n", (unsigned long long)n, reps);
-    run<8, 4096, true>(b, n, reps);
-    run<8, 4096, false>(b, n, reps);
-    run<10, 4096, true>(b, n, reps);
-    run<10, 4096, false>(b, n, reps);
-    run<11, 4096, true>(b, n, reps);
-    run<11, 4096, false>(b, n, reps);
-    run<12, 4096, true>(b, n, reps);
-    run<12, 4096, false>(b, n, reps);
-    run<11, 8192, true>(b, n, reps);
-    run<12, 8192, true>(b, n, reps);
-    run<12, 8192, false>(b, n, reps);
-    run<13, 8192, true>(b, n, reps);
-    run<13, 8192, false>(b, n, reps);
+    if (argc > 2) {   // round 4, late: longer runs for the 8-bit digit
+        run<8, 4096, 1>(b, n, reps);
+        run<8, 4096, 2>(b, n, reps);
+        run<8, 8192, 1>(b, n, reps);
+        run<8, 8192, 2>(b, n, reps);
+        return 0;
+    }
+    run<8, 4096, 1>(b, n, reps);
+    run<8, 4096, 0>(b, n, reps);
+    run<10, 4096, 1>(b, n, reps);
+    run<10, 4096, 0>(b, n, reps);
+    run<11, 4096, 1>(b, n, reps);
+    run<11, 4096, 0>(b, n, reps);
+    run<12, 4096, 1>(b, n, reps);
+    run<12, 4096, 0>(b, n, reps);
+    run<11, 8192, 1>(b, n, reps);
+    run<12, 8192, 1>(b, n, reps);
+    run<12, 8192, 0>(b, n, reps);
+    run<13, 8192, 1>(b, n, reps);
+    run<13, 8192, 0>(b, n, reps);
     return 0;
 }
