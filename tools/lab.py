@@ -1193,6 +1193,10 @@ def powerlaw():
         rng = np.random.default_rng(5)
         n = 2_000_000
         pl = np.minimum((rng.pareto(1.6, n) * 6 + 1).astype(np.int64), 5000)
+        if "sorted" in sys.argv[1:]:   # the same rows, ordered by length inside every block of 1024: what a permuted copy would see
+            nb = n // 1024 * 1024
+            pl[:nb] = -np.sort(-pl[:nb].reshape(-1, 1024), axis=1).reshape(-1)
+            pl[nb:] = -np.sort(-pl[nb:])
         cases = [("local +-5000", lambda r, p, g: np.clip(r - 5000 + g.integers(0, 10000, r.size), 0, n - 1)),
                  ("uniform", lambda r, p, g: g.integers(0, n, r.size))]
         only = [a for a in sys.argv[1:] if a in ("local", "uniform")]
@@ -1209,6 +1213,8 @@ def powerlaw():
             print(f"power-law rows (mean {pl.mean():.1f}, max {pl.max()}), columns {name}: nnz {nnz}, floor {B/8e12*1e6:.1f} us", flush=True)
             variants = ([("row_split", -1)], [("row_split", 0)], [("row_split", -1), ("row_split_threshold", 64)],
                         [("row_split", -1), ("row_split_threshold", 256)]) if quick else None
+            if "sorted" in sys.argv[1:]:
+                variants = ([("row_split", 1)], [("row_split", 1), ("row_split_threshold", 64)], [("row_split", 1), ("row_split_threshold", 32)])
             for opts in variants or ([("kernel", 0)], [("stream_row_max", 1024)], [("stream_row_max", 256)], [("stream_row_max", 128)],
                          [("stream_row_max", 64)], [("stream_row_max", 32)],
                          [("stream_row_max", 128), ("rows_per_tile", 64)], [("stream_row_max", 128), ("rows_per_tile", 16)],
