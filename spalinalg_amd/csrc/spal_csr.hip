@@ -976,6 +976,10 @@ int csr_launch(spal_csr *a, const void *x_dev, void *y_dev, hipStream_t stream) 
             SPAL_TRY(csr_launch(a->parts[b], x_dev, (char *)y_dev + a->part_row0[b] * (uint64_t)a->elem_size, stream));
         return SPAL_OK;
     }
+    if (a->bw_on) {   // skewed rows, columns near the rows: the block-window kernel (spal_csr_blockwin.hip)
+        SPAL_HIP_TRY(blockwin_launch(a, x_dev, y_dev, stream));
+        return SPAL_OK;
+    }
     if (a->split_short) {   // row split: the short rows' handle writes every row of y, the long rows are then overwritten
         SPAL_TRY(csr_launch(a->split_short, x_dev, y_dev, stream));
         const uint32_t grid = a->split_nheavy + (a->split_nlong - a->split_nheavy + kStreamWaves - 1) / kStreamWaves;
@@ -1397,12 +1401,66 @@ static int csr_try_row_split(spal_csr *a, bool *did) {
     return SPAL_OK;
 }
 
+// Skewed matrices whose columns stay near their rows: the block-window kernel against the row split just built, both timed on
+// scratch vectors (setup time); the faster form stays, the other is freed.
+static int csr_blockwin_or_split(spal_csr *a) {
+    if (blockwin_plan(a) != SPAL_OK || !a->bw_rows) { blockwin_free(a); (void)hipGetLastError(); return SPAL_OK; }   // (optional form)
+    void *sx = nullptr, *sy = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t te = dev_alloc(&sx, std::max<uint64_t>(a->ncols, 2) * (size_t)a->elem_size);
+    if (te == hipSuccess) te = dev_alloc(&sy, std::max<uint64_t>(a->nrows, 1) * (size_t)a->elem_size);
+    if (te == hipSuccess) te = hipMemsetAsync(sx, 0, a->ncols * (size_t)a->elem_size, a->stream);
+    if (te == hipSuccess) te = hipEventCreate(&e0);
+    if (te == hipSuccess) te = hipEventCreate(&e1);
+    float ms[2] = {0.f, 0.f};
+    int trc = SPAL_OK;
+    for (int on = 0; on < 2 && te == hipSuccess && trc == SPAL_OK; ++on) {
+        a->bw_on = on;
+        for (int i = 0; i < 2 && trc == SPAL_OK; ++i) trc = csr_launch(a, sx, sy, a->stream);
+        te = hipEventRecord(e0, a->stream);
+        for (int i = 0; i < 5 && trc == SPAL_OK; ++i) trc = csr_launch(a, sx, sy, a->stream);
+        if (te == hipSuccess) te = hipEventRecord(e1, a->stream);
+        if (te == hipSuccess) te = hipEventSynchronize(e1);
+        if (te == hipSuccess) te = hipEventElapsedTime(&ms[on], e0, e1);
+    }
+    const bool keep = te == hipSuccess && trc == SPAL_OK && ms[1] < ms[0];
+    const float us0 = ms[0] * 200.f, us1 = ms[1] * 200.f;   // (us per product: 5 launches)
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)dev_free(sx); (void)dev_free(sy);
+    (void)hipGetLastError();
+    if (keep) {
+        a->bw_on = 1;
+        if (a->split_short) { csr_free(a->split_short); a->split_short = nullptr; }
+        (void)dev_free(a->d_split_rows); a->d_split_rows = nullptr;
+        a->split_nlong = 0; a->split_nheavy = 0; a->split_long_entries = 0;
+        a->plan.kernel = 4;
+    } else {
+        blockwin_free(a);
+    }
+    a->bw_us[0] = us0; a->bw_us[1] = us1;
+    return SPAL_OK;
+}
+
 int csr_plan_build(spal_csr *a) {
     SPAL_TRY(csr_fetch_group_windows(a));
+    blockwin_free(a);
+    a->bw_us[0] = a->bw_us[1] = 0.f;
+    if (a->plan.blockwin == 1 && !a->split_child) {   // asked for by name (tests): whenever the windows fit
+        if (a->split_short) { csr_free(a->split_short); a->split_short = nullptr; }
+        (void)dev_free(a->d_split_rows); a->d_split_rows = nullptr;
+        a->split_nlong = 0;
+        SPAL_TRY(blockwin_plan(a));
+        if (a->bw_rows) { a->bw_on = 1; a->plan.kernel = 4; return SPAL_OK; }
+    }
     {
         bool did = false;
         SPAL_TRY(csr_try_row_split(a, &did));
-        if (did) { a->plan.kernel = 3; return SPAL_OK; }   // ("split": the products run through the short part's handle)
+        if (did) {   // ("split": the products run through the short part's handle -- unless the block-window kernel beats it)
+            a->plan.kernel = 3;
+            if (a->plan.blockwin != 0) SPAL_TRY(csr_blockwin_or_split(a));
+            return SPAL_OK;
+        }
     }
     CsrPlan &p = a->plan;
     const double mean = a->nrows ? (double)a->nnz / (double)a->nrows : 0.0;
@@ -1712,6 +1770,7 @@ static void csr_free(spal_csr *a) {
     (void)dev_free(a->d_pwin);
     if (a->split_short) csr_free(a->split_short);
     (void)dev_free(a->d_split_rows);
+    blockwin_free(a);
     if (a->d_vec_block && a->vec_block_owned) (void)hipFree(a->d_vec_block);
     else place_free(a->device, a->d_vec_block);
     (void)dev_free(a->d_win_groups);
@@ -1974,6 +2033,7 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
     DeviceGuard guard(a->device);
     if (guard.status != SPAL_OK) return guard.status;
     SPAL_TRY(csr_ensure_plan(a, nullptr, false));
+    if (a->bw_on) return SPAL_OK;   // (nothing to tune: one kernel, its geometry fixed by the windows)
     if (a->split_short) return csr_autotune<T>(a->split_short, x_dev, y_dev, stream, iters);   // (the short part's kernels; y is scratch here)
     std::lock_guard<std::mutex> lock(a->mu);
     CsrPlan &p = a->plan;
@@ -2165,6 +2225,14 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
     DeviceGuard guard(a->device);
     if (guard.status != SPAL_OK) return guard.status;
     SPAL_TRY(csr_ensure_plan(a, nullptr, false));
+    if (!strcmp(key, "blockwin")) {
+        // the block-window kernel (spal_csr_blockwin.hip): -1 = timed against the row split where that is built, 0 = never,
+        // 1 = whenever the matrix's windows fit LDS
+        if (value < -1 || value > 1) return fail(SPAL_ERR_INVALID_ARGUMENT, "blockwin must be -1 (auto), 0 or 1");
+        std::lock_guard<std::mutex> lock(a->mu);
+        a->plan.blockwin = (int)value;
+        return a->split_child ? SPAL_OK : csr_plan_build(a);
+    }
     if (!strcmp(key, "row_split") || !strcmp(key, "row_split_threshold")) {
         // skewed row lengths: rows above the threshold multiplied apart from the rest (csr_try_row_split): -1 = when they keep
         // a tenth of the 64-row tiles from streaming, 0 = never, 1 = whenever there is such a row
@@ -2179,6 +2247,7 @@ int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value) {
         return a->split_child ? SPAL_OK : csr_plan_build(a);
     }
     if (a->split_short) return spal_csr_set_option(a->split_short, key, value);   // every other option concerns the short part's kernels
+    if (a->bw_on) return SPAL_OK;   // (the block-window kernel has no options of its own; the stream kernels' do not concern it)
     std::lock_guard<std::mutex> lock(a->mu);
     CsrPlan saved = a->plan;
     CsrPlan &p = a->plan;
@@ -2521,6 +2590,15 @@ int spal_csr_describe(spal_csr_t a, char *buf, size_t buf_len) {
         DeviceGuard guard(a->device);
         if (guard.status != SPAL_OK) return guard.status;
         SPAL_TRY(csr_ensure_plan(a, nullptr, false));
+    }
+    if (a->bw_on) {
+        snprintf(buf, buf_len,
+                 "{\"format\": \"csr\", \"dtype\": \"%s\", \"nrows\": %llu, \"ncols\": %llu, \"nnz\": %llu, \"kernel\": \"blockwin\", "
+                 "\"index_bits\": 32, \"block_rows\": %u, \"blocks\": %u, \"window_columns\": %u, \"threads_per_block\": 1024, "
+                 "\"pass_entries\": 4096, \"thread_rows_up_to\": 32, \"setup_us\": [%.1f, %.1f]}",
+                 a->elem_size == 8 ? "f64" : "f32", (unsigned long long)a->nrows, (unsigned long long)a->ncols,
+                 (unsigned long long)a->nnz, a->bw_rows, a->bw_blocks, a->bw_cols, a->bw_us[0], a->bw_us[1]);
+        return SPAL_OK;
     }
     if (a->split_short) {   // row split: the whole, what was split off, and the short part's plan
         std::vector<char> part(buf_len);

@@ -165,6 +165,7 @@ struct CsrPlan {
     int slide_fill_ok = 1;   // the sliding kernel's tiles are full enough for its fixed count of loads per tile (csr_slide plan)
     int slide_fill_user = -1; // -1 = by the tiles' average fill, 1 = "slide_on" was asked for by name
     int slide_even = 1;      // option "slide_even": one run per workgroup -> the XCD's steps split evenly over all its workgroups
+    int blockwin = -1;       // option "blockwin": -1 = timed against the row split where that is built, 0 never, 1 whenever the windows fit (tests)
     int row_split = -1;      // option "row_split": -1 = when long rows keep a tenth of the 64-row tiles from streaming, 0 never, 1 always (tests)
     int split_threshold = 128;   // option "row_split_threshold": rows above it are "long"
     int place_tries = 8;     // autotune: blocks of 1 GiB the 16-bit columns are tried in, at most (see csr_autotune)
@@ -230,6 +231,11 @@ struct spal_csr {
     uint32_t split_nlong = 0, split_nheavy = 0;   // listed rows (longest first); the first split_nheavy hold more than 1024 entries
     uint64_t split_long_entries = 0;
     int split_child = 0;           // this handle IS the short part of a split (never splits again)
+    // BLOCK WINDOW kernel (spal_csr_blockwin.hip): {first column, columns} of every block of bw_rows rows; bw_on: the products run it
+    uint2 *d_bwin = nullptr;
+    uint32_t bw_blocks = 0, bw_rows = 0, bw_cols = 0;
+    int bw_on = 0;
+    float bw_us[2] = {0.f, 0.f};   // setup: per product {what it was timed against, the block-window kernel}
     int plan_pending = 0;          // a device-assembled handle: the product kernels' plan is built by whoever needs it first (csr_ensure_plan)
     int cblock_lazy = 0;           // build the tiled copy with the first product, not with the plan (csr_adopt_device)
     int cblock_failed = 0;         // building it failed (out of memory, ...): the stream kernels run instead
@@ -364,6 +370,10 @@ hipError_t launch_csc_rowtiles(const spal_csc *a, const void *x, void *y, hipStr
 int cblock_plan(spal_csr *a, bool force);
 void cblock_free(spal_csr *a);
 hipError_t launch_cblock(const spal_csr *a, const void *x, void *y, hipStream_t st);
+// spal_csr_blockwin.hip: skewed row lengths with columns near the rows -- entries streamed, one LDS window of x per row block
+int blockwin_plan(spal_csr *a);        // measures the windows; a->bw_rows != 0 when the matrix fits the kernel
+void blockwin_free(spal_csr *a);
+hipError_t blockwin_launch(const spal_csr *a, const void *x, void *y, hipStream_t st);
 // builds a handle around device arrays it takes ownership of (used by the COO
 // assembly, which produces CSR directly on the device)
 // (cap_entries = allocated entries of d_colind / d_values; re-allocated with

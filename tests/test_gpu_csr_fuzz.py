@@ -76,6 +76,13 @@ def test_random_matrices_all_planner_paths(oracle, seed):
     dev = sp.CsrMatrix(n, ncols, rp, ci, va).device()
     d = dev.describe()
     assert_spmv_close(dev.spmv(x), y_ref, bound, TOL[va.dtype])
+    if d["kernel"] == "blockwin":       # skewed rows near the diagonal: the block-window kernel won against the split at setup
+        assert d["setup_us"][1] < d["setup_us"][0], d
+        dev.set_option("blockwin", 0)
+        d = dev.describe()
+        assert d["kernel"] == "split", d
+        assert_spmv_close(dev.spmv(x), y_ref, bound, TOL[va.dtype])
+    dev.set_option("blockwin", 0)       # (the paths below are the split's and the one-handle kernels')
     if d["kernel"] == "split":          # skewed rows: the planner split the long rows off (round 4); the rest of this test
         assert d["split_long_rows"] > 0 and d["short_part"]["nnz"] + d["split_long_entries"] == int(rp[-1]), d
         dev.set_option("row_split", 0)  # drives the one-handle paths
@@ -114,3 +121,13 @@ def test_random_matrices_all_planner_paths(oracle, seed):
         if (lens > d.get("split_threshold", 1 << 30)).any() and d["kernel"] == "split":
             assert d["split_long_rows"] == int((lens > d["split_threshold"]).sum()), d
         assert_spmv_close(dev.spmv(x), y_ref, bound, TOL[va.dtype])
+        # ... and the block-window kernel forced on whatever this is: where the windows fit LDS, rows of at most 32 entries keep
+        # the reference's bits (one thread, left to right, across pass boundaries), longer rows are wave sums
+        dev.set_option("row_split", -1)
+        dev.set_option("blockwin", 1)
+        d = dev.describe()
+        yb = dev.spmv(x)
+        assert_spmv_close(yb, y_ref, bound, TOL[va.dtype])
+        if d["kernel"] == "blockwin":
+            bits = np.uint64 if dtype == np.float64 else np.uint32
+            assert np.array_equal(yb[lens <= 32].view(bits), y_ref[lens <= 32].view(bits)), d

@@ -1130,6 +1130,77 @@ def test_handle_owned_vectors(oracle):
     assert np.array_equal(y.cpu().numpy(), oracle.csr_spmv(rp, ci, va, xh))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_block_window_kernel_on_power_law_rows(oracle, dtype):
+    """Skewed row lengths with columns near the rows (round 4, late): entries streamed in passes, one LDS window of x per row
+    block, rows of at most 32 entries summed by one thread in the reference's order (bit for bit, also across a pass boundary),
+    longer rows by a wave (1e-10 / 1e-4).  Forced by name, then chosen -- or not -- by time against the row split."""
+    rng = np.random.default_rng(12)
+    n = 300_001                                     # (the last block is a partial one)
+    lens = np.minimum((rng.pareto(1.6, n) * 6 + 1).astype(np.int64), 5000)
+    lens[:6] = (0, 9000, 33, 32, 0, 1)             # a row across three passes, the two sides of the thread / wave limit, empty rows
+    lens[700:1300] = 0                              # more than a block's unit of empty rows in a run
+    lens[-3:] = (0, 40, 0)
+    rows = np.repeat(np.arange(n, dtype=np.int64), lens)
+    cols = np.clip(rows - 5000 + rng.integers(0, 10000, rows.size), 0, n - 1)
+    key = np.unique(rows * n + cols)
+    r2, c2 = key // n, key % n
+    rp = np.concatenate([[0], np.cumsum(np.bincount(r2, minlength=n))]).astype(np.uint64)
+    ci, va = c2.astype(np.uint64), rng.uniform(-1, 1, c2.size).astype(dtype)
+    x = rng.uniform(-1, 1, n).astype(dtype)
+    y_ref = oracle.csr_spmv(rp, ci, va, x)
+    bound = oracle.csr_abs_bound(rp, ci, va.astype(np.float64), x.astype(np.float64))
+    tol = 1e-10 if dtype == np.float64 else 1e-4
+    bits = np.uint64 if dtype == np.float64 else np.uint32
+    rl = np.diff(rp.astype(np.int64))
+    dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    dev.set_option("blockwin", 1)
+    d = dev.describe()
+    assert d["kernel"] == "blockwin" and d["block_rows"] in (512, 1024, 2048, 4096) and d["window_columns"] % 256 == 0, d
+    assert d["blocks"] == -(-n // d["block_rows"]), d
+    y = dev.spmv(x)
+    assert_spmv_close(y, y_ref, bound, tol)
+    thread_rows = rl <= 32
+    assert np.array_equal(y[thread_rows].view(bits), y_ref[thread_rows].view(bits))    # the reference's order of additions
+    assert np.all(y[rl == 0] == 0)
+    # two streams at once: the kernel keeps nothing on the handle
+    import torch
+    xt = torch.from_numpy(x).cuda()
+    ys = [torch.full((n,), float("nan"), dtype=xt.dtype, device="cuda") for _ in range(2)]
+    st = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    for _ in range(3):
+        for k in range(2):
+            dev.spmv_dev(xt.data_ptr(), ys[k].data_ptr(), st[k])
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert np.array_equal(ys[k].cpu().numpy().view(bits), y.view(bits))
+    # an x that is only 8-byte aligned takes the scalar staging loop
+    if dtype == np.float64:
+        xo = torch.empty(n + 1, dtype=torch.float64, device="cuda")[1:]
+        xo.copy_(xt)
+        yo = torch.empty(n, dtype=torch.float64, device="cuda")
+        dev.spmv_dev(xo.data_ptr(), yo.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(yo.cpu().numpy().view(bits), y.view(bits))
+    # auto: timed against the row split at setup, the faster of the two stays and says what both took
+    dev.set_option("blockwin", -1)
+    da = dev.describe()
+    assert da["kernel"] in ("blockwin", "split"), da
+    if da["kernel"] == "blockwin":
+        assert 0 < da["setup_us"][1] < da["setup_us"][0], da
+    assert_spmv_close(dev.spmv(x), y_ref, bound, tol)
+    dev.set_option("blockwin", 0)
+    assert dev.describe()["kernel"] == "split"
+    # columns anywhere: no window fits, the request by name falls back to what the plan would have run
+    ci2 = np.sort(rng.integers(0, n, size=(2000, 8)), axis=1)
+    ci2 += np.arange(8)                              # (strictly ascending inside a row)
+    rp2 = (np.arange(2001) * 8).astype(np.uint64)
+    far = sp.CsrMatrix(2000, n + 8, rp2, ci2.reshape(-1).astype(np.uint64), rng.uniform(-1, 1, 16000).astype(dtype)).device()
+    far.set_option("blockwin", 1)
+    assert far.describe()["kernel"] != "blockwin"
+
+
 def test_device_copy_is_a_handle_of_its_own(oracle):
     """`device()` caches ONE handle per matrix and device; `device_copy()` uploads again -- what a benchmark rotates its
     launches over, so that a matrix below the Infinity Cache's 256 MB is not served from it (bench.py, configs 2 and 4)."""
@@ -1167,6 +1238,7 @@ def test_row_split_on_power_law_rows(oracle, dtype):
     bound = oracle.csr_abs_bound(rp, ci, va.astype(np.float64), x.astype(np.float64))
     tol = 1e-10 if dtype == np.float64 else 1e-4
     dev = sp.CsrMatrix(n, n, rp, ci, va).device()
+    dev.set_option("blockwin", 0)          # (the block-window kernel may beat the split at setup: its own test below)
     d = dev.describe()
     rl = np.diff(rp.astype(np.int64))
     assert d["kernel"] == "split" and d["split_threshold"] == 128 and d["split_long_rows"] == int((rl > 128).sum()), d

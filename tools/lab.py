@@ -1211,7 +1211,8 @@ def powerlaw():
             x = torch.from_numpy(synth.vector(n)).cuda()
             y = torch.empty(n, dtype=torch.float64, device="cuda")
             print(f"power-law rows (mean {pl.mean():.1f}, max {pl.max()}), columns {name}: nnz {nnz}, floor {B/8e12*1e6:.1f} us", flush=True)
-            variants = ([("row_split", -1)], [("row_split", 0)], [("row_split", -1), ("row_split_threshold", 64)],
+            variants = ([("blockwin", 1)], [("blockwin", -1)], [("blockwin", 0), ("row_split", -1)], [("row_split", 0)],
+                        [("row_split", -1), ("row_split_threshold", 64)],
                         [("row_split", -1), ("row_split_threshold", 256)]) if quick else None
             if "sorted" in sys.argv[1:]:
                 variants = ([("row_split", 1)], [("row_split", 1), ("row_split_threshold", 64)], [("row_split", 1), ("row_split_threshold", 32)])
@@ -1224,6 +1225,12 @@ def powerlaw():
                     dev.set_option(k, v)
                 for pers in (0, 1):
                     d = dev.describe()
+                    if d["kernel"] == "blockwin":
+                        if not pers:
+                            t = timeit(lambda: dev.spmv_torch(x, out=y))
+                            print(f"  {str(dict(opts)):70s}        : {t*1e3:8.1f} us = {100*B/(t*1e-3)/8e12:5.1f} %  [blockwin rows={d['block_rows']} "
+                                  f"window={d['window_columns']} setup_us={d['setup_us']}]", flush=True)
+                        continue
                     split = d["kernel"] == "split"
                     if split:
                         d = d["short_part"]
