@@ -17,7 +17,10 @@
 //     bit for bit; a longer row by a wave (strided partial sums, a shuffle tree: 1e-10), carried across passes the same way.
 // One row is open at the end of a pass at most; its running sum waits in one of two carry slots (by pass parity).
 // Chosen at setup by time against the row split (spal_csr.hip: csr_plan_build); option "blockwin" -1 / 0 / 1.
+#include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <vector>
 
 #include "spal_internal.hpp"
 
@@ -28,12 +31,15 @@ constexpr uint32_t kBwPass = 4096;     // entries per pass
 constexpr uint32_t kBwItems = kBwPass / kBwThreads;
 constexpr uint32_t kBwShort = 32;      // rows up to this many entries are summed by one thread, in the reference's order
 constexpr uint32_t kBwLongCap = kBwPass / (kBwShort + 1) + 4;   // long rows a pass can touch
+constexpr uint32_t kBwHeavy = 512;     // entries of ONE row inside a pass above which the whole workgroup sums it
+constexpr uint32_t kBwHeavyCap = (kBwPass / (kBwHeavy + 1) + 4 + 1) & ~1u;   // (even: what follows it in LDS is 8-byte aligned)
+constexpr uint32_t kBwWinLoads = 8;    // 16-byte loads of the window a thread has in flight at once
 constexpr uint32_t kBwUnit = 512;      // rows: the windows are measured per unit, a block is 1, 2, 4 or 8 units
 constexpr size_t kBwLdsMax = 160 * 1024;
 
 // setup: {first column, one past the last column} of every unit of kBwUnit rows ({~0, 0}: no entries)
 __global__ __launch_bounds__(256) void bw_unit_windows(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
-                                                       uint32_t nrows, uint2 *__restrict__ out) {
+                                                       uint32_t nrows, uint2 *__restrict__ out, uint32_t *__restrict__ first_entry) {
     __shared__ uint32_t s_lo[4], s_hi[4];
     const uint32_t r0 = blockIdx.x * kBwUnit, r1 = min(r0 + kBwUnit, nrows);
     const uint32_t e0 = rowptr[r0], e1 = rowptr[r1];
@@ -50,8 +56,40 @@ __global__ __launch_bounds__(256) void bw_unit_windows(const uint32_t *__restric
     }
     if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         out[blockIdx.x] = make_uint2(min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3])), max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3])));
+        first_entry[blockIdx.x] = e0;
+        if (blockIdx.x + 1 == gridDim.x) first_entry[gridDim.x] = e1;
+    }
+}
+
+// sum over the 16 lanes of a DPP row, in lane 0 of the row (row_shl: lane i receives lane i + n of its row, 0.0 past the end)
+template <int CTRL>
+__device__ __forceinline__ double bw_dpp(double v) {
+    const uint64_t u = __builtin_bit_cast(uint64_t, v);
+    int lo = (int)(uint32_t)u, hi = (int)(uint32_t)(u >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float bw_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <typename T>
+__device__ __forceinline__ T bw_sum16(T v) {
+    v = v + bw_dpp<0x108>(v);
+    v = v + bw_dpp<0x104>(v);
+    v = v + bw_dpp<0x102>(v);
+    v = v + bw_dpp<0x101>(v);
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T bw_sum64(T v) {   // in lane 0 of the wave
+    v = bw_sum16(v);
+    v = v + __shfl_down(v, 16, 64);
+    v = v + __shfl_down(v, 32, 64);
+    return v;
 }
 
 // first i in [lo, n] with rp[i] >= v (rp ascending, rp[n] >= v), by the whole wave: two rounds of 64 probes for n - lo <= 4096
@@ -70,87 +108,130 @@ __device__ __forceinline__ uint32_t bw_first_at_least(const uint32_t *rp, uint32
     return a + (uint32_t)__builtin_ctzll(m);
 }
 
+// -DSPAL_BW_STAMPS (lab builds): thread 0 of every workgroup adds up wall_clock64() (100 MHz) per phase into g_bw_stamps[block][8]
+#ifdef SPAL_BW_STAMPS
+__device__ unsigned long long *g_bw_stamps = nullptr;
+// (summed in registers and written once at the end: a read-modify-write per stamp would wait for every load in flight)
+#define BW_STAMP(i) do { const unsigned long long now_ = wall_clock64(); acc_[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define BW_STAMP(i) do { } while (0)
+#endif
+
 template <typename T>
 __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
                                                                 const T *__restrict__ vals, const T *__restrict__ x, T *__restrict__ y,
-                                                                const uint2 *__restrict__ bwin, uint32_t nrows, uint32_t ncols,
-                                                                uint32_t RB, uint32_t nblocks, uint32_t per_xcd, uint32_t win_cols) {
+                                                                const uint2 *__restrict__ bwin, const uint32_t *__restrict__ order,
+                                                                uint32_t nrows, uint32_t ncols, uint32_t RB, uint32_t nblocks,
+                                                                uint32_t win_cols) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_bw_smem[];
     T *xw = reinterpret_cast<T *>(spal_bw_smem);                      // win_cols (a multiple of 256)
     T *sp = xw + win_cols;                                             // kBwPass products, in entry order
     T *s_carry = sp + kBwPass;                                         // [2]: the running sum of the row a pass boundary cut
     uint32_t *s_rp = reinterpret_cast<uint32_t *>(s_carry + 2);        // RB + 1 (+ 1 pad)
-    uint32_t *s_long = s_rp + RB + 2;                                  // kBwLongCap
-    uint32_t *s_nlong = s_long + kBwLongCap;
+    uint32_t *s_long = s_rp + RB + 2;                                  // kBwLongCap: rows a group of 16 lanes sums
+    uint32_t *s_heavy = s_long + kBwLongCap;                           // kBwHeavyCap: rows the whole workgroup sums
+    uint32_t *s_nlong = s_heavy + kBwHeavyCap;                         // [2]: the lists' lengths
+    T *s_part = reinterpret_cast<T *>(s_nlong + 2);                    // [16]: the waves' partial sums of a heavy row
 
-    // consecutive blocks share most of their windows: a block's neighbours run on the same XCD (one L2)
-    const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    if (blk >= nblocks) return;   // block-uniform
+    // blocks are dealt in the plan's order: XCD k (workgroups k, k + 8, ...) takes the k-th eighth of the blocks -- neighbours
+    // share most of their windows and meet in one L2 --, inside it the blocks with the most entries first (a workgroup per CU
+    // and four rounds of them: the launch ends with its shortest blocks)
+    const uint32_t blk = order[blockIdx.x];
+    if (blk >= nblocks) return;   // block-uniform (padding of the last round)
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+#ifdef SPAL_BW_STAMPS
+    unsigned long long last_ = wall_clock64(), acc_[4] = {0, 0, 0, 0};
+    const unsigned long long first_ = last_;
+#endif
     const uint32_t r0 = blk * RB, nr = min(RB, nrows - r0);
     const uint32_t e0 = rowptr[r0], e1 = rowptr[r0 + nr];
     // the first pass's entries are requested before anything else
-    uint32_t cc[kBwItems], nc[kBwItems];
-    T cv[kBwItems], nv[kBwItems];
+    uint32_t ca[kBwItems], cb[kBwItems];
+    T va[kBwItems], vb[kBwItems];
 #pragma unroll
     for (uint32_t k = 0; k < kBwItems; ++k) {
         const uint32_t idx = min(e0 + k * kBwThreads + t, e1 ? e1 - 1u : 0u);
-        cc[k] = e1 > e0 ? colind[idx] : 0u;
-        cv[k] = e1 > e0 ? vals[idx] : T(0);
+        ca[k] = e1 > e0 ? colind[idx] : 0u;
+        va[k] = e1 > e0 ? vals[idx] : T(0);
+        cb[k] = 0u;
+        vb[k] = T(0);
     }
     for (uint32_t i = t; i <= nr; i += kBwThreads) s_rp[i] = rowptr[r0 + i];
     const uint2 win = bwin[blk];            // {first column (a multiple of 256), columns}
     const uint32_t c0 = win.x;
     {
         const uint32_t wn = min(win.y, ncols - min(c0, ncols));
-        if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0 && sizeof(T) == 8) {   // (uniform) 16-byte loads of two columns
-            typedef double d2 __attribute__((ext_vector_type(2)));
-            const d2 *xs = reinterpret_cast<const d2 *>(x + c0);
-            d2 *xd = reinterpret_cast<d2 *>(xw);
-            const uint32_t pairs = wn / 2u;
-            for (uint32_t i = t; i < pairs; i += kBwThreads) xd[i] = xs[i];
-            if (t == 0 && (wn & 1u)) xw[wn - 1u] = x[c0 + wn - 1u];
+        if ((reinterpret_cast<uintptr_t>(x + c0) & 15u) == 0) {   // (uniform) 16-byte loads, kBwWinLoads of them in flight per thread
+            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+            constexpr uint32_t V = 16 / sizeof(T);
+            const u4 *xs = reinterpret_cast<const u4 *>(x + c0);
+            u4 *xd = reinterpret_cast<u4 *>(xw);
+            const uint32_t nvec = wn / V;
+            for (uint32_t i0 = 0; i0 < nvec; i0 += kBwWinLoads * kBwThreads) {   // (uniform)
+                u4 r[kBwWinLoads];
+#pragma unroll
+                for (uint32_t k = 0; k < kBwWinLoads; ++k) r[k] = xs[min(i0 + k * kBwThreads + t, nvec - 1u)];
+#pragma unroll
+                for (uint32_t k = 0; k < kBwWinLoads; ++k)
+                    if (i0 + k * kBwThreads + t < nvec) xd[i0 + k * kBwThreads + t] = r[k];
+            }
+            for (uint32_t i = nvec * V + t; i < wn; i += kBwThreads) xw[i] = x[c0 + i];
         } else {
-            for (uint32_t i = t; i < wn; i += kBwThreads) xw[i] = x[c0 + i];
+            for (uint32_t i0 = 0; i0 < wn; i0 += kBwWinLoads * kBwThreads) {
+                T r[kBwWinLoads];
+#pragma unroll
+                for (uint32_t k = 0; k < kBwWinLoads; ++k) r[k] = x[c0 + min(i0 + k * kBwThreads + t, wn - 1u)];
+#pragma unroll
+                for (uint32_t k = 0; k < kBwWinLoads; ++k)
+                    if (i0 + k * kBwThreads + t < wn) xw[i0 + k * kBwThreads + t] = r[k];
+            }
         }
     }
     __syncthreads();
+    BW_STAMP(0);
     for (uint32_t i = t; i < nr; i += kBwThreads)   // empty rows: nothing below writes them
         if (s_rp[i + 1] == s_rp[i]) y[r0 + i] = T(0);
 
     uint32_t rlo = 0, parity = 0;
-    for (uint32_t ps = e0; ps < e1; ps += kBwPass, parity ^= 1u) {   // (block-uniform)
+    // one pass: the entries [ps, ps + kBwPass) are in (cc, cv); the next pass's are requested into (nc, nv) first.  Called with
+    // the two register sets swapped every other pass: a copy at the end of the pass would wait for the loads just issued.
+    auto one_pass = [&](uint32_t ps, uint32_t (&cc)[kBwItems], T (&cv)[kBwItems], uint32_t (&nc)[kBwItems], T (&nv)[kBwItems]) {
         const uint32_t pe = min(ps + kBwPass, e1);
-        const bool more = pe < e1;
-        if (more) {
-#pragma unroll
-            for (uint32_t k = 0; k < kBwItems; ++k) {
-                const uint32_t idx = min(pe + k * kBwThreads + t, e1 - 1u);
-                nc[k] = colind[idx];
-                nv[k] = vals[idx];
-            }
-        }
+        // (requested unconditionally -- the block's last pass reads its last entry again -- and the products written
+        //  unconditionally -- places beyond the pass's end are never read: under conditions the compiler no longer knows how many
+        //  loads are in flight and waits for ALL of them, the ones just requested included, before the first product)
 #pragma unroll
         for (uint32_t k = 0; k < kBwItems; ++k) {
-            const uint32_t idx = ps + k * kBwThreads + t;
-            if (idx < pe) sp[k * kBwThreads + t] = cv[k] * xw[cc[k] - c0];   // one rounding, as `val * x[col]` in the reference
+            const uint32_t idx = min(pe + k * kBwThreads + t, e1 - 1u);
+            nc[k] = colind[idx];
+            nv[k] = vals[idx];
         }
-        if (t == 0) *s_nlong = 0u;
+        T xv[kBwItems];   // (all gathers first: window and strip are both LDS, a write between two reads keeps them in order)
+#pragma unroll
+        for (uint32_t k = 0; k < kBwItems; ++k) xv[k] = xw[cc[k] - c0];
+#pragma unroll
+        for (uint32_t k = 0; k < kBwItems; ++k)
+            sp[k * kBwThreads + t] = cv[k] * xv[k];   // one rounding, as `val * x[col]` in the reference
+        if (t == 0) { s_nlong[0] = 0u; s_nlong[1] = 0u; }
         __syncthreads();
+        BW_STAMP(1);
         // rows rlo ... rhi - 1 may hold entries of [ps, pe)
         const uint32_t rhi = bw_first_at_least(s_rp, rlo, nr, pe, lane);
+        // (a pass of 4096 entries touches ~400 rows of ten entries, seven waves' worth; half the lanes of ALL sixteen waves
+        //  taking 32 rows each measured slower, 6.4 -> 7.4 us per block: the phase lasts as long as its longest row)
         for (uint32_t i = rlo + t; i < rhi; i += kBwThreads) {
             const uint32_t rs = s_rp[i], re = s_rp[i + 1];
             const uint32_t a = max(rs, ps), b = min(re, pe);
             if (a >= b) continue;                               // empty, or ended where the pass begins
-            if (re - rs > kBwShort) {
-                s_long[atomicAdd(s_nlong, 1u)] = i;             // (at most kBwLongCap of them touch a pass)
+            if (re - rs > kBwShort) {                           // (at most kBwLongCap / kBwHeavyCap of them touch a pass)
+                if (b - a > kBwHeavy) s_heavy[atomicAdd(&s_nlong[1], 1u)] = i;
+                else s_long[atomicAdd(&s_nlong[0], 1u)] = i;
                 continue;
             }
             T acc = rs < ps ? s_carry[parity ^ 1u] : T(0);      // a cut row goes on where the last pass stopped
-            uint32_t j = a - ps;
             const uint32_t jb = b - ps;
-            for (; j + 4u <= jb; j += 4u) {
+            uint32_t j = a - ps;
+            for (; j + 4u <= jb; j += 4u) {   // (eight requested at once and added under predicates: 7.4 -> 9.4 us per block)
                 const T v0 = sp[j], v1 = sp[j + 1], v2 = sp[j + 2], v3 = sp[j + 3];
                 acc = acc + v0;
                 acc = acc + v1;
@@ -162,37 +243,72 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
             else s_carry[parity] = acc;
         }
         __syncthreads();
-        const uint32_t nlong = *s_nlong;
-        for (uint32_t li = wave; li < nlong; li += kBwThreads / 64) {   // wave-uniform
-            const uint32_t i = s_long[li];
-            const uint32_t rs = s_rp[i], re = s_rp[i + 1];
-            const uint32_t a = max(rs, ps) - ps, b = min(re, pe) - ps;
-            T part = T(0);
-            for (uint32_t j = a + lane; j < b; j += 64u) part = part + sp[j];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) part = part + __shfl_xor(part, o, 64);
-            const T tot = (rs < ps ? s_carry[parity ^ 1u] : T(0)) + part;
-            if (lane == 0) {
-                if (re <= pe) y[r0 + i] = tot;
-                else s_carry[parity] = tot;
+        BW_STAMP(2);
+        {   // rows of more than kBwShort entries: a group of 16 lanes each (four rows per wave at a time)
+            const uint32_t nlong = s_nlong[0], g = t >> 4, gl = t & 15u;
+            for (uint32_t li = g; li < nlong; li += kBwThreads / 16) {
+                const uint32_t i = s_long[li];
+                const uint32_t rs = s_rp[i], re = s_rp[i + 1];
+                const uint32_t a = max(rs, ps) - ps, b = min(re, pe) - ps;
+                T p0 = T(0), p1 = T(0);
+                uint32_t j = a + gl;
+                for (; j + 16u < b; j += 32u) { p0 = p0 + sp[j]; p1 = p1 + sp[j + 16u]; }
+                if (j < b) p0 = p0 + sp[j];
+                const T part = bw_sum16(p0 + p1);
+                if (gl == 0) {
+                    const T tot = (rs < ps ? s_carry[parity ^ 1u] : T(0)) + part;
+                    if (re <= pe) y[r0 + i] = tot;
+                    else s_carry[parity] = tot;
+                }
+            }
+        }
+        {   // rows with more than kBwHeavy entries in this pass: the whole workgroup, one row after the other
+            const uint32_t nheavy = s_nlong[1];   // (block-uniform)
+            for (uint32_t hi = 0; hi < nheavy; ++hi) {
+                const uint32_t i = s_heavy[hi];
+                const uint32_t rs = s_rp[i], re = s_rp[i + 1];
+                const uint32_t a = max(rs, ps) - ps, b = min(re, pe) - ps;
+                T p = T(0);
+                for (uint32_t j = a + t; j < b; j += kBwThreads) p = p + sp[j];
+                p = bw_sum64(p);
+                if (lane == 0) s_part[wave] = p;
+                __syncthreads();
+                if (wave == 0) {
+                    const T q = bw_sum16(lane < 16u ? s_part[lane] : T(0));
+                    if (lane == 0) {
+                        const T tot = (rs < ps ? s_carry[parity ^ 1u] : T(0)) + q;
+                        if (re <= pe) y[r0 + i] = tot;
+                        else s_carry[parity] = tot;
+                    }
+                }
+                __syncthreads();   // (s_part is written again by the next heavy row)
             }
         }
         __syncthreads();
+        BW_STAMP(3);
         rlo = s_rp[rhi] == pe ? rhi : rhi - 1u;   // the row that holds entry pe (rhi >= 1: rp[0] = e0 < pe)
-        if (more) {
-#pragma unroll
-            for (uint32_t k = 0; k < kBwItems; ++k) { cc[k] = nc[k]; cv[k] = nv[k]; }
-        }
+        parity ^= 1u;
+    };
+    for (uint32_t ps = e0; ps < e1; ps += 2u * kBwPass) {   // (block-uniform)
+        one_pass(ps, ca, va, cb, vb);
+        if (ps + kBwPass < e1) one_pass(ps + kBwPass, cb, vb, ca, va);
     }
+#ifdef SPAL_BW_STAMPS
+    if (t == 0 && g_bw_stamps) {
+        for (int i = 0; i < 4; ++i) g_bw_stamps[(size_t)blk * 8 + i] = acc_[i];
+        g_bw_stamps[(size_t)blk * 8 + 7] = first_;
+    }
+#endif
 }
 
 static size_t bw_lds_bytes(uint32_t RB, uint32_t win_cols, size_t esz) {
-    return (size_t)win_cols * esz + (size_t)kBwPass * esz + 2 * esz + (size_t)(RB + 2 + kBwLongCap + 2) * 4;
+    return (size_t)win_cols * esz + (size_t)kBwPass * esz + 2 * esz + (size_t)(RB + 2 + kBwLongCap + kBwHeavyCap + 2) * 4 + 16 * esz;
 }
 
 void blockwin_free(spal_csr *a) {
     a->bw_on = 0;
     (void)dev_free(a->d_bwin); a->d_bwin = nullptr;
+    (void)dev_free(a->d_bworder); a->d_bworder = nullptr;
     a->bw_blocks = 0; a->bw_rows = 0; a->bw_cols = 0;
 }
 
@@ -202,13 +318,16 @@ int blockwin_plan(spal_csr *a) {
     blockwin_free(a);
     if (a->nnz == 0 || a->nrows < kBwUnit || !a->parts.empty()) return SPAL_OK;
     const uint32_t nunits = (uint32_t)((a->nrows + kBwUnit - 1) / kBwUnit);
-    DevBuf d_win;
+    DevBuf d_win, d_first;
     SPAL_HIP_TRY(d_win.alloc((size_t)nunits * sizeof(uint2)));
+    SPAL_HIP_TRY(d_first.alloc((size_t)(nunits + 1) * 4));
     hipLaunchKernelGGL(bw_unit_windows, dim3(nunits), dim3(256), 0, a->stream, a->d_rowptr, a->d_colind, (uint32_t)a->nrows,
-                       d_win.as<uint2>());
+                       d_win.as<uint2>(), d_first.as<uint32_t>());
     SPAL_HIP_TRY(hipGetLastError());
     std::vector<uint2> win(nunits);
+    std::vector<uint32_t> first(nunits + 1);
     SPAL_HIP_TRY(hipMemcpyAsync(win.data(), d_win.p, win.size() * sizeof(uint2), hipMemcpyDeviceToHost, a->stream));
+    SPAL_HIP_TRY(hipMemcpyAsync(first.data(), d_first.p, first.size() * 4, hipMemcpyDeviceToHost, a->stream));
     SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
     const size_t esz = (size_t)a->elem_size;
     for (uint32_t units = 8; units >= 1; units >>= 1) {
@@ -226,8 +345,19 @@ int blockwin_plan(spal_csr *a) {
         }
         const uint32_t win_cols = std::max(256u, (widest + 255u) & ~255u);
         if (bw_lds_bytes(RB, win_cols, esz) > kBwLdsMax) continue;
+        const uint32_t per_xcd = (nb + 7u) / 8u;
+        std::vector<uint32_t> order((size_t)per_xcd * 8u, 0xffffffffu), part;
+        auto entries = [&](uint32_t b) { return first[std::min(nunits, (b + 1) * units)] - first[b * units]; };
+        for (uint32_t k = 0; k < 8u; ++k) {
+            part.clear();
+            for (uint32_t b = k * per_xcd; b < std::min(nb, (k + 1) * per_xcd); ++b) part.push_back(b);
+            std::stable_sort(part.begin(), part.end(), [&](uint32_t p, uint32_t q) { return entries(p) > entries(q); });
+            for (size_t i = 0; i < part.size(); ++i) order[i * 8u + k] = part[i];
+        }
         SPAL_HIP_TRY(dev_alloc((void **)&a->d_bwin, (size_t)nb * sizeof(uint2)));
+        SPAL_HIP_TRY(dev_alloc((void **)&a->d_bworder, order.size() * 4));
         SPAL_HIP_TRY(hipMemcpy(a->d_bwin, bw.data(), (size_t)nb * sizeof(uint2), hipMemcpyHostToDevice));
+        SPAL_HIP_TRY(hipMemcpy(a->d_bworder, order.data(), order.size() * 4, hipMemcpyHostToDevice));
         a->bw_blocks = nb;
         a->bw_rows = RB;
         a->bw_cols = win_cols;
@@ -246,11 +376,40 @@ static hipError_t bw_launch_t(const spal_csr *a, const void *x, void *y, hipStre
         if (e != hipSuccess) return e;
         configured.fetch_or(bit, std::memory_order_relaxed);
     }
-    const uint32_t per_xcd = (a->bw_blocks + 7u) / 8u;
     const size_t lds = bw_lds_bytes(a->bw_rows, a->bw_cols, sizeof(T));
-    hipLaunchKernelGGL(csr_spmv_blockwin<T>, dim3(per_xcd * 8u), dim3(kBwThreads), lds, st, a->d_rowptr, a->d_colind,
-                       (const T *)a->d_values, (const T *)x, (T *)y, a->d_bwin, (uint32_t)a->nrows, (uint32_t)a->ncols, a->bw_rows,
-                       a->bw_blocks, per_xcd, a->bw_cols);
+#ifdef SPAL_BW_STAMPS
+    static unsigned long long *d_st = nullptr;
+    static uint32_t st_for = 0, calls = 0;
+    if (st_for < a->bw_blocks) {
+        if (d_st) (void)hipFree(d_st);
+        if (hipMalloc((void **)&d_st, (size_t)a->bw_blocks * 64) != hipSuccess) return hipErrorOutOfMemory;
+        st_for = a->bw_blocks;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bw_stamps), &d_st, sizeof(d_st));
+    }
+    (void)hipMemsetAsync(d_st, 0, (size_t)a->bw_blocks * 64, st);
+#endif
+    hipLaunchKernelGGL(csr_spmv_blockwin<T>, dim3((a->bw_blocks + 7u) / 8u * 8u), dim3(kBwThreads), lds, st, a->d_rowptr, a->d_colind,
+                       (const T *)a->d_values, (const T *)x, (T *)y, a->d_bwin, a->d_bworder, (uint32_t)a->nrows, (uint32_t)a->ncols,
+                       a->bw_rows, a->bw_blocks, a->bw_cols);
+#ifdef SPAL_BW_STAMPS
+    if (++calls % 16 == 0) {
+        std::vector<unsigned long long> h((size_t)a->bw_blocks * 8);
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
+        double sum[4] = {0, 0, 0, 0}, tot_max = 0;
+        unsigned long long first = ~0ull, last = 0;
+        for (uint32_t b = 0; b < a->bw_blocks; ++b) {
+            double tot = 0;
+            for (int i = 0; i < 4; ++i) { sum[i] += (double)h[(size_t)b * 8 + i]; tot += (double)h[(size_t)b * 8 + i]; }
+            tot_max = std::max(tot_max, tot);
+            first = std::min(first, h[(size_t)b * 8 + 7]);
+            last = std::max(last, h[(size_t)b * 8 + 7] + (unsigned long long)tot);
+        }
+        fprintf(stderr, "[spal blockwin stamps] %u blocks, kernel %.1f us; mean us per block: window + first loads %.2f, products %.2f, thread rows %.2f, "
+                "wave rows %.2f; longest block %.2f\n", a->bw_blocks, (double)(last - first) / 100.0, sum[0] / a->bw_blocks / 100.0,
+                sum[1] / a->bw_blocks / 100.0, sum[2] / a->bw_blocks / 100.0, sum[3] / a->bw_blocks / 100.0, tot_max / 100.0);
+    }
+#endif
     return hipGetLastError();
 }
 
