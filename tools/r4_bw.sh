@@ -9,4 +9,5 @@ timeout -k 10 300 python tools/lab.py powerlaw local quick > $O/pl_bw.log 2>&1; 
 if [ -f spalinalg_amd/lib_var/bwstamps/libspal_hip.so ]; then
   SPAL_HIP_LIB=$PWD/spalinalg_amd/lib_var/bwstamps/libspal_hip.so timeout -k 10 300 python tools/lab.py powerlaw local quick > $O/pl_bws.log 2>&1; grep "blockwin stamps" $O/pl_bws.log | head -2
 fi
+for v in ${VARIANTS:-}; do SPAL_HIP_LIB=$PWD/spalinalg_amd/lib_var/$v/libspal_hip.so timeout -k 10 300 python tools/lab.py powerlaw local quick > $O/pl_bw_$v.log 2>&1; echo "$v: $(grep blockwin $O/pl_bw_$v.log | head -1)"; done
 exit 0
