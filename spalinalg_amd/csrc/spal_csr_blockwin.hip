@@ -28,7 +28,7 @@ namespace spal {
 
 constexpr int kBwThreads = 1024;
 #ifndef SPAL_BW_PASS
-#define SPAL_BW_PASS 4096
+#define SPAL_BW_PASS 3072
 #endif
 #ifndef SPAL_BW_ROW_WAVES
 #define SPAL_BW_ROW_WAVES 8
@@ -38,9 +38,10 @@ constexpr uint32_t kBwItems = kBwPass / kBwThreads;
 constexpr uint32_t kBwRowThreads = SPAL_BW_ROW_WAVES * 64;                  // waves 0 ... : a short row per thread
 constexpr uint32_t kBwGroups = (kBwThreads - kBwRowThreads) / 16;           // the other waves: a long row per 16 lanes
 constexpr uint32_t kBwShort = 32;      // rows up to this many entries are summed by one thread, in the reference's order
-constexpr uint32_t kBwLongCap = kBwPass / (kBwShort + 1) + 4;   // long rows a pass can touch
+constexpr uint32_t kBwLongCap = (kBwPass / (kBwShort + 1) + 4 + 1) & ~1u;   // long rows a pass can touch
 constexpr uint32_t kBwHeavy = 512;     // entries of ONE row inside a pass above which the whole workgroup sums it
 constexpr uint32_t kBwHeavyCap = (kBwPass / (kBwHeavy + 1) + 4 + 1) & ~1u;   // (even: what follows it in LDS is 8-byte aligned)
+constexpr uint32_t kBwListCap = kBwLongCap + kBwHeavyCap;   // one pass's lists: 16-lane rows, then heavy rows
 constexpr uint32_t kBwWinLoads = 8;    // 16-byte loads of the window a thread has in flight at once
 constexpr uint32_t kBwUnit = 512;      // rows: the windows are measured per unit, a block is 1, 2, 4 or 8 units
 constexpr size_t kBwLdsMax = 160 * 1024;
@@ -133,13 +134,12 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
                                                                 uint32_t win_cols) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_bw_smem[];
     T *xw = reinterpret_cast<T *>(spal_bw_smem);                      // win_cols (a multiple of 256)
-    T *sp = xw + win_cols;                                             // kBwPass products, in entry order
-    T *s_carry = sp + kBwPass;                                         // [2]: the running sum of the row a pass boundary cut
-    uint32_t *s_rp = reinterpret_cast<uint32_t *>(s_carry + 2);        // RB + 1 (+ 1 pad)
-    uint32_t *s_long = s_rp + RB + 2;                                  // kBwLongCap: rows a group of 16 lanes sums
-    uint32_t *s_heavy = s_long + kBwLongCap;                           // kBwHeavyCap: rows the whole workgroup sums
-    uint32_t *s_nlong = s_heavy + kBwHeavyCap;                         // [2]: the lists' lengths
-    T *s_part = reinterpret_cast<T *>(s_nlong + 2);                    // [16]: the waves' partial sums of a heavy row
+    T *sp = xw + win_cols;                                             // [2][kBwPass] products in entry order: pass p in strip p & 1
+    T *s_carry = sp + 2 * kBwPass;                                     // [2]: the running sum of the row a pass boundary cut
+    T *s_part = s_carry + 2;                                           // [16]: the waves' partial sums of a heavy row
+    uint32_t *s_rp = reinterpret_cast<uint32_t *>(s_part + 16);        // RB + 1 (+ 1 pad)
+    uint32_t *s_list = s_rp + RB + 2;                                  // [3][kBwListCap]: pass p's listed rows in list p % 3
+    uint32_t *s_n = s_list + 3 * kBwListCap;                           // [3][2]: the lists' lengths {16-lane rows, heavy rows}
 
     // blocks are dealt in the plan's order: XCD k (workgroups k, k + 8, ...) takes the k-th eighth of the blocks -- neighbours
     // share most of their windows and meet in one L2 --, inside it the blocks with the most entries first (a workgroup per CU
@@ -153,18 +153,26 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
 #endif
     const uint32_t r0 = blk * RB, nr = min(RB, nrows - r0);
     const uint32_t e0 = rowptr[r0], e1 = rowptr[r0 + nr];
-    // the first pass's entries are requested before anything else
+    const uint32_t npass = (e1 - e0 + kBwPass - 1u) / kBwPass;
+    // Entries of pass p, requested unconditionally (a pass beyond the block's last reads the last entry again): under
+    // conditions the compiler no longer knows how many loads are in flight and waits for ALL of them before the first product.
     uint32_t ca[kBwItems], cb[kBwItems];
     T va[kBwItems], vb[kBwItems];
+    auto load_pass = [&](uint32_t p, uint32_t (&c)[kBwItems], T (&v)[kBwItems]) {
+        const uint32_t last = e1 > e0 ? e1 - 1u : 0u;
 #pragma unroll
-    for (uint32_t k = 0; k < kBwItems; ++k) {
-        const uint32_t idx = min(e0 + k * kBwThreads + t, e1 ? e1 - 1u : 0u);
-        ca[k] = e1 > e0 ? colind[idx] : 0u;
-        va[k] = e1 > e0 ? vals[idx] : T(0);
-        cb[k] = 0u;
-        vb[k] = T(0);
+        for (uint32_t k = 0; k < kBwItems; ++k) {
+            const uint32_t idx = min(e0 + min(p, npass) * kBwPass + k * kBwThreads + t, last);
+            c[k] = colind[idx];
+            v[k] = vals[idx];
+        }
+    };
+    if (e1 > e0) {   // (block-uniform; a block without entries only zeroes its rows)
+        load_pass(0, ca, va);
+        load_pass(1, cb, vb);
     }
     for (uint32_t i = t; i <= nr; i += kBwThreads) s_rp[i] = rowptr[r0 + i];
+    if (t < 6u) s_n[t] = 0u;
     const uint2 win = bwin[blk];            // {first column (a multiple of 256), columns}
     const uint32_t c0 = win.x;
     {
@@ -199,47 +207,62 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
     BW_STAMP(0);
     for (uint32_t i = t; i < nr; i += kBwThreads)   // empty rows: nothing below writes them
         if (s_rp[i + 1] == s_rp[i]) y[r0 + i] = T(0);
+    if (e1 == e0) return;   // block-uniform
 
-    uint32_t rlo = 0, parity = 0;
-    // one pass: the entries [ps, ps + kBwPass) are in (cc, cv); the next pass's are requested into (nc, nv) first.  Called with
-    // the two register sets swapped every other pass: a copy at the end of the pass would wait for the loads just issued.
-    auto one_pass = [&](uint32_t ps, uint32_t (&cc)[kBwItems], T (&cv)[kBwItems], uint32_t (&nc)[kBwItems], T (&nv)[kBwItems]) {
-        const uint32_t pe = min(ps + kBwPass, e1);
-        // (requested unconditionally -- the block's last pass reads its last entry again -- and the products written
-        //  unconditionally -- places beyond the pass's end are never read: under conditions the compiler no longer knows how many
-        //  loads are in flight and waits for ALL of them, the ones just requested included, before the first product)
+    // the products of pass p, into strip p & 1 (all gathers first: window and strip are both LDS, a write between two reads
+    // keeps them in order; written unconditionally: places beyond the pass's end are never read)
+    auto products = [&](uint32_t p, const uint32_t (&c)[kBwItems], const T (&v)[kBwItems]) {
+        T *strip = sp + (p & 1u) * kBwPass;
+        T xv[kBwItems];
 #pragma unroll
-        for (uint32_t k = 0; k < kBwItems; ++k) {
-            const uint32_t idx = min(pe + k * kBwThreads + t, e1 - 1u);
-            nc[k] = colind[idx];
-            nv[k] = vals[idx];
-        }
-        T xv[kBwItems];   // (all gathers first: window and strip are both LDS, a write between two reads keeps them in order)
+        for (uint32_t k = 0; k < kBwItems; ++k) xv[k] = xw[c[k] - c0];
 #pragma unroll
-        for (uint32_t k = 0; k < kBwItems; ++k) xv[k] = xw[cc[k] - c0];
-#pragma unroll
-        for (uint32_t k = 0; k < kBwItems; ++k)
-            sp[k * kBwThreads + t] = cv[k] * xv[k];   // one rounding, as `val * x[col]` in the reference
-        if (t == 0) { s_nlong[0] = 0u; s_nlong[1] = 0u; }
-        __syncthreads();
-        BW_STAMP(1);
-        // rows rlo ... rhi - 1 may hold entries of [ps, pe).  First every row is looked at once: the long ones go on two lists
-        const uint32_t rhi = bw_first_at_least(s_rp, rlo, nr, pe, lane);
-        for (uint32_t i = rlo + t; i < rhi; i += kBwThreads) {
+        for (uint32_t k = 0; k < kBwItems; ++k) strip[k * kBwThreads + t] = v[k] * xv[k];   // one rounding, as `val * x[col]` in the reference
+    };
+    // the rows lo ... hi - 1 may hold entries of pass p = [ps, pe): those of more than kBwShort entries go on pass p's lists
+    auto classify = [&](uint32_t p, uint32_t lo, uint32_t hi) {
+        const uint32_t ps = e0 + p * kBwPass, pe = min(ps + kBwPass, e1);
+        uint32_t *lst = s_list + (p % 3u) * kBwListCap, *cnt = s_n + (p % 3u) * 2u;
+        for (uint32_t i = lo + t; i < hi; i += kBwThreads) {
             const uint32_t rs = s_rp[i], re = s_rp[i + 1];
             const uint32_t a = max(rs, ps), b = min(re, pe);
             if (a < b && re - rs > kBwShort) {                  // (at most kBwLongCap / kBwHeavyCap of them touch a pass)
-                if (b - a > kBwHeavy) s_heavy[atomicAdd(&s_nlong[1], 1u)] = i;
-                else s_long[atomicAdd(&s_nlong[0], 1u)] = i;
+                if (b - a > kBwHeavy) lst[kBwLongCap + atomicAdd(&cnt[1], 1u)] = i;
+                else lst[atomicAdd(&cnt[0], 1u)] = i;
             }
         }
-        __syncthreads();
-        BW_STAMP(2);
-        // ... then the two kinds of rows are summed SIDE BY SIDE: the first kBwRowThreads threads take a short row each (a pass
-        // of 4096 entries touches ~400 rows of ten entries; the phase lasts as long as its longest row), the other waves the
-        // listed rows, 16 lanes per row -- one phase instead of two (6.4 + 5.2 us per block of five passes)
+    };
+
+    // prologue: pass 0's products and lists
+    uint32_t cur_lo = 0, cur_hi = bw_first_at_least(s_rp, 0u, nr, min(e0 + kBwPass, e1), lane);
+    products(0, ca, va);
+    classify(0, cur_lo, cur_hi);
+    __syncthreads();
+    BW_STAMP(1);
+    // One PHASE per pass, one barrier per phase: while pass p's rows are summed out of strip p & 1, pass p + 1's products go
+    // into the other strip (their entries were requested a phase ago), its rows are looked at and listed, and pass p + 2's
+    // entries are requested.  (First form: products | barrier | rows looked at | barrier | rows summed | barrier per pass.)
+    auto phase = [&](uint32_t p, uint32_t (&cn)[kBwItems], T (&vn)[kBwItems], uint32_t (&cf)[kBwItems], T (&vf)[kBwItems]) {
+        // (cn, vn): pass p + 1's entries, in registers since the last phase; (cf, vf): free, takes pass p + 2's
+        const uint32_t ps = e0 + p * kBwPass, pe = min(ps + kBwPass, e1), parity = p & 1u;
+        const T *strip = sp + parity * kBwPass;
+        uint32_t nxt_lo = 0, nxt_hi = 0;
+        products(p + 1u, cn, vn);           // (beyond the last pass: of the last entry again, into the strip nobody reads)
+        load_pass(p + 2u, cf, vf);
+        if (p + 1u < npass) {               // (block-uniform)
+            nxt_lo = s_rp[cur_hi] == pe ? cur_hi : cur_hi - 1u;   // the row that holds entry pe (cur_hi >= 1: rp[0] = e0 < pe)
+            nxt_hi = bw_first_at_least(s_rp, nxt_lo, nr, min(pe + kBwPass, e1), lane);
+            classify(p + 1u, nxt_lo, nxt_hi);
+        }
+        if (t == 0) { s_n[((p + 2u) % 3u) * 2u] = 0u; s_n[((p + 2u) % 3u) * 2u + 1u] = 0u; }   // (last read a phase ago)
+        const uint32_t *lst = s_list + (p % 3u) * kBwListCap, *cnt = s_n + (p % 3u) * 2u;
+        // (pass p's lists are complete since the last barrier; their lengths are read HERE: the next phase's thread 0 zeroes
+        //  them for pass p + 3 while a slower thread may still be on its way out of this phase)
+        const uint32_t nlong = cnt[0], nheavy = cnt[1];
+        // the first kBwRowThreads threads take a short row each (a pass of 4096 entries touches ~400 rows of ten entries; it
+        // lasts as long as its longest row), the other waves the listed rows, 16 lanes per row
         if (t < kBwRowThreads) {
-            for (uint32_t i = rlo + t; i < rhi; i += kBwRowThreads) {
+            for (uint32_t i = cur_lo + t; i < cur_hi; i += kBwRowThreads) {
                 const uint32_t rs = s_rp[i], re = s_rp[i + 1];
                 const uint32_t a = max(rs, ps), b = min(re, pe);
                 if (a >= b || re - rs > kBwShort) continue;         // empty, ended where the pass begins, or listed
@@ -247,26 +270,26 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
                 const uint32_t jb = b - ps;
                 uint32_t j = a - ps;
                 for (; j + 4u <= jb; j += 4u) {   // (eight requested at once and added under predicates: 7.4 -> 9.4 us per block)
-                    const T v0 = sp[j], v1 = sp[j + 1], v2 = sp[j + 2], v3 = sp[j + 3];
+                    const T v0 = strip[j], v1 = strip[j + 1], v2 = strip[j + 2], v3 = strip[j + 3];
                     acc = acc + v0;
                     acc = acc + v1;
                     acc = acc + v2;
                     acc = acc + v3;
                 }
-                for (; j < jb; ++j) acc = acc + sp[j];
+                for (; j < jb; ++j) acc = acc + strip[j];
                 if (re <= pe) y[r0 + i] = acc;
                 else s_carry[parity] = acc;
             }
-        } else {   // rows of more than kBwShort entries: a group of 16 lanes each
-            const uint32_t nlong = s_nlong[0], g = (t - kBwRowThreads) >> 4, gl = t & 15u;
+        } else {
+            const uint32_t g = (t - kBwRowThreads) >> 4, gl = t & 15u;
             for (uint32_t li = g; li < nlong; li += kBwGroups) {
-                const uint32_t i = s_long[li];
+                const uint32_t i = lst[li];
                 const uint32_t rs = s_rp[i], re = s_rp[i + 1];
                 const uint32_t a = max(rs, ps) - ps, b = min(re, pe) - ps;
                 T p0 = T(0), p1 = T(0);
                 uint32_t j = a + gl;
-                for (; j + 16u < b; j += 32u) { p0 = p0 + sp[j]; p1 = p1 + sp[j + 16u]; }
-                if (j < b) p0 = p0 + sp[j];
+                for (; j + 16u < b; j += 32u) { p0 = p0 + strip[j]; p1 = p1 + strip[j + 16u]; }
+                if (j < b) p0 = p0 + strip[j];
                 const T part = bw_sum16(p0 + p1);
                 if (gl == 0) {
                     const T tot = (rs < ps ? s_carry[parity ^ 1u] : T(0)) + part;
@@ -275,36 +298,36 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
                 }
             }
         }
+        __syncthreads();
+        BW_STAMP(2);
         {   // rows with more than kBwHeavy entries in this pass: the whole workgroup, one row after the other
-            const uint32_t nheavy = s_nlong[1];   // (block-uniform)
-            for (uint32_t hi = 0; hi < nheavy; ++hi) {
-                const uint32_t i = s_heavy[hi];
+            for (uint32_t hi = 0; hi < nheavy; ++hi) {   // (block-uniform)
+                const uint32_t i = lst[kBwLongCap + hi];
                 const uint32_t rs = s_rp[i], re = s_rp[i + 1];
                 const uint32_t a = max(rs, ps) - ps, b = min(re, pe) - ps;
-                T p = T(0);
-                for (uint32_t j = a + t; j < b; j += kBwThreads) p = p + sp[j];
-                p = bw_sum64(p);
-                if (lane == 0) s_part[wave] = p;
+                T q = T(0);
+                for (uint32_t j = a + t; j < b; j += kBwThreads) q = q + strip[j];
+                q = bw_sum64(q);
+                if (lane == 0) s_part[wave] = q;
                 __syncthreads();
                 if (wave == 0) {
-                    const T q = bw_sum16(lane < 16u ? s_part[lane] : T(0));
+                    const T tot16 = bw_sum16(lane < 16u ? s_part[lane] : T(0));
                     if (lane == 0) {
-                        const T tot = (rs < ps ? s_carry[parity ^ 1u] : T(0)) + q;
+                        const T tot = (rs < ps ? s_carry[parity ^ 1u] : T(0)) + tot16;
                         if (re <= pe) y[r0 + i] = tot;
                         else s_carry[parity] = tot;
                     }
                 }
-                __syncthreads();   // (s_part is written again by the next heavy row)
+                __syncthreads();   // (s_part is written again by the next heavy row; the strip by the next phase)
             }
         }
-        __syncthreads();
         BW_STAMP(3);
-        rlo = s_rp[rhi] == pe ? rhi : rhi - 1u;   // the row that holds entry pe (rhi >= 1: rp[0] = e0 < pe)
-        parity ^= 1u;
+        cur_lo = nxt_lo;
+        cur_hi = nxt_hi;
     };
-    for (uint32_t ps = e0; ps < e1; ps += 2u * kBwPass) {   // (block-uniform)
-        one_pass(ps, ca, va, cb, vb);
-        if (ps + kBwPass < e1) one_pass(ps + kBwPass, cb, vb, ca, va);
+    for (uint32_t p = 0; p < npass; p += 2u) {   // (block-uniform) the two register sets take turns
+        phase(p, cb, vb, ca, va);
+        if (p + 1u < npass) phase(p + 1u, ca, va, cb, vb);
     }
 #ifdef SPAL_BW_STAMPS
     if (t == 0 && g_bw_stamps) {
@@ -315,7 +338,7 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
 }
 
 static size_t bw_lds_bytes(uint32_t RB, uint32_t win_cols, size_t esz) {
-    return (size_t)win_cols * esz + (size_t)kBwPass * esz + 2 * esz + (size_t)(RB + 2 + kBwLongCap + kBwHeavyCap + 2) * 4 + 16 * esz;
+    return (size_t)win_cols * esz + 2 * (size_t)kBwPass * esz + (2 + 16) * esz + (size_t)(RB + 2 + 3 * kBwListCap + 6) * 4;
 }
 
 void blockwin_free(spal_csr *a) {
@@ -418,8 +441,8 @@ static hipError_t bw_launch_t(const spal_csr *a, const void *x, void *y, hipStre
             first = std::min(first, h[(size_t)b * 8 + 7]);
             last = std::max(last, h[(size_t)b * 8 + 7] + (unsigned long long)tot);
         }
-        fprintf(stderr, "[spal blockwin stamps] %u blocks, kernel %.1f us; mean us per block: window + first loads %.2f, products %.2f, rows looked at %.2f, "
-                "rows summed %.2f; longest block %.2f\n", a->bw_blocks, (double)(last - first) / 100.0, sum[0] / a->bw_blocks / 100.0,
+        fprintf(stderr, "[spal blockwin stamps] %u blocks, kernel %.1f us; mean us per block: window + first loads %.2f, first pass's products %.2f, phases %.2f, "
+                "heavy rows %.2f; longest block %.2f\n", a->bw_blocks, (double)(last - first) / 100.0, sum[0] / a->bw_blocks / 100.0,
                 sum[1] / a->bw_blocks / 100.0, sum[2] / a->bw_blocks / 100.0, sum[3] / a->bw_blocks / 100.0, tot_max / 100.0);
     }
 #endif
