@@ -39,7 +39,7 @@ constexpr uint32_t kBwRowThreads = SPAL_BW_ROW_WAVES * 64;                  // w
 constexpr uint32_t kBwGroups = (kBwThreads - kBwRowThreads) / 16;           // the other waves: a long row per 16 lanes
 constexpr uint32_t kBwShort = 32;      // rows up to this many entries are summed by one thread, in the reference's order
 constexpr uint32_t kBwLongCap = (kBwPass / (kBwShort + 1) + 4 + 1) & ~1u;   // long rows a pass can touch
-constexpr uint32_t kBwHeavy = 512;     // entries of ONE row inside a pass above which the whole workgroup sums it
+constexpr uint32_t kBwHeavy = 512;     // entries of ONE row inside a pass above which a whole wave sums it (16 lanes below)
 constexpr uint32_t kBwHeavyCap = (kBwPass / (kBwHeavy + 1) + 4 + 1) & ~1u;   // (even: what follows it in LDS is 8-byte aligned)
 constexpr uint32_t kBwListCap = kBwLongCap + kBwHeavyCap;   // one pass's lists: 16-lane rows, then heavy rows
 constexpr uint32_t kBwWinLoads = 8;    // 16-byte loads of the window a thread has in flight at once
@@ -136,23 +136,26 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
     T *xw = reinterpret_cast<T *>(spal_bw_smem);                      // win_cols (a multiple of 256)
     T *sp = xw + win_cols;                                             // [2][kBwPass] products in entry order: pass p in strip p & 1
     T *s_carry = sp + 2 * kBwPass;                                     // [2]: the running sum of the row a pass boundary cut
-    T *s_part = s_carry + 2;                                           // [16]: the waves' partial sums of a heavy row
-    uint32_t *s_rp = reinterpret_cast<uint32_t *>(s_part + 16);        // RB + 1 (+ 1 pad)
+    uint32_t *s_rp = reinterpret_cast<uint32_t *>(s_carry + 2);        // RB + 1 (+ 1 pad)
     uint32_t *s_list = s_rp + RB + 2;                                  // [3][kBwListCap]: pass p's listed rows in list p % 3
     uint32_t *s_n = s_list + 3 * kBwListCap;                           // [3][2]: the lists' lengths {16-lane rows, heavy rows}
 
     // blocks are dealt in the plan's order: XCD k (workgroups k, k + 8, ...) takes the k-th eighth of the blocks -- neighbours
     // share most of their windows and meet in one L2 --, inside it the blocks with the most entries first (a workgroup per CU
     // and four rounds of them: the launch ends with its shortest blocks)
-    const uint32_t blk = order[blockIdx.x];
+    // (everything a workgroup needs to know about its block comes in ONE record, by blockIdx: read one after the other --
+    //  position in the order, then rowptr and the window -- it was two more round trips before the first useful load)
+    const uint4 rec0 = reinterpret_cast<const uint4 *>(order)[blockIdx.x * 2u];        // {block, first entry, one past the last, first column}
+    const uint32_t blk = rec0.x;
     if (blk >= nblocks) return;   // block-uniform (padding of the last round)
+    const uint32_t win_n = order[blockIdx.x * 8u + 4u];                                // columns of the window
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
 #ifdef SPAL_BW_STAMPS
     unsigned long long last_ = wall_clock64(), acc_[4] = {0, 0, 0, 0};
     const unsigned long long first_ = last_;
 #endif
     const uint32_t r0 = blk * RB, nr = min(RB, nrows - r0);
-    const uint32_t e0 = rowptr[r0], e1 = rowptr[r0 + nr];
+    const uint32_t e0 = rec0.y, e1 = rec0.z;
     const uint32_t npass = (e1 - e0 + kBwPass - 1u) / kBwPass;
     // Entries of pass p, requested unconditionally (a pass beyond the block's last reads the last entry again): under
     // conditions the compiler no longer knows how many loads are in flight and waits for ALL of them before the first product.
@@ -173,10 +176,9 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
     }
     for (uint32_t i = t; i <= nr; i += kBwThreads) s_rp[i] = rowptr[r0 + i];
     if (t < 6u) s_n[t] = 0u;
-    const uint2 win = bwin[blk];            // {first column (a multiple of 256), columns}
-    const uint32_t c0 = win.x;
+    const uint32_t c0 = rec0.w;             // first column of the window (a multiple of 256)
     {
-        const uint32_t wn = min(win.y, ncols - min(c0, ncols));
+        const uint32_t wn = min(win_n, ncols - min(c0, ncols));
         if ((reinterpret_cast<uintptr_t>(x + c0) & 15u) == 0) {   // (uniform) 16-byte loads, kBwWinLoads of them in flight per thread
             typedef uint32_t u4 __attribute__((ext_vector_type(4)));
             constexpr uint32_t V = 16 / sizeof(T);
@@ -281,6 +283,22 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
                 else s_carry[parity] = acc;
             }
         } else {
+            // rows with more than kBwHeavy entries in this pass first: a whole wave each (two running sums per lane)
+            for (uint32_t hi = wave - kBwRowThreads / 64u; hi < nheavy; hi += (kBwThreads - kBwRowThreads) / 64u) {   // wave-uniform
+                const uint32_t i = lst[kBwLongCap + hi];
+                const uint32_t rs = s_rp[i], re = s_rp[i + 1];
+                const uint32_t a = max(rs, ps) - ps, b = min(re, pe) - ps;
+                T p0 = T(0), p1 = T(0);
+                uint32_t j = a + lane;
+                for (; j + 64u < b; j += 128u) { p0 = p0 + strip[j]; p1 = p1 + strip[j + 64u]; }
+                if (j < b) p0 = p0 + strip[j];
+                const T part = bw_sum64(p0 + p1);
+                if (lane == 0) {
+                    const T tot = (rs < ps ? s_carry[parity ^ 1u] : T(0)) + part;
+                    if (re <= pe) y[r0 + i] = tot;
+                    else s_carry[parity] = tot;
+                }
+            }
             const uint32_t g = (t - kBwRowThreads) >> 4, gl = t & 15u;
             for (uint32_t li = g; li < nlong; li += kBwGroups) {
                 const uint32_t i = lst[li];
@@ -300,27 +318,6 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
         }
         __syncthreads();
         BW_STAMP(2);
-        {   // rows with more than kBwHeavy entries in this pass: the whole workgroup, one row after the other
-            for (uint32_t hi = 0; hi < nheavy; ++hi) {   // (block-uniform)
-                const uint32_t i = lst[kBwLongCap + hi];
-                const uint32_t rs = s_rp[i], re = s_rp[i + 1];
-                const uint32_t a = max(rs, ps) - ps, b = min(re, pe) - ps;
-                T q = T(0);
-                for (uint32_t j = a + t; j < b; j += kBwThreads) q = q + strip[j];
-                q = bw_sum64(q);
-                if (lane == 0) s_part[wave] = q;
-                __syncthreads();
-                if (wave == 0) {
-                    const T tot16 = bw_sum16(lane < 16u ? s_part[lane] : T(0));
-                    if (lane == 0) {
-                        const T tot = (rs < ps ? s_carry[parity ^ 1u] : T(0)) + tot16;
-                        if (re <= pe) y[r0 + i] = tot;
-                        else s_carry[parity] = tot;
-                    }
-                }
-                __syncthreads();   // (s_part is written again by the next heavy row; the strip by the next phase)
-            }
-        }
         BW_STAMP(3);
         cur_lo = nxt_lo;
         cur_hi = nxt_hi;
@@ -338,7 +335,7 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
 }
 
 static size_t bw_lds_bytes(uint32_t RB, uint32_t win_cols, size_t esz) {
-    return (size_t)win_cols * esz + 2 * (size_t)kBwPass * esz + (2 + 16) * esz + (size_t)(RB + 2 + 3 * kBwListCap + 6) * 4;
+    return (size_t)win_cols * esz + 2 * (size_t)kBwPass * esz + 2 * esz + (size_t)(RB + 2 + 3 * kBwListCap + 6) * 4;
 }
 
 void blockwin_free(spal_csr *a) {
@@ -382,7 +379,7 @@ int blockwin_plan(spal_csr *a) {
         const uint32_t win_cols = std::max(256u, (widest + 255u) & ~255u);
         if (bw_lds_bytes(RB, win_cols, esz) > kBwLdsMax) continue;
         const uint32_t per_xcd = (nb + 7u) / 8u;
-        std::vector<uint32_t> order((size_t)per_xcd * 8u, 0xffffffffu), part;
+        std::vector<uint32_t> order((size_t)per_xcd * 8u, 0xffffffffu), part, rec((size_t)per_xcd * 8u * 8u, 0xffffffffu);
         auto entries = [&](uint32_t b) { return first[std::min(nunits, (b + 1) * units)] - first[b * units]; };
         for (uint32_t k = 0; k < 8u; ++k) {
             part.clear();
@@ -390,10 +387,17 @@ int blockwin_plan(spal_csr *a) {
             std::stable_sort(part.begin(), part.end(), [&](uint32_t p, uint32_t q) { return entries(p) > entries(q); });
             for (size_t i = 0; i < part.size(); ++i) order[i * 8u + k] = part[i];
         }
+        for (size_t i = 0; i < order.size(); ++i) {   // 32-byte records in dealing order
+            const uint32_t b = order[i];
+            if (b == 0xffffffffu) continue;
+            uint32_t *r = &rec[i * 8u];
+            r[0] = b; r[1] = first[b * units]; r[2] = first[std::min(nunits, (b + 1) * units)]; r[3] = bw[b].x; r[4] = bw[b].y;
+            r[5] = r[6] = r[7] = 0u;
+        }
         SPAL_HIP_TRY(dev_alloc((void **)&a->d_bwin, (size_t)nb * sizeof(uint2)));
-        SPAL_HIP_TRY(dev_alloc((void **)&a->d_bworder, order.size() * 4));
+        SPAL_HIP_TRY(dev_alloc((void **)&a->d_bworder, rec.size() * 4));
         SPAL_HIP_TRY(hipMemcpy(a->d_bwin, bw.data(), (size_t)nb * sizeof(uint2), hipMemcpyHostToDevice));
-        SPAL_HIP_TRY(hipMemcpy(a->d_bworder, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+        SPAL_HIP_TRY(hipMemcpy(a->d_bworder, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
         a->bw_blocks = nb;
         a->bw_rows = RB;
         a->bw_cols = win_cols;
@@ -442,7 +446,7 @@ static hipError_t bw_launch_t(const spal_csr *a, const void *x, void *y, hipStre
             last = std::max(last, h[(size_t)b * 8 + 7] + (unsigned long long)tot);
         }
         fprintf(stderr, "[spal blockwin stamps] %u blocks, kernel %.1f us; mean us per block: window + first loads %.2f, first pass's products %.2f, phases %.2f, "
-                "heavy rows %.2f; longest block %.2f\n", a->bw_blocks, (double)(last - first) / 100.0, sum[0] / a->bw_blocks / 100.0,
+                "(unused) %.2f; longest block %.2f\n", a->bw_blocks, (double)(last - first) / 100.0, sum[0] / a->bw_blocks / 100.0,
                 sum[1] / a->bw_blocks / 100.0, sum[2] / a->bw_blocks / 100.0, sum[3] / a->bw_blocks / 100.0, tot_max / 100.0);
     }
 #endif

@@ -233,7 +233,7 @@ struct spal_csr {
     int split_child = 0;           // this handle IS the short part of a split (never splits again)
     // BLOCK WINDOW kernel (spal_csr_blockwin.hip): {first column, columns} of every block of bw_rows rows; bw_on: the products run it
     uint2 *d_bwin = nullptr;
-    uint32_t *d_bworder = nullptr; // the blocks in the order they are dealt to the workgroups (most entries first)
+    uint32_t *d_bworder = nullptr; // 32-byte records {block, first entry, one past the last, window's first column, columns, -, -, -} in the order the blocks are dealt
     uint32_t bw_blocks = 0, bw_rows = 0, bw_cols = 0;
     int bw_on = 0;
     float bw_us[2] = {0.f, 0.f};   // setup: per product {what it was timed against, the block-window kernel}
