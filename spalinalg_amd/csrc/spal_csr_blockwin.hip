@@ -6,16 +6,25 @@
 // what a lane may sum sends the tile elsewhere.  Power-law row lengths (mean 10, 0.7 % of the rows above 128 entries holding a
 // fifth of the entries) made that 0.18 of the roofline; the row split (A = A_short + A_long) 0.255: its short part still
 // walks ragged tiles, its long rows gather x through the vector memory path (~4 clocks per gathered line and CU).  Here the
-// ENTRIES are the unit of work, whatever row they belong to:
+// ENTRIES are the unit of work, whatever row they belong to (0.45 - 0.46 on the same matrix):
 //   * a workgroup of 1024 threads takes a block of RB consecutive rows (512 ... 4096, the plan's choice) whose columns span at
-//     most what LDS holds beside the rest (14 336 columns of f64): the window of x is staged ONCE per block -- every gather of
-//     the block, short row or long, is an LDS read;
-//   * the block's entries go by in passes of 4096 (four per thread, coalesced, the next pass's loads in flight): every entry's
-//     product -- rounded once, as in the reference -- lands in a strip in LDS in entry order;
-//   * the rows that a pass touches are found from the block's rowptr (LDS): a row of at most kBwShort entries is summed by ONE
-//     thread, left to right, continuing from the carry when the pass boundary cut it -- the reference's order of additions,
-//     bit for bit; a longer row by a wave (strided partial sums, a shuffle tree: 1e-10), carried across passes the same way.
+//     most what LDS holds beside the rest (~12 000 columns of f64): the window of x is staged ONCE per block -- every gather of
+//     the block, short row or long, is an LDS read.  Blocks are dealt by XCD (an eighth of the matrix each: neighbours share
+//     most of their windows and one L2) and, inside an XCD, most entries first; all a workgroup needs to know about its block
+//     is one 32-byte record;
+//   * the block's entries go by in passes of kBwPass = 3072 (three per thread, coalesced, requested two passes ahead and
+//     unconditionally, so that the waits are counted): every entry's product -- rounded once, as in the reference -- lands in
+//     one of two strips in LDS in entry order;
+//   * ONE phase and one barrier per pass: while pass p's rows are summed out of strip p & 1, pass p + 1's products go into
+//     the other strip and its rows are looked at (three rotating lists of the rows that are not one thread's business);
+//   * rows: the first eight waves take a row per thread -- a row of at most kBwShort = 32 entries is summed by ONE thread,
+//     left to right, continuing from the carry when the pass boundary cut it: the reference's order of additions, bit for bit;
+//     the other eight waves take the listed rows, 16 lanes per row (a whole wave above 512 entries inside the pass): strided
+//     partial sums and a DPP tree (1e-10), carried across passes the same way.
 // One row is open at the end of a pass at most; its running sum waits in one of two carry slots (by pass parity).
+// What bounds it (lab build -DSPAL_BW_STAMPS, per block of 20.9K entries: window + first loads 4.4 us, phases 13 us): LDS --
+// one gather, one strip write and one strip read per entry plus the conflicts of the threads' row walks are ~1 clock per entry
+// of the CU's one LDS pipe -- and the window, staged behind a barrier by the CU's only workgroup.
 // Chosen at setup by time against the row split (spal_csr.hip: csr_plan_build); option "blockwin" -1 / 0 / 1.
 #include <algorithm>
 #include <atomic>
@@ -129,7 +138,7 @@ __device__ unsigned long long *g_bw_stamps = nullptr;
 template <typename T>
 __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
                                                                 const T *__restrict__ vals, const T *__restrict__ x, T *__restrict__ y,
-                                                                const uint2 *__restrict__ bwin, const uint32_t *__restrict__ order,
+                                                                const uint32_t *__restrict__ order,
                                                                 uint32_t nrows, uint32_t ncols, uint32_t RB, uint32_t nblocks,
                                                                 uint32_t win_cols) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_bw_smem[];
@@ -340,7 +349,6 @@ static size_t bw_lds_bytes(uint32_t RB, uint32_t win_cols, size_t esz) {
 
 void blockwin_free(spal_csr *a) {
     a->bw_on = 0;
-    (void)dev_free(a->d_bwin); a->d_bwin = nullptr;
     (void)dev_free(a->d_bworder); a->d_bworder = nullptr;
     a->bw_blocks = 0; a->bw_rows = 0; a->bw_cols = 0;
 }
@@ -394,9 +402,7 @@ int blockwin_plan(spal_csr *a) {
             r[0] = b; r[1] = first[b * units]; r[2] = first[std::min(nunits, (b + 1) * units)]; r[3] = bw[b].x; r[4] = bw[b].y;
             r[5] = r[6] = r[7] = 0u;
         }
-        SPAL_HIP_TRY(dev_alloc((void **)&a->d_bwin, (size_t)nb * sizeof(uint2)));
         SPAL_HIP_TRY(dev_alloc((void **)&a->d_bworder, rec.size() * 4));
-        SPAL_HIP_TRY(hipMemcpy(a->d_bwin, bw.data(), (size_t)nb * sizeof(uint2), hipMemcpyHostToDevice));
         SPAL_HIP_TRY(hipMemcpy(a->d_bworder, rec.data(), rec.size() * 4, hipMemcpyHostToDevice));
         a->bw_blocks = nb;
         a->bw_rows = RB;
@@ -429,7 +435,7 @@ static hipError_t bw_launch_t(const spal_csr *a, const void *x, void *y, hipStre
     (void)hipMemsetAsync(d_st, 0, (size_t)a->bw_blocks * 64, st);
 #endif
     hipLaunchKernelGGL(csr_spmv_blockwin<T>, dim3((a->bw_blocks + 7u) / 8u * 8u), dim3(kBwThreads), lds, st, a->d_rowptr, a->d_colind,
-                       (const T *)a->d_values, (const T *)x, (T *)y, a->d_bwin, a->d_bworder, (uint32_t)a->nrows, (uint32_t)a->ncols,
+                       (const T *)a->d_values, (const T *)x, (T *)y, a->d_bworder, (uint32_t)a->nrows, (uint32_t)a->ncols,
                        a->bw_rows, a->bw_blocks, a->bw_cols);
 #ifdef SPAL_BW_STAMPS
     if (++calls % 16 == 0) {

@@ -231,8 +231,7 @@ struct spal_csr {
     uint32_t split_nlong = 0, split_nheavy = 0;   // listed rows (longest first); the first split_nheavy hold more than 1024 entries
     uint64_t split_long_entries = 0;
     int split_child = 0;           // this handle IS the short part of a split (never splits again)
-    // BLOCK WINDOW kernel (spal_csr_blockwin.hip): {first column, columns} of every block of bw_rows rows; bw_on: the products run it
-    uint2 *d_bwin = nullptr;
+    // BLOCK WINDOW kernel (spal_csr_blockwin.hip): blocks of bw_rows rows, a window of at most bw_cols columns each; bw_on: the products run it
     uint32_t *d_bworder = nullptr; // 32-byte records {block, first entry, one past the last, window's first column, columns, -, -, -} in the order the blocks are dealt
     uint32_t bw_blocks = 0, bw_rows = 0, bw_cols = 0;
     int bw_on = 0;
