@@ -140,8 +140,13 @@ int spal_csr_download_f32(spal_csr_t a, uint64_t *rowptr, uint64_t *colind,
  * (-1 auto / 0 / 1: the column-blocked kernels for columns anywhere),
  * "cblock_form" (-1 by the entries a row holds per column block / 0 entry-
  * parallel / 1 rows form), "cblock_rows", "cblock_shift" (0 auto; rows of a row
- * block, log2 of the columns of a column block).  Unknown key or a value
- * the kernels are not instantiated for: SPAL_ERR_INVALID_ARGUMENT. */
+ * block, log2 of the columns of a column block); "row_split" (-1 auto / 0 / 1:
+ * skewed row lengths -- rows above "row_split_threshold" entries, default 128,
+ * are multiplied apart from the rest), "blockwin" (-1 / 0 / 1: the block-window
+ * kernel for skewed rows whose columns stay near the rows -- -1: timed against
+ * the row split at setup, 1: whenever every row block's window of x fits LDS).
+ * Unknown key or a value the kernels are not instantiated for:
+ * SPAL_ERR_INVALID_ARGUMENT. */
 int spal_csr_set_option(spal_csr_t a, const char *key, int64_t value);
 /* Setup-time autotune: runs the planned kernel's variants (the stream kernel
  * with one workgroup per super-tile vs. its walking form -- the sliding-window

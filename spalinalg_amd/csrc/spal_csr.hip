@@ -2089,8 +2089,9 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
     }
     // ---- 1. the form.  candidate c: bit 0 = walking form (sliding kernel / persistent), bit 1 = non-temporal y stores
     const bool walking_is_slide = p.slide != 0;
-    int best = ((walking_is_slide ? p.slide_on : p.persistent) ? 1 : 0) | (p.nt_store ? 2 : 0);
-    float best_ms = 1e30f;
+    const int planned = ((walking_is_slide ? p.slide_on : p.persistent) ? 1 : 0) | (p.nt_store ? 2 : 0);   // what the plan chose by structure
+    int best = planned;
+    float best_ms = 1e30f, planned_ms = 1e30f;
     for (int round = 0; round < 2 && rc == SPAL_OK; ++round) {      // round 0 also settles the clocks
         for (int cand = 0; cand < 4 && rc == SPAL_OK; ++cand) {
             if (walking_is_slide) { p.slide_on = cand & 1; p.slide_fill_ok = 1; p.persistent = 0; }
@@ -2101,9 +2102,13 @@ static int csr_autotune(spal_csr_t a, const T *x_dev, T *y_dev, void *stream, in
             if (rc == SPAL_OK && round == 1) {
                 a->tuned_us[cand] = ms * 1e3f;
                 if (ms < best_ms) { best_ms = ms; best = cand; }
+                if (cand == planned) planned_ms = ms;
             }
         }
     }
+    // (a form has to beat the planned one by 1 %: at config 3 the two forms measure within 0.1 us of each other on some boxes,
+    //  and the one-super-tile form picked on such a margin then ran 4 % slower over the timed launches than the sliding form does)
+    if (planned_ms <= 1.01f * best_ms) best = planned;
     if (walking_is_slide) { p.slide_on = best & 1; p.slide_fill_ok = 1; p.persistent = 0; }
     else p.persistent = best & 1;
     p.user_persistent = true;   // measured: a later re-plan keeps it
