@@ -135,7 +135,9 @@ __device__ unsigned long long *g_bw_stamps = nullptr;
 #define BW_STAMP(i) do { } while (0)
 #endif
 
-template <typename T>
+// WIN = false: no block's window fits LDS (columns anywhere) -- the same passes, strips and row sums, x gathered from global
+// memory / L2 one phase ahead of its product (three register sets take turns instead of two).
+template <typename T, bool WIN>
 __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
                                                                 const T *__restrict__ vals, const T *__restrict__ x, T *__restrict__ y,
                                                                 const uint32_t *__restrict__ order,
@@ -168,25 +170,30 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
     const uint32_t npass = (e1 - e0 + kBwPass - 1u) / kBwPass;
     // Entries of pass p, requested unconditionally (a pass beyond the block's last reads the last entry again): under
     // conditions the compiler no longer knows how many loads are in flight and waits for ALL of them before the first product.
-    uint32_t ca[kBwItems], cb[kBwItems];
-    T va[kBwItems], vb[kBwItems];
-    auto load_pass = [&](uint32_t p, uint32_t (&c)[kBwItems], T (&v)[kBwItems]) {
+    struct Set { uint32_t c[kBwItems]; T v[kBwItems]; T xg[kBwItems]; };   // a pass's entries (and, WIN = false, their x)
+    Set sa, sb, sc;
+    auto load_pass = [&](uint32_t p, Set &q) {
         const uint32_t last = e1 > e0 ? e1 - 1u : 0u;
 #pragma unroll
         for (uint32_t k = 0; k < kBwItems; ++k) {
             const uint32_t idx = min(e0 + min(p, npass) * kBwPass + k * kBwThreads + t, last);
-            c[k] = colind[idx];
-            v[k] = vals[idx];
+            q.c[k] = colind[idx];
+            q.v[k] = vals[idx];
         }
     };
+    auto gather = [&](Set &q) {   // (WIN = false) x of the set's entries, through the vector memory path
+#pragma unroll
+        for (uint32_t k = 0; k < kBwItems; ++k) q.xg[k] = x[q.c[k]];
+    };
     if (e1 > e0) {   // (block-uniform; a block without entries only zeroes its rows)
-        load_pass(0, ca, va);
-        load_pass(1, cb, vb);
+        load_pass(0, sa);
+        load_pass(1, sb);
+        if (!WIN) load_pass(2, sc);
     }
     for (uint32_t i = t; i <= nr; i += kBwThreads) s_rp[i] = rowptr[r0 + i];
     if (t < 6u) s_n[t] = 0u;
     const uint32_t c0 = rec0.w;             // first column of the window (a multiple of 256)
-    {
+    if (WIN) {
         const uint32_t wn = min(win_n, ncols - min(c0, ncols));
         if ((reinterpret_cast<uintptr_t>(x + c0) & 15u) == 0) {   // (uniform) 16-byte loads, kBwWinLoads of them in flight per thread
             typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -222,13 +229,13 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
 
     // the products of pass p, into strip p & 1 (all gathers first: window and strip are both LDS, a write between two reads
     // keeps them in order; written unconditionally: places beyond the pass's end are never read)
-    auto products = [&](uint32_t p, const uint32_t (&c)[kBwItems], const T (&v)[kBwItems]) {
+    auto products = [&](uint32_t p, const Set &q) {
         T *strip = sp + (p & 1u) * kBwPass;
         T xv[kBwItems];
 #pragma unroll
-        for (uint32_t k = 0; k < kBwItems; ++k) xv[k] = xw[c[k] - c0];
+        for (uint32_t k = 0; k < kBwItems; ++k) xv[k] = WIN ? xw[q.c[k] - c0] : q.xg[k];
 #pragma unroll
-        for (uint32_t k = 0; k < kBwItems; ++k) strip[k * kBwThreads + t] = v[k] * xv[k];   // one rounding, as `val * x[col]` in the reference
+        for (uint32_t k = 0; k < kBwItems; ++k) strip[k * kBwThreads + t] = q.v[k] * xv[k];   // one rounding, as `val * x[col]` in the reference
     };
     // the rows lo ... hi - 1 may hold entries of pass p = [ps, pe): those of more than kBwShort entries go on pass p's lists
     auto classify = [&](uint32_t p, uint32_t lo, uint32_t hi) {
@@ -246,20 +253,27 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
 
     // prologue: pass 0's products and lists
     uint32_t cur_lo = 0, cur_hi = bw_first_at_least(s_rp, 0u, nr, min(e0 + kBwPass, e1), lane);
-    products(0, ca, va);
+    if (!WIN) { gather(sa); gather(sb); }
+    products(0, sa);
     classify(0, cur_lo, cur_hi);
     __syncthreads();
     BW_STAMP(1);
     // One PHASE per pass, one barrier per phase: while pass p's rows are summed out of strip p & 1, pass p + 1's products go
     // into the other strip (their entries were requested a phase ago), its rows are looked at and listed, and pass p + 2's
     // entries are requested.  (First form: products | barrier | rows looked at | barrier | rows summed | barrier per pass.)
-    auto phase = [&](uint32_t p, uint32_t (&cn)[kBwItems], T (&vn)[kBwItems], uint32_t (&cf)[kBwItems], T (&vf)[kBwItems]) {
-        // (cn, vn): pass p + 1's entries, in registers since the last phase; (cf, vf): free, takes pass p + 2's
+    auto phase = [&](uint32_t p, Set &s1, Set &s2, Set &s3) {
+        // WIN: s1 = pass p + 1's entries, in registers since the last phase; s2 = free, takes pass p + 2's (s3 unused).
+        // else: s1 = pass p + 1's entries and their x; s2 = pass p + 2's entries, their x is gathered now; s3 takes pass p + 3's.
         const uint32_t ps = e0 + p * kBwPass, pe = min(ps + kBwPass, e1), parity = p & 1u;
         const T *strip = sp + parity * kBwPass;
         uint32_t nxt_lo = 0, nxt_hi = 0;
-        products(p + 1u, cn, vn);           // (beyond the last pass: of the last entry again, into the strip nobody reads)
-        load_pass(p + 2u, cf, vf);
+        products(p + 1u, s1);               // (beyond the last pass: of the last entry again, into the strip nobody reads)
+        if (WIN) {
+            load_pass(p + 2u, s2);
+        } else {
+            gather(s2);
+            load_pass(p + 3u, s3);
+        }
         if (p + 1u < npass) {               // (block-uniform)
             nxt_lo = s_rp[cur_hi] == pe ? cur_hi : cur_hi - 1u;   // the row that holds entry pe (cur_hi >= 1: rp[0] = e0 < pe)
             nxt_hi = bw_first_at_least(s_rp, nxt_lo, nr, min(pe + kBwPass, e1), lane);
@@ -331,9 +345,17 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
         cur_lo = nxt_lo;
         cur_hi = nxt_hi;
     };
-    for (uint32_t p = 0; p < npass; p += 2u) {   // (block-uniform) the two register sets take turns
-        phase(p, cb, vb, ca, va);
-        if (p + 1u < npass) phase(p + 1u, ca, va, cb, vb);
+    if (WIN) {
+        for (uint32_t p = 0; p < npass; p += 2u) {   // (block-uniform) two register sets take turns
+            phase(p, sb, sa, sc);
+            if (p + 1u < npass) phase(p + 1u, sa, sb, sc);
+        }
+    } else {
+        for (uint32_t p = 0; p < npass; p += 3u) {   // (block-uniform) three register sets take turns
+            phase(p, sb, sc, sa);
+            if (p + 1u < npass) phase(p + 1u, sc, sa, sb);
+            if (p + 2u < npass) phase(p + 2u, sa, sb, sc);
+        }
     }
 #ifdef SPAL_BW_STAMPS
     if (t == 0 && g_bw_stamps) {
@@ -371,7 +393,10 @@ int blockwin_plan(spal_csr *a) {
     SPAL_HIP_TRY(hipMemcpyAsync(first.data(), d_first.p, first.size() * 4, hipMemcpyDeviceToHost, a->stream));
     SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
     const size_t esz = (size_t)a->elem_size;
-    for (uint32_t units = 8; units >= 1; units >>= 1) {
+    // units = 8, 4, 2, 1 with the window in LDS; when none fits (columns anywhere): blocks of 2048 rows, x gathered from memory
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        const bool windowed = attempt < 4;
+        const uint32_t units = windowed ? (8u >> attempt) : 4u;
         const uint32_t RB = units * kBwUnit;
         const uint32_t nb = (uint32_t)((a->nrows + RB - 1) / RB);
         std::vector<uint2> bw(nb);
@@ -384,7 +409,7 @@ int blockwin_plan(spal_csr *a) {
             bw[b] = make_uint2(c0, hi - c0);
             widest = std::max(widest, hi - c0);
         }
-        const uint32_t win_cols = std::max(256u, (widest + 255u) & ~255u);
+        const uint32_t win_cols = windowed ? std::max(256u, (widest + 255u) & ~255u) : 0u;
         if (bw_lds_bytes(RB, win_cols, esz) > kBwLdsMax) continue;
         const uint32_t per_xcd = (nb + 7u) / 8u;
         std::vector<uint32_t> order((size_t)per_xcd * 8u, 0xffffffffu), part, rec((size_t)per_xcd * 8u * 8u, 0xffffffffu);
@@ -412,12 +437,12 @@ int blockwin_plan(spal_csr *a) {
     return SPAL_OK;
 }
 
-template <typename T>
+template <typename T, bool WIN>
 static hipError_t bw_launch_t(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     static std::atomic<uint64_t> configured{0};   // devices on which this instantiation's LDS cap has been raised
     const uint64_t bit = 1ull << (a->device & 63);
     if (!(configured.load(std::memory_order_relaxed) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(csr_spmv_blockwin<T>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(csr_spmv_blockwin<T, WIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwLdsMax);
         if (e != hipSuccess) return e;
         configured.fetch_or(bit, std::memory_order_relaxed);
@@ -434,7 +459,7 @@ static hipError_t bw_launch_t(const spal_csr *a, const void *x, void *y, hipStre
     }
     (void)hipMemsetAsync(d_st, 0, (size_t)a->bw_blocks * 64, st);
 #endif
-    hipLaunchKernelGGL(csr_spmv_blockwin<T>, dim3((a->bw_blocks + 7u) / 8u * 8u), dim3(kBwThreads), lds, st, a->d_rowptr, a->d_colind,
+    hipLaunchKernelGGL((csr_spmv_blockwin<T, WIN>), dim3((a->bw_blocks + 7u) / 8u * 8u), dim3(kBwThreads), lds, st, a->d_rowptr, a->d_colind,
                        (const T *)a->d_values, (const T *)x, (T *)y, a->d_bworder, (uint32_t)a->nrows, (uint32_t)a->ncols,
                        a->bw_rows, a->bw_blocks, a->bw_cols);
 #ifdef SPAL_BW_STAMPS
@@ -460,7 +485,8 @@ static hipError_t bw_launch_t(const spal_csr *a, const void *x, void *y, hipStre
 }
 
 hipError_t blockwin_launch(const spal_csr *a, const void *x, void *y, hipStream_t st) {
-    return a->elem_size == 8 ? bw_launch_t<double>(a, x, y, st) : bw_launch_t<float>(a, x, y, st);
+    if (a->bw_cols) return a->elem_size == 8 ? bw_launch_t<double, true>(a, x, y, st) : bw_launch_t<float, true>(a, x, y, st);
+    return a->elem_size == 8 ? bw_launch_t<double, false>(a, x, y, st) : bw_launch_t<float, false>(a, x, y, st);
 }
 
 }  // namespace spal

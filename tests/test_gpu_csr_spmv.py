@@ -1192,13 +1192,23 @@ def test_block_window_kernel_on_power_law_rows(oracle, dtype):
     assert_spmv_close(dev.spmv(x), y_ref, bound, tol)
     dev.set_option("blockwin", 0)
     assert dev.describe()["kernel"] == "split"
-    # columns anywhere: no window fits, the request by name falls back to what the plan would have run
-    ci2 = np.sort(rng.integers(0, n, size=(2000, 8)), axis=1)
-    ci2 += np.arange(8)                              # (strictly ascending inside a row)
-    rp2 = (np.arange(2001) * 8).astype(np.uint64)
-    far = sp.CsrMatrix(2000, n + 8, rp2, ci2.reshape(-1).astype(np.uint64), rng.uniform(-1, 1, 16000).astype(dtype)).device()
+    # columns anywhere: no window fits LDS -- the same passes and row sums with x gathered from memory (window_columns 0)
+    lens2 = np.minimum((rng.pareto(1.6, 6000) * 6 + 1).astype(np.int64), 3000)
+    rows2 = np.repeat(np.arange(6000, dtype=np.int64), lens2)
+    key2 = np.unique(rows2 * (n + 8) + rng.integers(0, n + 8, rows2.size))
+    r3, c3 = key2 // (n + 8), key2 % (n + 8)
+    rp2 = np.concatenate([[0], np.cumsum(np.bincount(r3, minlength=6000))]).astype(np.uint64)
+    va2 = rng.uniform(-1, 1, c3.size).astype(dtype)
+    x2 = rng.uniform(-1, 1, n + 8).astype(dtype)
+    far = sp.CsrMatrix(6000, n + 8, rp2, c3.astype(np.uint64), va2).device()
     far.set_option("blockwin", 1)
-    assert far.describe()["kernel"] != "blockwin"
+    df = far.describe()
+    assert df["kernel"] == "blockwin" and df["window_columns"] == 0, df
+    y2 = far.spmv(x2)
+    y2_ref = oracle.csr_spmv(rp2, c3.astype(np.uint64), va2, x2)
+    assert_spmv_close(y2, y2_ref, oracle.csr_abs_bound(rp2, c3.astype(np.uint64), va2.astype(np.float64), x2.astype(np.float64)), tol)
+    rl2 = np.diff(rp2.astype(np.int64))
+    assert np.array_equal(y2[rl2 <= 32].view(bits), y2_ref[rl2 <= 32].view(bits))
 
 
 def test_device_copy_is_a_handle_of_its_own(oracle):
