@@ -137,12 +137,17 @@ __device__ unsigned long long *g_bw_stamps = nullptr;
 
 // WIN = false: no block's window fits LDS (columns anywhere) -- the same passes, strips and row sums, x gathered from global
 // memory / L2 one phase ahead of its product (three register sets take turns instead of two).
-template <typename T, bool WIN>
+// PRE (WIN, x 16-byte aligned): a workgroup walks its blocks with the NEXT block's window and row pointers on their way into
+// registers (kBwWinRegs 16-byte vectors and kBwRpRegs words per thread) while the current block's passes go by: between two blocks
+// they are written to LDS instead of being waited for behind a barrier (4.4 of a block's 18.4 us).
+constexpr uint32_t kBwWinRegs = 7;   // 7 x 16 bytes x 1024 threads = 112 KB of window
+constexpr uint32_t kBwRpRegs = 5;    // 5 x 1024 words >= 4097 row pointers
+template <typename T, bool WIN, bool PRE>
 __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ colind,
                                                                 const T *__restrict__ vals, const T *__restrict__ x, T *__restrict__ y,
                                                                 const uint32_t *__restrict__ order,
                                                                 uint32_t nrows, uint32_t ncols, uint32_t RB, uint32_t nblocks,
-                                                                uint32_t win_cols) {
+                                                                uint32_t win_cols, uint32_t per_xcd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char spal_bw_smem[];
     T *xw = reinterpret_cast<T *>(spal_bw_smem);                      // win_cols (a multiple of 256)
     T *sp = xw + win_cols;                                             // [2][kBwPass] products in entry order: pass p in strip p & 1
@@ -156,15 +161,50 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
     // and four rounds of them: the launch ends with its shortest blocks)
     // (everything a workgroup needs to know about its block comes in ONE record, by blockIdx: read one after the other --
     //  position in the order, then rowptr and the window -- it was two more round trips before the first useful load)
-    const uint4 rec0 = reinterpret_cast<const uint4 *>(order)[blockIdx.x * 2u];        // {block, first entry, one past the last, first column}
-    const uint32_t blk = rec0.x;
-    if (blk >= nblocks) return;   // block-uniform (padding of the last round)
-    const uint32_t win_n = order[blockIdx.x * 8u + 4u];                                // columns of the window
+    // A RESIDENT grid (8 x J workgroups, J <= CUs per XCD): workgroup w walks the records (w >> 3) + i * J of XCD w & 7's list,
+    // which the plan lays out so that every walk holds a block of every size class (longest first, dealt back and forth).
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t xcd = blockIdx.x & 7u, J = gridDim.x >> 3;
+    uint32_t slot = blockIdx.x >> 3;
+    if (slot >= per_xcd) return;
+    uint4 rec0 = reinterpret_cast<const uint4 *>(order)[(slot * 8u + xcd) * 2u];       // {block, first entry, one past the last, first column}
+    uint32_t win_n = order[(slot * 8u + xcd) * 8u + 4u];                               // columns of the window
+    if (rec0.x >= nblocks) return;   // block-uniform (the XCD's list is padded at its end)
 #ifdef SPAL_BW_STAMPS
     unsigned long long last_ = wall_clock64(), acc_[4] = {0, 0, 0, 0};
     const unsigned long long first_ = last_;
+    uint32_t nblk_ = 0;
 #endif
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 wr[kBwWinRegs];
+    uint32_t rpr[kBwRpRegs];
+    // (unconditional, clamped: the counted waits of the passes' loads must not depend on a branch)
+    auto prefetch_block = [&](const uint4 &rec, uint32_t wn_cols) {
+        constexpr uint32_t V = 16 / sizeof(T);
+        const uint32_t wn = min(wn_cols, ncols - min(rec.w, ncols));
+        const uint32_t nvec = max((wn + V - 1u) / V, 1u);
+        const u4 *xs = reinterpret_cast<const u4 *>(x + rec.w);
+        // (the last vector of a window that ends at the matrix's last column may reach past x by one element: clamped below)
+        const uint32_t safe = (ncols - min(rec.w, ncols)) / V;   // whole vectors of x from the window's first column
+#pragma unroll
+        for (uint32_t k = 0; k < kBwWinRegs; ++k) wr[k] = xs[min(min(k * kBwThreads + t, nvec - 1u), safe ? safe - 1u : 0u)];
+        const uint32_t rb0 = rec.x * RB, nrb = min(RB, nrows - rb0);
+#pragma unroll
+        for (uint32_t k = 0; k < kBwRpRegs; ++k) rpr[k] = rowptr[rb0 + min(k * kBwThreads + t, nrb)];
+    };
+    if (PRE) prefetch_block(rec0, win_n);
+  for (;;) {   // the workgroup's blocks
+    const uint32_t blk = rec0.x;
+    const uint32_t nslot = slot + J;
+    uint4 rec1 = rec0;
+    uint32_t win_n1 = win_n;
+    bool has_next = false;
+    if (nslot < per_xcd) {   // (block-uniform)
+        rec1 = reinterpret_cast<const uint4 *>(order)[(nslot * 8u + xcd) * 2u];
+        win_n1 = order[(nslot * 8u + xcd) * 8u + 4u];
+        has_next = rec1.x < nblocks;
+        if (!has_next) { rec1 = rec0; win_n1 = win_n; }
+    }
     const uint32_t r0 = blk * RB, nr = min(RB, nrows - r0);
     const uint32_t e0 = rec0.y, e1 = rec0.z;
     const uint32_t npass = (e1 - e0 + kBwPass - 1u) / kBwPass;
@@ -185,15 +225,28 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
 #pragma unroll
         for (uint32_t k = 0; k < kBwItems; ++k) q.xg[k] = x[q.c[k]];
     };
-    if (e1 > e0) {   // (block-uniform; a block without entries only zeroes its rows)
-        load_pass(0, sa);
-        load_pass(1, sb);
-        if (!WIN) load_pass(2, sc);
+    load_pass(0, sa);   // (a block without entries reads the matrix's first entry: unconditional, like every load here)
+    load_pass(1, sb);
+    if (!WIN) load_pass(2, sc);
+    if (PRE) {
+#pragma unroll
+        for (uint32_t k = 0; k < kBwRpRegs; ++k)
+            if (k * kBwThreads + t <= nr) s_rp[k * kBwThreads + t] = rpr[k];
+    } else {
+        for (uint32_t i = t; i <= nr; i += kBwThreads) s_rp[i] = rowptr[r0 + i];
     }
-    for (uint32_t i = t; i <= nr; i += kBwThreads) s_rp[i] = rowptr[r0 + i];
     if (t < 6u) s_n[t] = 0u;
     const uint32_t c0 = rec0.w;             // first column of the window (a multiple of 256)
-    if (WIN) {
+    if (PRE) {   // the window is in registers (requested a block ago, or at the kernel's start)
+        constexpr uint32_t V = 16 / sizeof(T);
+        const uint32_t wn = min(win_n, ncols - min(c0, ncols));
+        const uint32_t nvec = wn / V;
+        u4 *xd = reinterpret_cast<u4 *>(xw);
+#pragma unroll
+        for (uint32_t k = 0; k < kBwWinRegs; ++k)
+            if (k * kBwThreads + t < nvec) xd[k * kBwThreads + t] = wr[k];
+        for (uint32_t i = nvec * V + t; i < wn; i += kBwThreads) xw[i] = x[c0 + i];   // (a window that ends inside a vector)
+    } else if (WIN) {
         const uint32_t wn = min(win_n, ncols - min(c0, ncols));
         if ((reinterpret_cast<uintptr_t>(x + c0) & 15u) == 0) {   // (uniform) 16-byte loads, kBwWinLoads of them in flight per thread
             typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -223,9 +276,10 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
     }
     __syncthreads();
     BW_STAMP(0);
+    if (PRE) prefetch_block(rec1, win_n1);   // (the next block's -- this block's again when there is none: unconditional)
     for (uint32_t i = t; i < nr; i += kBwThreads)   // empty rows: nothing below writes them
         if (s_rp[i + 1] == s_rp[i]) y[r0 + i] = T(0);
-    if (e1 == e0) return;   // block-uniform
+    if (e1 != e0) {   // block-uniform (a block without entries: its rows are zeroed, that is all)
 
     // the products of pass p, into strip p & 1 (all gathers first: window and strip are both LDS, a write between two reads
     // keeps them in order; written unconditionally: places beyond the pass's end are never read)
@@ -357,10 +411,22 @@ __global__ __launch_bounds__(kBwThreads) void csr_spmv_blockwin(const uint32_t *
             if (p + 2u < npass) phase(p + 2u, sa, sb, sc);
         }
     }
+    } else {
+        __syncthreads();   // (s_rp and the counters are written again by the next block)
+    }
+#ifdef SPAL_BW_STAMPS
+    ++nblk_;
+#endif
+    if (!has_next) break;
+    rec0 = rec1;
+    win_n = win_n1;
+    slot = nslot;
+  }
 #ifdef SPAL_BW_STAMPS
     if (t == 0 && g_bw_stamps) {
-        for (int i = 0; i < 4; ++i) g_bw_stamps[(size_t)blk * 8 + i] = acc_[i];
-        g_bw_stamps[(size_t)blk * 8 + 7] = first_;
+        for (int i = 0; i < 4; ++i) g_bw_stamps[(size_t)blockIdx.x * 8 + i] = acc_[i];
+        g_bw_stamps[(size_t)blockIdx.x * 8 + 6] = nblk_;
+        g_bw_stamps[(size_t)blockIdx.x * 8 + 7] = first_;
     }
 #endif
 }
@@ -393,6 +459,9 @@ int blockwin_plan(spal_csr *a) {
     SPAL_HIP_TRY(hipMemcpyAsync(first.data(), d_first.p, first.size() * 4, hipMemcpyDeviceToHost, a->stream));
     SPAL_HIP_TRY(hipStreamSynchronize(a->stream));
     const size_t esz = (size_t)a->elem_size;
+    int cu_count = 0;
+    SPAL_HIP_TRY(hipDeviceGetAttribute(&cu_count, hipDeviceAttributeMultiprocessorCount, a->device));
+    const uint32_t cus = (uint32_t)std::max(cu_count, 8);
     // units = 8, 4, 2, 1 with the window in LDS; when none fits (columns anywhere): blocks of 2048 rows, x gathered from memory
     for (int attempt = 0; attempt < 5; ++attempt) {
         const bool windowed = attempt < 4;
@@ -411,14 +480,20 @@ int blockwin_plan(spal_csr *a) {
         }
         const uint32_t win_cols = windowed ? std::max(256u, (widest + 255u) & ~255u) : 0u;
         if (bw_lds_bytes(RB, win_cols, esz) > kBwLdsMax) continue;
+        if ((size_t)win_cols * esz > (size_t)kBwWinRegs * 16 * kBwThreads || RB + 1 > kBwRpRegs * kBwThreads) continue;   // (what a walk prefetches)
         const uint32_t per_xcd = (nb + 7u) / 8u;
+        const uint32_t J = std::max(1u, std::min(per_xcd, cus / 8u));   // resident workgroups per XCD
         std::vector<uint32_t> order((size_t)per_xcd * 8u, 0xffffffffu), part, rec((size_t)per_xcd * 8u * 8u, 0xffffffffu);
         auto entries = [&](uint32_t b) { return first[std::min(nunits, (b + 1) * units)] - first[b * units]; };
         for (uint32_t k = 0; k < 8u; ++k) {
             part.clear();
             for (uint32_t b = k * per_xcd; b < std::min(nb, (k + 1) * per_xcd); ++b) part.push_back(b);
             std::stable_sort(part.begin(), part.end(), [&](uint32_t p, uint32_t q) { return entries(p) > entries(q); });
-            for (size_t i = 0; i < part.size(); ++i) order[i * 8u + k] = part[i];
+            // dealt back and forth over the XCD's J resident workgroups: walk j holds list places j, j + J, j + 2 J, ...
+            for (size_t i = 0; i < part.size(); ++i) {
+                const size_t r = i / J, pos = i % J, m = std::min<size_t>(J, part.size() - r * J);
+                order[i * 8u + k] = part[r * J + ((r & 1u) ? m - 1u - pos : pos)];
+            }
         }
         for (size_t i = 0; i < order.size(); ++i) {   // 32-byte records in dealing order
             const uint32_t b = order[i];
@@ -432,17 +507,18 @@ int blockwin_plan(spal_csr *a) {
         a->bw_blocks = nb;
         a->bw_rows = RB;
         a->bw_cols = win_cols;
+        a->bw_grid = 8u * J;
         return SPAL_OK;
     }
     return SPAL_OK;
 }
 
-template <typename T, bool WIN>
+template <typename T, bool WIN, bool PRE>
 static hipError_t bw_launch_t(const spal_csr *a, const void *x, void *y, hipStream_t st) {
     static std::atomic<uint64_t> configured{0};   // devices on which this instantiation's LDS cap has been raised
     const uint64_t bit = 1ull << (a->device & 63);
     if (!(configured.load(std::memory_order_relaxed) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(csr_spmv_blockwin<T, WIN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(csr_spmv_blockwin<T, WIN, PRE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBwLdsMax);
         if (e != hipSuccess) return e;
         configured.fetch_or(bit, std::memory_order_relaxed);
@@ -453,40 +529,46 @@ static hipError_t bw_launch_t(const spal_csr *a, const void *x, void *y, hipStre
     static uint32_t st_for = 0, calls = 0;
     if (st_for < a->bw_blocks) {
         if (d_st) (void)hipFree(d_st);
-        if (hipMalloc((void **)&d_st, (size_t)a->bw_blocks * 64) != hipSuccess) return hipErrorOutOfMemory;
+        if (hipMalloc((void **)&d_st, (size_t)a->bw_blocks * 64 + 4096 * 64) != hipSuccess) return hipErrorOutOfMemory;
         st_for = a->bw_blocks;
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bw_stamps), &d_st, sizeof(d_st));
     }
-    (void)hipMemsetAsync(d_st, 0, (size_t)a->bw_blocks * 64, st);
+    (void)hipMemsetAsync(d_st, 0, (size_t)a->bw_grid * 64, st);
 #endif
-    hipLaunchKernelGGL((csr_spmv_blockwin<T, WIN>), dim3((a->bw_blocks + 7u) / 8u * 8u), dim3(kBwThreads), lds, st, a->d_rowptr, a->d_colind,
+    hipLaunchKernelGGL((csr_spmv_blockwin<T, WIN, PRE>), dim3(a->bw_grid), dim3(kBwThreads), lds, st, a->d_rowptr, a->d_colind,
                        (const T *)a->d_values, (const T *)x, (T *)y, a->d_bworder, (uint32_t)a->nrows, (uint32_t)a->ncols,
-                       a->bw_rows, a->bw_blocks, a->bw_cols);
+                       a->bw_rows, a->bw_blocks, a->bw_cols, (a->bw_blocks + 7u) / 8u);
 #ifdef SPAL_BW_STAMPS
     if (++calls % 16 == 0) {
-        std::vector<unsigned long long> h((size_t)a->bw_blocks * 8);
+        std::vector<unsigned long long> h((size_t)a->bw_grid * 8);
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
-        double sum[4] = {0, 0, 0, 0}, tot_max = 0;
+        double sum[4] = {0, 0, 0, 0}, tot_max = 0, tot_min = 1e30, nb = 0;
         unsigned long long first = ~0ull, last = 0;
-        for (uint32_t b = 0; b < a->bw_blocks; ++b) {
+        for (uint32_t b = 0; b < a->bw_grid; ++b) {
+            if (!h[(size_t)b * 8 + 6]) continue;
             double tot = 0;
             for (int i = 0; i < 4; ++i) { sum[i] += (double)h[(size_t)b * 8 + i]; tot += (double)h[(size_t)b * 8 + i]; }
-            tot_max = std::max(tot_max, tot);
+            tot_max = std::max(tot_max, tot); tot_min = std::min(tot_min, tot);
+            nb += (double)h[(size_t)b * 8 + 6];
             first = std::min(first, h[(size_t)b * 8 + 7]);
             last = std::max(last, h[(size_t)b * 8 + 7] + (unsigned long long)tot);
         }
-        fprintf(stderr, "[spal blockwin stamps] %u blocks, kernel %.1f us; mean us per block: window + first loads %.2f, first pass's products %.2f, phases %.2f, "
-                "(unused) %.2f; longest block %.2f\n", a->bw_blocks, (double)(last - first) / 100.0, sum[0] / a->bw_blocks / 100.0,
-                sum[1] / a->bw_blocks / 100.0, sum[2] / a->bw_blocks / 100.0, sum[3] / a->bw_blocks / 100.0, tot_max / 100.0);
+        fprintf(stderr, "[spal blockwin stamps] %.0f blocks by %u workgroups, kernel %.1f us; mean us per block: window + first loads %.2f, first pass's "
+                "products %.2f, phases %.2f, (unused) %.2f; a workgroup's walk: %.1f ... %.1f us\n", nb, a->bw_grid, (double)(last - first) / 100.0,
+                sum[0] / nb / 100.0, sum[1] / nb / 100.0, sum[2] / nb / 100.0, sum[3] / nb / 100.0, tot_min / 100.0, tot_max / 100.0);
     }
 #endif
     return hipGetLastError();
 }
 
 hipError_t blockwin_launch(const spal_csr *a, const void *x, void *y, hipStream_t st) {
-    if (a->bw_cols) return a->elem_size == 8 ? bw_launch_t<double, true>(a, x, y, st) : bw_launch_t<float, true>(a, x, y, st);
-    return a->elem_size == 8 ? bw_launch_t<double, false>(a, x, y, st) : bw_launch_t<float, false>(a, x, y, st);
+    if (a->bw_cols) {
+        if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0)   // (the windows begin at multiples of 256 columns)
+            return a->elem_size == 8 ? bw_launch_t<double, true, true>(a, x, y, st) : bw_launch_t<float, true, true>(a, x, y, st);
+        return a->elem_size == 8 ? bw_launch_t<double, true, false>(a, x, y, st) : bw_launch_t<float, true, false>(a, x, y, st);
+    }
+    return a->elem_size == 8 ? bw_launch_t<double, false, false>(a, x, y, st) : bw_launch_t<float, false, false>(a, x, y, st);
 }
 
 }  // namespace spal
