@@ -6,12 +6,13 @@
 // what a lane may sum sends the tile elsewhere.  Power-law row lengths (mean 10, 0.7 % of the rows above 128 entries holding a
 // fifth of the entries) made that 0.18 of the roofline; the row split (A = A_short + A_long) 0.255: its short part still
 // walks ragged tiles, its long rows gather x through the vector memory path (~4 clocks per gathered line and CU).  Here the
-// ENTRIES are the unit of work, whatever row they belong to (0.45 - 0.46 on the same matrix):
-//   * a workgroup of 1024 threads takes a block of RB consecutive rows (512 ... 4096, the plan's choice) whose columns span at
-//     most what LDS holds beside the rest (~12 000 columns of f64): the window of x is staged ONCE per block -- every gather of
-//     the block, short row or long, is an LDS read.  Blocks are dealt by XCD (an eighth of the matrix each: neighbours share
-//     most of their windows and one L2) and, inside an XCD, most entries first; all a workgroup needs to know about its block
-//     is one 32-byte record;
+// ENTRIES are the unit of work, whatever row they belong to (0.47 - 0.48 on the same matrix):
+//   * a workgroup of 1024 threads takes a block of RB consecutive rows at a time (512 ... 4096, the plan's choice) whose columns
+//     span at most what LDS holds beside the rest (~12 000 columns of f64): the window of x is staged ONCE per block -- every
+//     gather of the block, short row or long, is an LDS read.  The grid is RESIDENT, a workgroup per CU: it walks ~4 blocks of
+//     its XCD's eighth of the matrix (neighbours share most of their windows and one L2; the plan deals the blocks longest
+//     first, each to the walk with the least work so far) with the NEXT block's window and row pointers on their way into
+//     registers while the current block's passes go by; all it needs to know about a block is one 32-byte record;
 //   * the block's entries go by in passes of kBwPass = 3072 (three per thread, coalesced, requested two passes ahead and
 //     unconditionally, so that the waits are counted): every entry's product -- rounded once, as in the reference -- lands in
 //     one of two strips in LDS in entry order;
@@ -22,9 +23,9 @@
 //     the other eight waves take the listed rows, 16 lanes per row (a whole wave above 512 entries inside the pass): strided
 //     partial sums and a DPP tree (1e-10), carried across passes the same way.
 // One row is open at the end of a pass at most; its running sum waits in one of two carry slots (by pass parity).
-// What bounds it (lab build -DSPAL_BW_STAMPS, per block of 20.9K entries: window + first loads 4.4 us, phases 13 us): LDS --
-// one gather, one strip write and one strip read per entry plus the conflicts of the threads' row walks are ~1 clock per entry
-// of the CU's one LDS pipe -- and the window, staged behind a barrier by the CU's only workgroup.
+// What bounds it (lab build -DSPAL_BW_STAMPS, per block of 20.9K entries: block change 2.7 us + first pass 1.9 us, phases 13 us):
+// LDS -- one gather, one strip write and one strip read per entry plus the conflicts of the threads' row walks are ~1 clock per
+// entry of the CU's one LDS pipe -- and the spread of the walks' ends (54 ... 75 us although their entry counts are equal).
 // Chosen at setup by time against the row split (spal_csr.hip: csr_plan_build); option "blockwin" -1 / 0 / 1.
 #include <algorithm>
 #include <atomic>
@@ -483,18 +484,29 @@ int blockwin_plan(spal_csr *a) {
         if ((size_t)win_cols * esz > (size_t)kBwWinRegs * 16 * kBwThreads || RB + 1 > kBwRpRegs * kBwThreads) continue;   // (what a walk prefetches)
         const uint32_t per_xcd = (nb + 7u) / 8u;
         const uint32_t J = std::max(1u, std::min(per_xcd, cus / 8u));   // resident workgroups per XCD
-        std::vector<uint32_t> order((size_t)per_xcd * 8u, 0xffffffffu), part, rec((size_t)per_xcd * 8u * 8u, 0xffffffffu);
+        // Every XCD's eighth of the blocks is dealt to its J walks longest first, each block to the walk with the least work so
+        // far (a block costs its entries + what changing blocks costs, ~8000 entries' worth): the walks end within a block's
+        // fraction of each other.  Walk j's r-th block is record (r * J + j) * 8 + XCD; a walk ends at its first padded record.
         auto entries = [&](uint32_t b) { return first[std::min(nunits, (b + 1) * units)] - first[b * units]; };
+        std::vector<std::vector<uint32_t>> walks((size_t)8u * J);
+        std::vector<uint32_t> part;
+        uint32_t rows = 1;
         for (uint32_t k = 0; k < 8u; ++k) {
             part.clear();
             for (uint32_t b = k * per_xcd; b < std::min(nb, (k + 1) * per_xcd); ++b) part.push_back(b);
             std::stable_sort(part.begin(), part.end(), [&](uint32_t p, uint32_t q) { return entries(p) > entries(q); });
-            // dealt back and forth over the XCD's J resident workgroups: walk j holds list places j, j + J, j + 2 J, ...
-            for (size_t i = 0; i < part.size(); ++i) {
-                const size_t r = i / J, pos = i % J, m = std::min<size_t>(J, part.size() - r * J);
-                order[i * 8u + k] = part[r * J + ((r & 1u) ? m - 1u - pos : pos)];
+            std::vector<uint64_t> load(J, 0);
+            for (uint32_t b : part) {
+                const uint32_t j = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
+                load[j] += (uint64_t)entries(b) + 8000u;
+                walks[(size_t)k * J + j].push_back(b);
+                rows = std::max<uint32_t>(rows, (uint32_t)walks[(size_t)k * J + j].size());
             }
         }
+        std::vector<uint32_t> order((size_t)rows * J * 8u, 0xffffffffu), rec((size_t)rows * J * 8u * 8u, 0xffffffffu);
+        for (uint32_t k = 0; k < 8u; ++k)
+            for (uint32_t j = 0; j < J; ++j)
+                for (size_t r = 0; r < walks[(size_t)k * J + j].size(); ++r) order[(r * J + j) * 8u + k] = walks[(size_t)k * J + j][r];
         for (size_t i = 0; i < order.size(); ++i) {   // 32-byte records in dealing order
             const uint32_t b = order[i];
             if (b == 0xffffffffu) continue;
@@ -508,6 +520,7 @@ int blockwin_plan(spal_csr *a) {
         a->bw_rows = RB;
         a->bw_cols = win_cols;
         a->bw_grid = 8u * J;
+        a->bw_list_rows = rows * J;
         return SPAL_OK;
     }
     return SPAL_OK;
@@ -537,7 +550,7 @@ static hipError_t bw_launch_t(const spal_csr *a, const void *x, void *y, hipStre
 #endif
     hipLaunchKernelGGL((csr_spmv_blockwin<T, WIN, PRE>), dim3(a->bw_grid), dim3(kBwThreads), lds, st, a->d_rowptr, a->d_colind,
                        (const T *)a->d_values, (const T *)x, (T *)y, a->d_bworder, (uint32_t)a->nrows, (uint32_t)a->ncols,
-                       a->bw_rows, a->bw_blocks, a->bw_cols, (a->bw_blocks + 7u) / 8u);
+                       a->bw_rows, a->bw_blocks, a->bw_cols, a->bw_list_rows);
 #ifdef SPAL_BW_STAMPS
     if (++calls % 16 == 0) {
         std::vector<unsigned long long> h((size_t)a->bw_grid * 8);

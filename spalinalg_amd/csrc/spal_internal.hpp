@@ -234,6 +234,7 @@ struct spal_csr {
     // BLOCK WINDOW kernel (spal_csr_blockwin.hip): blocks of bw_rows rows, a window of at most bw_cols columns each; bw_on: the products run it
     uint32_t *d_bworder = nullptr; // 32-byte records {block, first entry, one past the last, window's first column, columns, -, -, -} in the order the blocks are dealt
     uint32_t bw_blocks = 0, bw_rows = 0, bw_cols = 0, bw_grid = 0;   // (bw_grid: resident workgroups, 8 x the walks per XCD)
+    uint32_t bw_list_rows = 0;     // rows of 8 records in d_bworder (a walk's blocks are J rows apart)
     int bw_on = 0;
     float bw_us[2] = {0.f, 0.f};   // setup: per product {what it was timed against, the block-window kernel}
     int plan_pending = 0;          // a device-assembled handle: the product kernels' plan is built by whoever needs it first (csr_ensure_plan)
