@@ -77,7 +77,7 @@ def test_random_matrices_all_planner_paths(oracle, seed):
     d = dev.describe()
     assert_spmv_close(dev.spmv(x), y_ref, bound, TOL[va.dtype])
     if d["kernel"] == "blockwin":       # skewed rows near the diagonal: the block-window kernel won against the split at setup
-        assert d["setup_us"][1] < d["setup_us"][0], d
+        assert d["setup_us"][1] <= d["setup_us"][0], d          # (printed to 0.1 us)
         dev.set_option("blockwin", 0)
         d = dev.describe()
         assert d["kernel"] == "split", d

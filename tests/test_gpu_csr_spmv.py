@@ -1188,7 +1188,7 @@ def test_block_window_kernel_on_power_law_rows(oracle, dtype):
     da = dev.describe()
     assert da["kernel"] in ("blockwin", "split"), da
     if da["kernel"] == "blockwin":
-        assert 0 < da["setup_us"][1] < da["setup_us"][0], da
+        assert 0 < da["setup_us"][1] <= da["setup_us"][0], da
     assert_spmv_close(dev.spmv(x), y_ref, bound, tol)
     dev.set_option("blockwin", 0)
     assert dev.describe()["kernel"] == "split"
