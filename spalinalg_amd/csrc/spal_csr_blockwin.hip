@@ -463,8 +463,31 @@ int blockwin_plan(spal_csr *a) {
     int cu_count = 0;
     SPAL_HIP_TRY(hipDeviceGetAttribute(&cu_count, hipDeviceAttributeMultiprocessorCount, a->device));
     const uint32_t cus = (uint32_t)std::max(cu_count, 8);
-    // units = 8, 4, 2, 1 with the window in LDS; when none fits (columns anywhere): blocks of 2048 rows, x gathered from memory
-    for (int attempt = 0; attempt < 5; ++attempt) {
+    // units = 8, 4, 2, 1 with the window in LDS; when none fits (columns anywhere): blocks of 2048 rows, x gathered from memory.
+    // The TALLEST block that fits stages its window for the most entries -- but the walks want three blocks per CU and more
+    // (250 000 rows of 400 entries in blocks of 4096 rows are 61 blocks for 256 CUs: 0.16 of the roofline): the tallest height with
+    // that many blocks, else the lowest that fits.
+    auto fits = [&](uint32_t units, uint32_t *nb_out) {
+        const uint32_t RB = units * kBwUnit, nb = (uint32_t)((a->nrows + RB - 1) / RB);
+        uint32_t widest = 0;
+        for (uint32_t b = 0; b < nb; ++b) {
+            uint32_t lo = 0xffffffffu, hi = 0;
+            for (uint32_t u = b * units; u < std::min(nunits, (b + 1) * units); ++u) { lo = std::min(lo, win[u].x); hi = std::max(hi, win[u].y); }
+            if (hi > lo) widest = std::max(widest, hi - (lo & ~255u));
+        }
+        const uint32_t win_cols = std::max(256u, (widest + 255u) & ~255u);
+        *nb_out = nb;
+        return bw_lds_bytes(RB, win_cols, esz) <= kBwLdsMax && (size_t)win_cols * esz <= (size_t)kBwWinRegs * 16 * kBwThreads &&
+               RB + 1 <= kBwRpRegs * kBwThreads;
+    };
+    int first_attempt = 4;   // (4: the window-less form)
+    for (int at = 0; at < 4; ++at) {
+        uint32_t nb = 0;
+        if (!fits(8u >> at, &nb)) continue;
+        first_attempt = at;                  // the lowest height that fits so far ...
+        if (nb >= 3u * cus) break;           // ... and the tallest with blocks enough
+    }
+    for (int attempt = first_attempt; attempt < 5; ++attempt) {
         const bool windowed = attempt < 4;
         const uint32_t units = windowed ? (8u >> attempt) : 4u;
         const uint32_t RB = units * kBwUnit;

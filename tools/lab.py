@@ -1582,9 +1582,19 @@ def zoo():
             if d["kernel"] == "split":
                 name = name + f" [split: {d['split_long_rows']} long rows]"
                 d = d["short_part"]
-            print(f"{name:52s} nnz {nnz:>10d}  {t*1e3:8.1f} us -> autotuned {t2*1e3:8.1f} us = {100*B/(t2*1e-3)/8e12:5.1f} % of 8 TB/s  "
-                  f"[{d['kernel']} rpt={d['rows_per_tile']} stream={d['stream_row_fraction']:.2f} lds={d['lds_row_fraction']:.2f} "
-                  f"win={d['lds_window_bytes']//1024}K pers={d['persistent']}]  (host {time.time()-t0:.0f} s)", flush=True)
+            if d["kernel"] == "blockwin":
+                print(f"{name:52s} nnz {nnz:>10d}  {t*1e3:8.1f} us -> autotuned {t2*1e3:8.1f} us = {100*B/(t2*1e-3)/8e12:5.1f} % of 8 TB/s  "
+                      f"[blockwin rows={d['block_rows']} window={d['window_columns']}]  (host {time.time()-t0:.0f} s)", flush=True)
+            else:
+                print(f"{name:52s} nnz {nnz:>10d}  {t*1e3:8.1f} us -> autotuned {t2*1e3:8.1f} us = {100*B/(t2*1e-3)/8e12:5.1f} % of 8 TB/s  "
+                      f"[{d['kernel']} rpt={d['rows_per_tile']} stream={d['stream_row_fraction']:.2f} lds={d['lds_row_fraction']:.2f} "
+                      f"win={d['lds_window_bytes']//1024}K pers={d['persistent']}]  (host {time.time()-t0:.0f} s)", flush=True)
+                # the block-window kernel by name on the same matrix (development: where else would it win?)
+                dev.set_option("blockwin", 1)
+                db = dev.describe()
+                if db["kernel"] == "blockwin":
+                    tb = timeit(lambda: dev.spmv_torch(x, out=y))
+                    print(f"{'':52s}     block-window kernel by name: {tb*1e3:8.1f} us = {100*B/(tb*1e-3)/8e12:5.1f} %  [rows={db['block_rows']} window={db['window_columns']}]", flush=True)
             del dev
 
     if True:  # (was the script's __main__ block)
