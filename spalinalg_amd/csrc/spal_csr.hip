@@ -1450,7 +1450,7 @@ int csr_plan_build(spal_csr *a) {
         if (a->split_short) { csr_free(a->split_short); a->split_short = nullptr; }
         (void)dev_free(a->d_split_rows); a->d_split_rows = nullptr;
         a->split_nlong = 0;
-        SPAL_TRY(blockwin_plan(a));
+        if (blockwin_plan(a) != SPAL_OK) { blockwin_free(a); (void)hipGetLastError(); }   // (an optional form: without it the plan below)
         if (a->bw_rows) { a->bw_on = 1; a->plan.kernel = 4; return SPAL_OK; }
     }
     {
