@@ -1211,6 +1211,64 @@ def test_block_window_kernel_on_power_law_rows(oracle, dtype):
     assert np.array_equal(y2[rl2 <= 32].view(bits), y2_ref[rl2 <= 32].view(bits))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_block_window_kernel_edge_shapes(oracle, dtype):
+    """The block-window kernel on shapes its passes and walks could trip over: a row that spans many passes among rows of one to
+    three entries, a dense row in a matrix of an odd number of columns (the window ends inside a 16-byte vector), blocks without
+    entries, a last block of a few rows, x 16-byte aligned and not."""
+    import torch
+    rng = np.random.default_rng(21)
+    tol = 1e-10 if dtype == np.float64 else 1e-4
+    bits = np.uint64 if dtype == np.float64 else np.uint32
+    cases = []
+    # (a) 5000 rows, one of 6000 entries (two passes), the rest 1 ... 3 entries near it; 50 001 columns (ten per row: a block of
+    # 512 rows spans 11 000)
+    lens = rng.integers(1, 4, 5000)
+    lens[2500] = 6000
+    cases.append((5000, 50_001, lens, 6000))
+    # (a') the same with a row of 40 000 entries (14 passes): wider than any window -- the window-less form
+    lens = rng.integers(1, 4, 5000)
+    lens[2500] = 40_000
+    cases.append((5000, 50_001, lens, 40_000))
+    # (b) 700 rows x 701 columns: ten empty rows, a dense row, short rows; the second block holds 188 rows
+    lens = rng.integers(0, 6, 700)
+    lens[:10] = 0
+    lens[10] = 701
+    cases.append((700, 701, lens, 701))
+    # (c) 3000 rows of which only the last 100 hold entries (five blocks of 512 without any)
+    lens = np.zeros(3000, np.int64)
+    lens[-100:] = rng.integers(1, 200, 100)
+    cases.append((3000, 4099, lens, 600))
+    for n, nc, lens, spread in cases:
+        ci = []
+        for r, k in enumerate(lens):
+            k = int(min(k, nc))
+            lo = max(0, min(nc - min(spread, nc), int(r * nc / n) - spread // 2))
+            ci.append(lo + np.sort(rng.choice(min(spread, nc - lo), k, replace=False)))
+        lens2 = np.array([c.size for c in ci])
+        rp = np.concatenate([[0], np.cumsum(lens2)]).astype(np.uint64)
+        ci = np.concatenate(ci).astype(np.uint64)
+        va = rng.uniform(-1, 1, ci.size).astype(dtype)
+        x = rng.uniform(-1, 1, nc).astype(dtype)
+        y_ref = oracle.csr_spmv(rp, ci, va, x)
+        bound = oracle.csr_abs_bound(rp, ci, va.astype(np.float64), x.astype(np.float64))
+        dev = sp.CsrMatrix(n, nc, rp, ci, va).device()
+        dev.set_option("blockwin", 1)
+        d = dev.describe()
+        assert d["kernel"] == "blockwin" and (d["window_columns"] > 0) == (spread <= 6000), d
+        y = dev.spmv(x)
+        assert_spmv_close(y, y_ref, bound, tol)
+        assert np.array_equal(y[lens2 <= 32].view(bits), y_ref[lens2 <= 32].view(bits)), d
+        # the same through the device entry point with x at an address that is not a multiple of 16
+        xo = torch.empty(nc + 3, dtype=torch.from_numpy(x).dtype, device="cuda")[(1 if dtype == np.float64 else 3):][:nc]
+        assert xo.data_ptr() % 16 != 0
+        xo.copy_(torch.from_numpy(x))
+        yo = torch.full((n,), float("nan"), dtype=xo.dtype, device="cuda")
+        dev.spmv_dev(xo.data_ptr(), yo.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(yo.cpu().numpy().view(bits), y.view(bits))
+
+
 def test_device_copy_is_a_handle_of_its_own(oracle):
     """`device()` caches ONE handle per matrix and device; `device_copy()` uploads again -- what a benchmark rotates its
     launches over, so that a matrix below the Infinity Cache's 256 MB is not served from it (bench.py, configs 2 and 4)."""
