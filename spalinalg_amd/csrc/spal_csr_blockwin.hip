@@ -24,8 +24,9 @@
 //     partial sums and a DPP tree (1e-10), carried across passes the same way.
 // One row is open at the end of a pass at most; its running sum waits in one of two carry slots (by pass parity).
 // What bounds it (lab build -DSPAL_BW_STAMPS, per block of 20.9K entries: block change 2.7 us + first pass 1.9 us, phases 13 us):
-// LDS -- one gather, one strip write and one strip read per entry plus the conflicts of the threads' row walks are ~1 clock per
-// entry of the CU's one LDS pipe -- and the spread of the walks' ends (54 ... 75 us although their entry counts are equal).
+// the chain inside a phase -- a barrier, the row search, a row's dependent sums -- on a CU that holds one workgroup (counters: the
+// LDS pipe is busy a third of the time; 1.16 x the algorithmic bytes fetched, 4.4 TB/s) and the spread of the walks' ends
+// (54 ... 75 us although their entry counts are equal).
 // Chosen at setup by time against the row split (spal_csr.hip: csr_plan_build); option "blockwin" -1 / 0 / 1.
 #include <algorithm>
 #include <atomic>
